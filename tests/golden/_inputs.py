@@ -1,0 +1,120 @@
+"""Deterministic inputs shared by the golden generator (development container only) and the tests.
+
+Everything here is seeded numpy/torch data; no reference code.  Keeping the *inputs* procedural keeps
+the committed fixtures small: `.npz` files hold the reference's OUTPUTS plus the few inputs that
+are not regenerated here.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+H480, W640 = 480, 640
+
+
+def projector_case(seed: int = 11, H: int = 96, W: int = 128):
+    rng = np.random.RandomState(seed)
+    # smooth-ish depth in metres
+    base = 3.0 + 2.0 * np.sin(np.linspace(0, 3, W))[None, :] * np.cos(np.linspace(0, 2, H))[:, None]
+    depth = np.clip(base + 0.3 * rng.randn(H, W), 0.5, 10.0).astype(np.float32)
+    xyzhe = np.array([[2.5, 1.5, 3.25, 0.35, math.pi]], dtype=np.float32)
+    vfov = 67.5 * math.pi / 180.0
+    world_shift = np.array([0.25, 0.0, -0.5], dtype=np.float32)     # ProjectorUtils.world_shift_origin
+    map_shift = np.array([-5.0, 0.0, -5.0], dtype=np.float32)       # map_world_shift
+    return dict(depth=depth, xyzhe=xyzhe, vfov=vfov, world_shift=world_shift, map_shift=map_shift,
+                cell=0.02 * 10, map_w=60, map_h=50)
+
+
+def memory_state_case(seed: int = 5, n_cells: int = 300):
+    g = torch.Generator().manual_seed(seed)
+    mem = torch.randn((n_cells, 512), generator=g) * 20.0
+    obs = torch.randint(0, 5, (n_cells,), generator=g).to(torch.float32)
+    return mem, obs
+
+
+def instance_masks_case(seed: int = 9, K: int = 6, H: int = H480, W: int = W640, n_cells: int = 300):
+    """K elliptical instance masks (overlapping), 512-d features, a proj index image."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((K, H, W), dtype=bool)
+    for k in range(K):
+        cy, cx = rng.uniform(0.2 * H, 0.8 * H), rng.uniform(0.2 * W, 0.8 * W)
+        ry, rx = rng.uniform(20, 90), rng.uniform(20, 120)
+        masks[k] = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+    feats = (rng.randn(K, 512) * 3.0).astype(np.float32)
+    # piecewise-constant projection image with some noise, values in [0, n_cells)
+    proj = ((yy // 24) * 14 + (xx // 46)) % n_cells
+    noise = rng.randint(0, n_cells, size=(H, W))
+    proj = np.where(rng.rand(H, W) < 0.05, noise, proj).astype(np.int64)
+    return torch.from_numpy(masks), torch.from_numpy(feats), torch.from_numpy(proj)
+
+
+def fpn_case(seed: int = 3, H: int = 64, W: int = 96, n_cells: int = 300):
+    """Bottom-up features C3..C5 for an HxW image, fp16 memory, proj indices, random FPN weights."""
+    g = torch.Generator().manual_seed(seed)
+    c3 = torch.randn((1, 512, H // 8, W // 8), generator=g)
+    c4 = torch.randn((1, 1024, H // 16, W // 16), generator=g)
+    c5 = torch.randn((1, 2048, H // 32, W // 32), generator=g)
+    mem = (torch.randn((n_cells, 512), generator=g) * 10.0)
+    mem = 50.0 * torch.nn.functional.normalize(mem, dim=1)
+    mem[::7] = 0
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    # make it blocky so neighbouring pixels often share a cell (like real projections)
+    blocky = (torch.arange(H)[:, None] // 5) * 13 + (torch.arange(W)[None, :] // 7)
+    proj = torch.where(torch.rand((H, W), generator=g) < 0.7, blocky % n_cells, proj).to(torch.int64)
+    return c3, c4, c5, mem, proj
+
+
+def fpn_weights(seed: int = 4):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rn(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    for lvl, cin in ((3, 512), (4, 1024), (5, 2048)):
+        sd[f"backbone.fpn_lateral{lvl}.weight"] = rn(256, cin, 1, 1, std=(1.0 / cin) ** 0.5)
+        sd[f"backbone.fpn_lateral{lvl}.bias"] = rn(256, std=0.1)
+        sd[f"backbone.fpn_output{lvl}.weight"] = rn(256, 256, 3, 3, std=(1.0 / 2304) ** 0.5)
+        sd[f"backbone.fpn_output{lvl}.bias"] = rn(256, std=0.1)
+    for n in ("p6", "p7"):
+        sd[f"backbone.top_block.{n}.weight"] = rn(256, 256, 3, 3, std=(1.0 / 2304) ** 0.5)
+        sd[f"backbone.top_block.{n}.bias"] = rn(256, std=0.1)
+    for i in (1, 2, 3):
+        sd[f"backbone.map_merge_projection{i}.weight"] = rn(256, 512, 1, 1, std=(1.0 / 512) ** 0.5 * 0.05)
+        sd[f"backbone.map_merge_projection{i}.bias"] = rn(256, std=0.01)
+    return sd
+
+
+def centernet_head_case(seed: int = 6):
+    g = torch.Generator().manual_seed(seed)
+    feats = [torch.randn((1, 256, h, w), generator=g) for (h, w) in ((8, 12), (4, 6), (2, 3), (1, 2), (1, 1))]
+    return feats
+
+
+def centernet_head_weights(seed: int = 7):
+    g = torch.Generator().manual_seed(seed)
+    h = "proposal_generator.centernet_head"
+    sd = {}
+    for i in range(4):
+        sd[f"{h}.bbox_tower.{3 * i}.weight"] = torch.randn((256, 256, 3, 3), generator=g) * 0.03
+        sd[f"{h}.bbox_tower.{3 * i}.bias"] = torch.randn((256,), generator=g) * 0.1
+        sd[f"{h}.bbox_tower.{3 * i + 1}.weight"] = torch.rand((256,), generator=g) + 0.5
+        sd[f"{h}.bbox_tower.{3 * i + 1}.bias"] = torch.randn((256,), generator=g) * 0.1
+    sd[f"{h}.bbox_pred.weight"] = torch.randn((4, 256, 3, 3), generator=g) * 0.03
+    sd[f"{h}.bbox_pred.bias"] = torch.full((4,), 2.0)
+    sd[f"{h}.agn_hm.weight"] = torch.randn((1, 256, 3, 3), generator=g) * 0.03
+    sd[f"{h}.agn_hm.bias"] = torch.full((1,), -2.0)
+    for l in range(5):
+        sd[f"{h}.scales.{l}.scale"] = torch.tensor([0.8 + 0.1 * l])
+    return sd
+
+
+def zs_case(seed: int = 8, R: int = 17):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((R, 1024), generator=g)
+    w = torch.randn((512, 1024), generator=g) * (1.0 / 1024) ** 0.5
+    b = torch.randn((512,), generator=g) * 0.1
+    return x, w, b

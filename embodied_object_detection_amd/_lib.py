@@ -1,0 +1,133 @@
+"""ctypes binding of libeod_hip.so (C ABI declared in include/eod_hip.h).
+
+Fails loudly: there is no CPU fallback.  If the shared library is missing or a call returns a negative
+EOD_ERR_* code, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libeod_hip.so")
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_void_p = C.c_void_p
+
+
+class EodError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "EOD_ERR_BAD_DIMS", -2: "EOD_ERR_ALIGN", -3: "EOD_ERR_LAUNCH", -4: "EOD_ERR_NULL", -5: "EOD_ERR_CAPACITY"}
+
+
+class EodConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("m_count", C.c_void_p), ("m_unit", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("Kpad", C.c_int32), ("relu", C.c_int32), ("res_mode", C.c_int32), ("in_relu", C.c_int32),
+        ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
+        ("out_scale", C.c_float),
+    ]
+
+
+class EodProposalDesc(C.Structure):
+    _fields_ = [
+        ("head_out", C.c_void_p), ("head_stride", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 6),
+        ("level_w", C.c_int32 * 5), ("level_stride", C.c_int32 * 5), ("level_scale", C.c_float * 5),
+        ("score_thresh", C.c_float), ("pre_nms_topk", C.c_int32), ("post_nms_topk", C.c_int32), ("nms_thresh", C.c_float),
+        ("cap", C.c_int32), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_count", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class EodDetDesc(C.Structure):
+    _fields_ = [
+        ("boxes", C.c_void_p), ("scores", C.c_void_p), ("count", C.c_void_p), ("R_cap", C.c_int32), ("C1", C.c_int32),
+        ("img_w", C.c_float), ("img_h", C.c_float), ("score_thresh", C.c_float), ("nms_thresh", C.c_float),
+        ("topk", C.c_int32), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_classes", C.c_void_p),
+        ("out_rows", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class EodMemWriteDesc(C.Structure):
+    _fields_ = [
+        ("featn", C.c_void_p), ("prop_boxes", C.c_void_p), ("prop_masks", C.c_void_p), ("det_rows", C.c_void_p),
+        ("det_count", C.c_void_p), ("K_cap", C.c_int32), ("R_cap", C.c_int32), ("proj", C.c_void_p),
+        ("H", C.c_int32), ("W", C.c_int32), ("D", C.c_int32), ("n_cells", C.c_int32), ("mask_thresh", C.c_float),
+        ("mem", C.c_void_p), ("obs", C.c_void_p), ("k_out", C.c_void_p), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/eod_hip.h declares
+SIGNATURES = {
+    "eod_abi_version": (C.c_int, []),
+    "eod_conv2d": (C.c_int, [C.POINTER(EodConvDesc), C.c_void_p]),
+    "eod_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(EodConvDesc)]),
+    "eod_preprocess_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
+    "eod_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "eod_groupnorm_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int, C.c_void_p]),
+    "eod_roi_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),
+    "eod_zs_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_float, C.c_void_p]),
+    "eod_apply_deltas": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "eod_cascade_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "eod_detections_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "eod_fast_rcnn_inference": (C.c_int, [C.POINTER(EodDetDesc), C.c_void_p]),
+    "eod_detector_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
+    "eod_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  C.c_void_p, C.c_void_p]),
+    "eod_unproject_grid_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eod_memory_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "eod_memory_gather_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p]),
+    "eod_memory_write_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "eod_memory_write_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "eod_memory_write": (C.c_int, [C.POINTER(EodMemWriteDesc), C.c_void_p]),
+    "eod_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]),
+    "eod_fill_i32": (C.c_int, [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise if it is not built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EodError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m embodied_object_detection_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise EodError(f"{what} failed: {_ERR.get(status, status)}")

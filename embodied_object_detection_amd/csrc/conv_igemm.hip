@@ -1,0 +1,376 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   y[m][n] = act( (sum_k A[m][k] * Wt[n][k] + bias[n]) * out_scale + res[m][n] )
+//
+// A[m][k] is the im2col view of the NHWC input: m = (img, oy, ox), k = (ky, kx, c) with c fastest, so a
+// 32-wide K chunk is 128 contiguous bytes of one input pixel.  Wt is [Cout][Kpad] (K fastest), which makes
+// both operand tiles "row = m or n, 32 contiguous k": they are staged through LDS as [rows][36] floats (the +4
+// pad makes the 16-lane groups of ds_read_b128 conflict free) and each lane fetches 4 consecutive k of its
+// row with ONE ds_read_b128.  The MFMA k-slot <-> k mapping is a free permutation as long as A and B agree:
+// lane half h supplies k = kk*8 + 4h + t to instruction t (t = 0..3), for both operands.
+//
+// fp32 in / fp32 accumulate: the result is an exact fp32 fma chain (same numerics class as the CPU
+// reference path), the peak is the fp32 MFMA rate 157 TFLOP/s.
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile BM x BN in {128x128, 128x64, 64x64}, each wave owns
+// (BM/2) x (BN/2) as 32x32 MFMA tiles.  Global -> register prefetch of chunk c+1 overlaps the MFMAs of chunk
+// c; one LDS buffer, two barriers per chunk.  Tiles are dealt to workgroups through an XCD-aware bijective
+// remap so that the workgroups sharing an L2 walk neighbouring tiles (same weight panel / same pixel rows).
+// Small problems are split along K (grid.y) into fp32 slabs reduced by a second kernel that also applies the
+// epilogue: deterministic, no atomics.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  float* partial;
+  const int* m_count;
+  int m_unit;
+  int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad;
+  int M, nchunks, splitk, cps;
+  int relu, res_mode, in_relu, out_mode;
+  int tiles_m, tiles_n;
+  float out_scale;
+};
+
+__device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
+  int co = n;
+  size_t oidx;
+  if (p.out_mode == 1) {
+    const int Cd = p.Cout >> 2;
+    const int quad = n / Cd;
+    co = n - quad * Cd;
+    const int dy = quad >> 1, dx = quad & 1;
+    const int ox = m % p.OW;
+    const int t = m / p.OW;
+    const int oy = t % p.OH;
+    const int img = t / p.OH;
+    oidx = ((size_t)(img * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + (2 * ox + dx)) * Cd + co;
+  } else {
+    oidx = (size_t)m * p.Cout + n;
+  }
+  if (p.bias) v += p.bias[co];
+  v *= p.out_scale;
+  if (p.res_mode == 1) {
+    v += p.res[(size_t)m * p.Cout + n];
+  } else if (p.res_mode == 2) {
+    const int ox = m % p.OW;
+    const int t = m / p.OW;
+    const int oy = t % p.OH;
+    const int img = t / p.OH;
+    const int rh = p.OH >> 1, rw = p.OW >> 1;
+    v += p.res[((size_t)(img * rh + (oy >> 1)) * rw + (ox >> 1)) * p.Cout + n];
+  }
+  if (p.relu) v = fmaxf(v, 0.0f);
+  p.y[oidx] = v;
+}
+
+template <int BM, int BN, bool TAP4>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int LS = 36;  // LDS row stride in floats
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LS];
+  float* As = lds;
+  float* Bs = lds + BM * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int M = p.M;
+  if (p.m_count) {
+    const int c = *p.m_count;
+    const int lim = c * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  if (m0 >= M) return;
+
+  const int z = blockIdx.y;
+  const int c_begin = z * p.cps;
+  int c_end = c_begin + p.cps;
+  if (c_end > p.nchunks) c_end = p.nchunks;
+
+  const int lr = tid >> 3, lq = tid & 7;
+  int a_off[AR], a_iy[AR], a_ix[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lr + 32 * i;
+    if (m < M) {
+      const int ox = m % p.OW;
+      const int t2 = m / p.OW;
+      const int oy = t2 % p.OH;
+      const int img = t2 / p.OH;
+      a_iy[i] = oy * p.stride - p.pad;
+      a_ix[i] = ox * p.stride - p.pad;
+      a_off[i] = img * p.H * p.W;
+    } else {
+      a_iy[i] = -(1 << 28);
+      a_ix[i] = 0;
+      a_off[i] = 0;
+    }
+  }
+  const float* wrow[BR];
+  bool wvalid[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lr + 32 * j;
+    wvalid[j] = n < p.Cout;
+    wrow[j] = p.w + (size_t)(wvalid[j] ? n : 0) * p.Kpad + 4 * lq;
+  }
+
+  f32x4 ar[AR], br[BR];
+  auto load_chunk = [&](int chunk) {
+    const int k0 = chunk * 32;
+    if (!TAP4) {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ky = tap / p.KW;
+      const int kx = tap - ky * p.KW;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * p.W + ix) * p.Cin + c0 + 4 * lq);
+        ar[i] = v;
+      }
+    } else {
+      const int tap = chunk * 8 + lq;
+      const int ky = tap / p.KW;
+      const int kx = tap - ky * p.KW;
+      const bool tv = tap < p.KH * p.KW;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = tv && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * p.W + ix) * 4);
+        ar[i] = v;
+      }
+    }
+    if (p.in_relu) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        ar[i].x = fmaxf(ar[i].x, 0.f);
+        ar[i].y = fmaxf(ar[i].y, 0.f);
+        ar[i].z = fmaxf(ar[i].z, 0.f);
+        ar[i].w = fmaxf(ar[i].w, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wvalid[j]) v = *reinterpret_cast<const f32x4*>(wrow[j] + k0);
+      br[j] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = 4 * (lane >> 5);
+  const float* a_base = As + (wm * TM * 32 + frag_row) * LS + frag_k;
+  const float* b_base = Bs + (wn * TN * 32 + frag_row) * LS + frag_k;
+
+  load_chunk(c_begin);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + 32 * i) * LS + 4 * lq) = ar[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + 32 * j) * LS + 4 * lq) = br[j];
+    __syncthreads();
+    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LS + kk * 8);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        if (m < M && n < p.Cout) {
+          const float v = acc[i][j][r];
+          if (p.splitk > 1) {
+            p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
+          } else {
+            epilogue_store(p, v, m, n);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
+  int M = p.M;
+  if (p.m_count) {
+    const int c = *p.m_count;
+    const int lim = c * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  const size_t total = (size_t)M * p.Cout;
+  const size_t slab = (size_t)p.M * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < p.splitk; ++z) v += p.partial[z * slab + idx];
+    const int m = (int)(idx / p.Cout);
+    const int n = (int)(idx - (size_t)m * p.Cout);
+    epilogue_store(p, v, m, n);
+  }
+}
+
+struct Plan {
+  int tile;  // 1=128x128 2=128x64 3=64x64
+  int bm, bn, tiles_m, tiles_n, splitk, cps;
+};
+
+Plan make_plan(const EodConvDesc* d, int M, int nchunks) {
+  static const int cfg[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  Plan pl{};
+  int pick = 2;
+  if (d->force_tile >= 1 && d->force_tile <= 3) {
+    pick = d->force_tile - 1;
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      const int bm = cfg[c][0], bn = cfg[c][1];
+      if (bn == 128 && d->Cout <= 64) continue;
+      const long tiles = (long)((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);
+      if (tiles >= 448) { pick = c; break; }
+    }
+  }
+  pl.tile = pick + 1;
+  pl.bm = cfg[pick][0];
+  pl.bn = cfg[pick][1];
+  pl.tiles_m = (M + pl.bm - 1) / pl.bm;
+  pl.tiles_n = (d->Cout + pl.bn - 1) / pl.bn;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  int splitk = 1;
+  if (d->force_splitk > 0) {
+    splitk = d->force_splitk;
+  } else if (tiles < 256 && nchunks >= 8) {
+    int want = (int)((512 + tiles - 1) / tiles);
+    int maxs = nchunks / 4;
+    splitk = want < maxs ? want : maxs;
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > nchunks) splitk = nchunks;
+  pl.cps = (nchunks + splitk - 1) / splitk;
+  pl.splitk = (nchunks + pl.cps - 1) / pl.cps;
+  return pl;
+}
+
+int check_desc(const EodConvDesc* d) {
+  if (!d || !d->x || !d->w || !d->y) return EOD_ERR_NULL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return EOD_ERR_BAD_DIMS;
+  if (d->Kpad % 32 != 0 || d->Kpad < d->KH * d->KW * d->Cin) return EOD_ERR_BAD_DIMS;
+  if (d->tap4) {
+    if (d->Cin != 4) return EOD_ERR_BAD_DIMS;
+  } else {
+    if (d->Cin % 32 != 0 || d->Kpad != d->KH * d->KW * d->Cin) return EOD_ERR_BAD_DIMS;
+  }
+  if (d->OH != (d->H + 2 * d->pad - d->KH) / d->stride + 1) return EOD_ERR_BAD_DIMS;
+  if (d->OW != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return EOD_ERR_BAD_DIMS;
+  if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return EOD_ERR_BAD_DIMS;
+  if ((long)d->N * d->OH * d->OW * d->Cout >= (1L << 31)) return EOD_ERR_BAD_DIMS;
+  if (d->out_mode == 1 && (d->Cout % 4 != 0)) return EOD_ERR_BAD_DIMS;
+  if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
+  if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
+  if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(d->x) || !eod_aligned16(d->w)) return EOD_ERR_ALIGN;
+  return EOD_OK;
+}
+
+template <int BM, int BN>
+void launch_tile(const ConvArgs& a, bool tap4, dim3 grid, hipStream_t s) {
+  if (tap4)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" size_t eod_conv2d_workspace_bytes(const EodConvDesc* d) {
+  if (check_desc(d) != EOD_OK) return 0;
+  const int M = d->N * d->OH * d->OW;
+  const int nchunks = d->Kpad / 32;
+  const Plan pl = make_plan(d, M, nchunks);
+  if (pl.splitk <= 1) return 0;
+  return (size_t)pl.splitk * M * d->Cout * sizeof(float);
+}
+
+extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
+  const int st = check_desc(d);
+  if (st != EOD_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvArgs a{};
+  a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
+  a.partial = d->workspace;
+  a.m_count = d->m_count; a.m_unit = d->m_unit;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
+  a.M = d->N * d->OH * d->OW;
+  a.nchunks = d->Kpad / 32;
+  a.relu = d->relu; a.res_mode = d->res_mode; a.in_relu = d->in_relu; a.out_mode = d->out_mode;
+  a.out_scale = d->out_scale;
+  const Plan pl = make_plan(d, a.M, a.nchunks);
+  a.splitk = pl.splitk; a.cps = pl.cps; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+  if (pl.splitk > 1) {
+    const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
+    if (!d->workspace || d->workspace_bytes < need) return EOD_ERR_CAPACITY;
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
+  switch (pl.tile) {
+    case 1: launch_tile<128, 128>(a, d->tap4 != 0, grid, s); break;
+    case 2: launch_tile<128, 64>(a, d->tap4 != 0, grid, s); break;
+    default: launch_tile<64, 64>(a, d->tap4 != 0, grid, s); break;
+  }
+  if (pl.splitk > 1) {
+    const size_t total = (size_t)a.M * a.Cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  }
+  return eod_launch_status();
+}

@@ -1,0 +1,221 @@
+// Memory-bound helper kernels of the dense path (NHWC fp32): image normalisation, stem max-pool,
+// GroupNorm(32)+ReLU over the concatenated FPN levels, mask predictor + sigmoid, fills.
+// All are pure streaming kernels: 16-byte accesses per lane, one pass over the data.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W,
+                                                          int Hp, int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int total = Hp * Wp;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int y = p / Wp, x = p - y * Wp;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y < H && x < W) {
+      const size_t o = (size_t)y * W + x;
+      const size_t plane = (size_t)H * W;
+      v.x = ((float)img[o] - m0) / s0;
+      v.y = ((float)img[plane + o] - m1) / s1;
+      v.z = ((float)img[2 * plane + o] - m2) / s2;
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)p * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                                       int OH, int OW) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * OH * OW * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    size_t t = i / c4;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + iy) * W + ix) * C + cc * 4);
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = m;
+  }
+}
+
+struct LevelOff {
+  int off[9];
+  int levels;
+};
+
+// one block per (level, group): two-pass mean / variance over rows x (C/groups) channels
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, LevelOff lo, int C, int groups, float eps,
+                                                        float* __restrict__ stats) {
+  const int level = blockIdx.x / groups;
+  const int g = blockIdx.x - level * groups;
+  const int cpg = C / groups;
+  const int r0 = lo.off[level], r1 = lo.off[level + 1];
+  const int n = (r1 - r0) * cpg;
+  __shared__ float red[4];
+  __shared__ float bc;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / cpg, c = i - r * cpg;
+    s += x[(size_t)(r0 + r) * C + g * cpg + c];
+  }
+  s = wave_reduce_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  __syncthreads();
+  const float mean = bc;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / cpg, c = i - r * cpg;
+    const float d = x[(size_t)(r0 + r) * C + g * cpg + c] - mean;
+    v += d * d;
+  }
+  v = wave_reduce_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    stats[(level * groups + g) * 2 + 0] = mean;
+    stats[(level * groups + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             LevelOff lo, int C, int groups, const float* __restrict__ stats) {
+  const int c4 = C >> 2;
+  const int cpg = C / groups;
+  const size_t total = (size_t)lo.off[lo.levels] * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4) * 4;
+    const int row = (int)(i / c4);
+    int level = 0;
+    while (level + 1 < lo.levels && row >= lo.off[level + 1]) ++level;
+    const int g = cc / cpg;
+    const float mean = stats[(level * groups + g) * 2 + 0];
+    const float rstd = stats[(level * groups + g) * 2 + 1];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cc);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + cc);
+    f32x4 o;
+    o.x = fmaxf((v.x - mean) * rstd * ga.x + be.x, 0.f);
+    o.y = fmaxf((v.y - mean) * rstd * ga.y + be.y, 0.f);
+    o.z = fmaxf((v.z - mean) * rstd * ga.z + be.z, 0.f);
+    o.w = fmaxf((v.w - mean) * rstd * ga.w + be.w, 0.f);
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+// one wave per row: dot(x[row,:], w) + b -> sigmoid
+__global__ __launch_bounds__(256) void mask_predictor_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                                              float* __restrict__ prob, int rows, int C,
+                                                              const int* __restrict__ unit_count, int unit_rows) {
+  int R = rows;
+  if (unit_count) {
+    const int lim = *unit_count * unit_rows;
+    R = lim < R ? lim : R;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < R; row += gridDim.x * wpb) {
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + c);
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+      s += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+    }
+    s = wave_reduce_sum(s);
+    if (lane == 0) prob[row] = eod_sigmoid_precise(s + bias);
+  }
+}
+
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_i32_kernel(int* p, int v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int grid_for(size_t work, int per_block = 256, int cap = 2048) {
+  size_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int eod_abi_version(void) { return 1; }
+
+extern "C" int eod_preprocess_image(const uint8_t* img, float* out, int H, int W, int Hp, int Wp, const float* mean3,
+                                    const float* std3, eod_stream_t stream) {
+  if (!img || !out || !mean3 || !std3) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || Hp < H || Wp < W) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(out)) return EOD_ERR_ALIGN;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((size_t)Hp * Wp)), dim3(256), 0, (hipStream_t)stream, img, out, H, W, Hp, Wp,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return eod_launch_status();
+}
+
+extern "C" int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, eod_stream_t stream) {
+  if (!x || !y) return EOD_ERR_NULL;
+  if (C % 4 != 0 || OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || N <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(x) || !eod_aligned16(y)) return EOD_ERR_ALIGN;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((size_t)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C,
+                     OH, OW);
+  return eod_launch_status();
+}
+
+extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
+                                  int levels, int C, int groups, float eps, float* stats, eod_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !level_off_host || !stats) return EOD_ERR_NULL;
+  if (levels < 1 || levels > 8 || C % groups != 0 || C % 4 != 0 || (C / groups) % 4 != 0) return EOD_ERR_BAD_DIMS;
+  LevelOff lo{};
+  lo.levels = levels;
+  for (int i = 0; i <= levels; ++i) lo.off[i] = level_off_host[i];
+  for (int i = 0; i < levels; ++i)
+    if (lo.off[i + 1] <= lo.off[i]) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(levels * groups), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, eps, stats);
+  hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)lo.off[levels] * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                     gamma, beta, lo, C, groups, stats);
+  return eod_launch_status();
+}
+
+extern "C" int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,
+                                          const int32_t* unit_count, int unit_rows, eod_stream_t stream) {
+  if (!x || !w || !prob) return EOD_ERR_NULL;
+  if (rows <= 0 || C % 4 != 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(mask_predictor_kernel, dim3(grid_for((size_t)rows, 4, 8192)), dim3(256), 0, (hipStream_t)stream, x, w, bias, prob,
+                     rows, C, unit_count, unit_rows);
+  return eod_launch_status();
+}
+
+extern "C" int eod_fill_f32(float* p, float v, size_t n, eod_stream_t stream) {
+  if (!p) return EOD_ERR_NULL;
+  if (n == 0) return EOD_OK;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  return eod_launch_status();
+}
+extern "C" int eod_fill_i32(int32_t* p, int32_t v, size_t n, eod_stream_t stream) {
+  if (!p) return EOD_ERR_NULL;
+  if (n == 0) return EOD_OK;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  return eod_launch_status();
+}

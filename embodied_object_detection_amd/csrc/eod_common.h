@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of the embodied-detector hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EOD_OK 0
+#define EOD_ERR_BAD_DIMS (-1)
+#define EOD_ERR_ALIGN (-2)
+#define EOD_ERR_LAUNCH (-3)
+#define EOD_ERR_NULL (-4)
+#define EOD_ERR_CAPACITY (-5)
+
+#define EOD_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int eod_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? EOD_OK : EOD_ERR_LAUNCH;
+}
+
+static inline bool eod_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float eod_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// exact-ish sigmoid used where scores are compared against thresholds / sorted: expf, IEEE divide
+__device__ __forceinline__ float eod_sigmoid_precise(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups that share an XCD (id % 8 equal under
+// round-robin dispatch) get a contiguous range of tile ids, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}

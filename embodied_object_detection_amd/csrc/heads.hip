@@ -1,0 +1,244 @@
+// Small per-ROI kernels of the cascade heads and the post-processing:
+//   zero-shot classifier tail, Box2BoxTransform, cascade score fusion, memory-side CLIP scoring,
+//   detector_postprocess compaction and paste_masks_in_image.
+// All rows are bounded by a device-side count; everything is latency-trivial next to the dense kernels.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+
+namespace {
+
+__device__ __forceinline__ int dyn_rows(const int* count, int cap) {
+  if (!count) return cap;
+  const int c = *count;
+  return c < cap ? c : cap;
+}
+
+// one wave per row.  feat [R,D] (D = 512 -> 8 per lane)
+__global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
+                                                           float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
+                                                           const int* __restrict__ count, int R_cap, int D, int C1, float temp) {
+  const int R = dyn_rows(count, R_cap);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int per = D / 64;  // 8
+  float x[8];
+  float ss = 0.f;
+  for (int q = 0; q < per; ++q) {
+    x[q] = feat[(size_t)row * D + lane * per + q];
+    ss += x[q] * x[q];
+  }
+  ss = wave_reduce_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+  for (int q = 0; q < per; ++q) {
+    x[q] = temp * (x[q] / denom);
+    if (featn_out) featn_out[(size_t)row * D + lane * per + q] = x[q];
+  }
+  for (int c = 0; c < C1; ++c) {
+    float s = 0.f;
+    for (int q = 0; q < per; ++q) s += x[q] * zs[(size_t)(lane * per + q) * C1 + c];
+    s = wave_reduce_sum(s);
+    if (lane == 0) {
+      const float p = eod_sigmoid_precise(s);
+      float* o = prob_acc + (size_t)row * C1 + c;
+      *o = accumulate ? (*o + p) : p;
+    }
+  }
+}
+
+__global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, float* __restrict__ out,
+                                    const int* __restrict__ count, int R_cap, float wx, float wy, float ww, float wh, int clip,
+                                    float img_w, float img_h) {
+  const int R = dyn_rows(count, R_cap);
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float x1 = boxes[r * 4 + 0], y1 = boxes[r * 4 + 1], x2 = boxes[r * 4 + 2], y2 = boxes[r * 4 + 3];
+  const float w = x2 - x1, h = y2 - y1;
+  const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
+  const float clampv = 4.135166556742356f;  // log(1000/16)
+  const float dx = deltas[(size_t)r * ld + 0] / wx;
+  const float dy = deltas[(size_t)r * ld + 1] / wy;
+  const float dw = fminf(deltas[(size_t)r * ld + 2] / ww, clampv);
+  const float dh = fminf(deltas[(size_t)r * ld + 3] / wh, clampv);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
+  if (clip) {
+    ox1 = fminf(fmaxf(ox1, 0.f), img_w);
+    oy1 = fminf(fmaxf(oy1, 0.f), img_h);
+    ox2 = fminf(fmaxf(ox2, 0.f), img_w);
+    oy2 = fminf(fmaxf(oy2, 0.f), img_h);
+  }
+  out[r * 4 + 0] = ox1;
+  out[r * 4 + 1] = oy1;
+  out[r * 4 + 2] = ox2;
+  out[r * 4 + 3] = oy2;
+}
+
+__global__ void cascade_scores_kernel(float* __restrict__ prob_acc, const float* __restrict__ prop_scores, const int* __restrict__ count,
+                                      int R_cap, int C1, float inv_stages) {
+  const int R = dyn_rows(count, R_cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * C1) return;
+  const int r = i / C1;
+  prob_acc[i] = sqrtf(prob_acc[i] * inv_stages * prop_scores[r]);
+}
+
+// one wave per row: scores[r][c] = sqrt(sigmoid(featn[r] . zs[:,c]) * ps[r]); rows with ps >= 1 are excluded (score 0)
+__global__ __launch_bounds__(256) void memory_scores_kernel(const float* __restrict__ featn, const float* __restrict__ zs,
+                                                             const float* __restrict__ ps, float* __restrict__ scores,
+                                                             const int* __restrict__ count, int R_cap, int D, int C1) {
+  const int R = dyn_rows(count, R_cap);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int per = D / 64;
+  float x[8];
+  for (int q = 0; q < per; ++q) x[q] = featn[(size_t)row * D + lane * per + q];
+  const float p = ps[row];
+  for (int c = 0; c < C1; ++c) {
+    float s = 0.f;
+    for (int q = 0; q < per; ++q) s += x[q] * zs[(size_t)(lane * per + q) * C1 + c];
+    s = wave_reduce_sum(s);
+    if (lane == 0) scores[(size_t)row * C1 + c] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(s) * p) : 0.0f;
+  }
+}
+
+// detector_postprocess: scale, clip, drop empty boxes (single block)
+__global__ __launch_bounds__(512) void postprocess_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                           const int* __restrict__ classes, const int* __restrict__ count, int cap,
+                                                           float sx, float sy, float out_w, float out_h, float* __restrict__ ob,
+                                                           float* __restrict__ os, int* __restrict__ oc, int* __restrict__ osrc,
+                                                           int* __restrict__ ocount) {
+  __shared__ int sh_keep[512];
+  __shared__ int sh_pos[512];
+  const int D = dyn_rows(count, cap);
+  const int t = threadIdx.x;
+  float b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  int keep = 0;
+  if (t < D) {
+    b0 = fminf(fmaxf(boxes[t * 4 + 0] * sx, 0.f), out_w);
+    b1 = fminf(fmaxf(boxes[t * 4 + 1] * sy, 0.f), out_h);
+    b2 = fminf(fmaxf(boxes[t * 4 + 2] * sx, 0.f), out_w);
+    b3 = fminf(fmaxf(boxes[t * 4 + 3] * sy, 0.f), out_h);
+    keep = ((b2 - b0) > 0.f && (b3 - b1) > 0.f) ? 1 : 0;
+  }
+  sh_keep[t] = keep;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 512; ++i) {
+      sh_pos[i] = run;
+      run += sh_keep[i];
+    }
+    *ocount = run;
+  }
+  __syncthreads();
+  if (keep) {
+    const int q = sh_pos[t];
+    ob[q * 4 + 0] = b0;
+    ob[q * 4 + 1] = b1;
+    ob[q * 4 + 2] = b2;
+    ob[q * 4 + 3] = b3;
+    os[q] = scores[t];
+    oc[q] = classes[t];
+    osrc[q] = t;
+  }
+}
+
+// grid (pixel tiles, K).  Exact op order of F.grid_sample(bilinear, zeros, align_corners=False) on the
+// normalised grid detectron2 builds in _do_paste_mask.
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ prob, const float* __restrict__ boxes,
+                                                           const int* __restrict__ rows, const int* __restrict__ count, int K_cap, int H,
+                                                           int W, float thr, uint8_t* __restrict__ out) {
+  const int K = dyn_rows(count, K_cap);
+  const int k = blockIdx.y;
+  if (k >= K) return;
+  __shared__ float m[28 * 28];
+  const int src = rows ? rows[k] : k;
+  for (int i = threadIdx.x; i < 784; i += blockDim.x) m[i] = prob[(size_t)src * 784 + i];
+  __syncthreads();
+  const float x0 = boxes[k * 4 + 0], y0 = boxes[k * 4 + 1], x1 = boxes[k * 4 + 2], y1 = boxes[k * 4 + 3];
+  const int total = H * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+    const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+    float v = 0.f;
+    if (ix > -1.0f && ix < 28.0f && iy > -1.0f && iy < 28.0f) {  // also false for NaN
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int xw = (int)fx, yn = (int)fy;
+      const int xe = xw + 1, ys = yn + 1;
+      const float nw = ((float)xe - ix) * ((float)ys - iy);
+      const float ne = (ix - (float)xw) * ((float)ys - iy);
+      const float sw = ((float)xe - ix) * (iy - (float)yn);
+      const float se = (ix - (float)xw) * (iy - (float)yn);
+      const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u, ynv = (unsigned)yn < 28u, ysv = (unsigned)ys < 28u;
+      if (xwv && ynv) v += m[yn * 28 + xw] * nw;
+      if (xev && ynv) v += m[yn * 28 + xe] * ne;
+      if (xwv && ysv) v += m[ys * 28 + xw] * sw;
+      if (xev && ysv) v += m[ys * 28 + xe] * se;
+    }
+    out[(size_t)k * total + p] = (v >= thr) ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_acc, int accumulate, float* feat_norm_out,
+                               const int32_t* count, int R_cap, int D, int C1, float temp, eod_stream_t stream) {
+  if (!feat || !zs || !prob_acc) return EOD_ERR_NULL;
+  if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
+                     feat_norm_out, count, R_cap, D, C1, temp);
+  return eod_launch_status();
+}
+
+extern "C" int eod_apply_deltas(const float* deltas, int ld, const float* boxes, float* out, const int32_t* count, int R_cap, float wx,
+                                float wy, float ww, float wh, int clip, float img_w, float img_h, eod_stream_t stream) {
+  if (!deltas || !boxes || !out) return EOD_ERR_NULL;
+  if (ld < 4 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(apply_deltas_kernel, dim3((R_cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas, ld, boxes, out, count,
+                     R_cap, wx, wy, ww, wh, clip, img_w, img_h);
+  return eod_launch_status();
+}
+
+extern "C" int eod_cascade_scores(float* prob_acc, const float* prop_scores, const int32_t* count, int R_cap, int C1, float inv_stages,
+                                  eod_stream_t stream) {
+  if (!prob_acc || !prop_scores) return EOD_ERR_NULL;
+  if (R_cap <= 0 || C1 <= 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(cascade_scores_kernel, dim3((R_cap * C1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob_acc, prop_scores,
+                     count, R_cap, C1, inv_stages);
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_scores(const float* featn, const float* zs, const float* prop_scores, float* scores, const int32_t* count,
+                                 int R_cap, int D, int C1, eod_stream_t stream) {
+  if (!featn || !zs || !prop_scores || !scores) return EOD_ERR_NULL;
+  if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(memory_scores_kernel, dim3((R_cap + 3) / 4), dim3(256), 0, (hipStream_t)stream, featn, zs, prop_scores, scores,
+                     count, R_cap, D, C1);
+  return eod_launch_status();
+}
+
+extern "C" int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
+                                        float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
+                                        int32_t* out_classes, int32_t* out_src, int32_t* out_count, eod_stream_t stream) {
+  if (!boxes || !scores || !classes || !out_boxes || !out_scores || !out_classes || !out_src || !out_count) return EOD_ERR_NULL;
+  if (cap <= 0 || cap > 512) return EOD_ERR_CAPACITY;
+  hipLaunchKernelGGL(postprocess_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, boxes, scores, classes, count, cap, sx, sy, out_w,
+                     out_h, out_boxes, out_scores, out_classes, out_src, out_count);
+  return eod_launch_status();
+}
+
+extern "C" int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap, int H, int W,
+                               float threshold, uint8_t* out, eod_stream_t stream) {
+  if (!prob || !boxes || !out) return EOD_ERR_NULL;
+  if (K_cap <= 0 || H <= 0 || W <= 0) return EOD_ERR_BAD_DIMS;
+  int tiles = (H * W + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(paste_masks_kernel, dim3(tiles, K_cap), dim3(256), 0, (hipStream_t)stream, prob, boxes, rows, count, K_cap, H, W,
+                     threshold, out);
+  return eod_launch_status();
+}

@@ -1,0 +1,557 @@
+// SMNet-style spatial feature memory on device: depth un-projection + integer grid-cell indexing, the memory
+// READ (observation normalise -> fp16 -> gather by cell index -> cascaded average pooling) and the memory
+// WRITE (instance CLIP features -> per-pixel mean over covering instances -> every 8th observed pixel ->
+// per-cell mean -> accumulate, observation counters).
+//
+// All of it is HBM / cache-bandwidth work on bytes and indices; nothing here is shaped into a GEMM.  The
+// reference materialises [H,W,512] fp16 + 2x f32 copies on the read side and a [1,512,H,W] f32 image plus a
+// dense [Npix/8, N] one-hot on the write side (Detic/detic/modeling/backbone/timm.py:147-152,
+// Detic/detic/modeling/meta_arch/custom_rcnn.py:884-936); here the gather is fused with the pooling and the
+// write works on the sparse set of selected pixels only.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------------------
+// a1 + a2
+// ------------------------------------------------------------------------------------------------------
+struct UnprojArgs {
+  float T[16];
+  float fx, fy, cx, cy;
+  float ps[3], ms[3];
+  float cell;
+  int map_w, map_h, order;
+};
+
+__global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict__ depth, int H, int W, UnprojArgs a,
+                                                         float* __restrict__ xyz, int* __restrict__ idx) {
+  const int total = H * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int v = p / W, u = p - v * W;
+    // explicit _rn intrinsics: no FMA contraction, IEEE divide -> bit-identical to oracle/projector.c
+    const float xs = __fdiv_rn(__fsub_rn(__fadd_rn((float)u, 0.5f), a.cx), a.fx);
+    const float ys = __fdiv_rn(__fsub_rn(__fadd_rn((float)v, 0.5f), a.cy), a.fy);
+    const float z = depth[p];
+    const float x = __fmul_rn(z, xs);
+    const float y = __fmul_rn(z, ys);
+    float w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float t0 = __fmul_rn(a.T[i * 4 + 0], x);
+      const float t1 = __fmul_rn(a.T[i * 4 + 1], y);
+      const float t2 = __fmul_rn(a.T[i * 4 + 2], z);
+      float s = __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), a.T[i * 4 + 3]);
+      s = __fsub_rn(s, a.ps[i]);
+      w[i] = s;
+    }
+    if (xyz) {
+      xyz[(size_t)p * 3 + 0] = w[0];
+      xyz[(size_t)p * 3 + 1] = w[1];
+      xyz[(size_t)p * 3 + 2] = w[2];
+    }
+    const float qx = rintf(__fdiv_rn(__fsub_rn(w[0], a.ms[0]), a.cell));
+    const float qz = rintf(__fdiv_rn(__fsub_rn(w[2], a.ms[2]), a.cell));
+    long ix = (qx != qx) ? 0 : (qx < -1e9f ? -1000000000L : (qx > 1e9f ? 1000000000L : (long)qx));
+    long iz = (qz != qz) ? 0 : (qz < -1e9f ? -1000000000L : (qz > 1e9f ? 1000000000L : (long)qz));
+    ix = ix < 0 ? 0 : (ix > a.map_w - 1 ? a.map_w - 1 : ix);
+    iz = iz < 0 ? 0 : (iz > a.map_h - 1 ? a.map_h - 1 : iz);
+    idx[p] = (int)(a.order == 0 ? iz * a.map_w + ix : ix * a.map_h + iz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a4 + fp16 cast
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restrict__ mem, const float* __restrict__ obs,
+                                                             __half* __restrict__ out, int n_cells, int D) {
+  const int d4 = D >> 2;
+  const size_t total = (size_t)n_cells * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cell = (int)(i / d4);
+    const float o = obs[cell];
+    f32x4 v = *reinterpret_cast<const f32x4*>(mem + i * 4);
+    if (o > 1.0f) {
+      v.x = __fdiv_rn(v.x, o);
+      v.y = __fdiv_rn(v.y, o);
+      v.z = __fdiv_rn(v.z, o);
+      v.w = __fdiv_rn(v.w, o);
+    }
+    __half2 h0 = __floats2half2_rn(v.x, v.y);
+    __half2 h1 = __floats2half2_rn(v.z, v.w);
+    uint2 pk;
+    pk.x = *reinterpret_cast<unsigned*>(&h0);
+    pk.y = *reinterpret_cast<unsigned*>(&h1);
+    *reinterpret_cast<uint2*>(out + i * 4) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a8: gather + cascaded average pooling
+// ------------------------------------------------------------------------------------------------------
+// One workgroup = one 32x32 pixel tile (= one stride-32 cell); wave q owns the 16x16 quadrant (= one stride-16
+// cell); each lane owns 8 consecutive channels (16 B of fp16 -> one 1 KiB coalesced row read per pixel).
+// Pooling order mirrors torch: avg_pool2d(4) sums the 16 pixels row-major in f32 and divides by 16; each
+// following avg_pool2d(2) sums 4 values row-major, divides by 4 and rounds to fp16 (timm.py:152,168).
+__device__ __forceinline__ float round_f16(float v) { return __half2float(__float2half_rn(v)); }
+
+__global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W, int D,
+                                                           float* __restrict__ p8, float* __restrict__ p16, float* __restrict__ p32) {
+  __shared__ int sidx[32 * 32];
+  __shared__ float s16[4][512];
+  const int tiles_x = W >> 5;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) {
+    const int yy = i >> 5, xx = i & 31;
+    sidx[i] = proj[(size_t)(ty * 32 + yy) * W + tx * 32 + xx];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int qy = wave >> 1, qx = wave & 1;  // quadrant
+  const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5;
+  for (int c0 = lane * 8; c0 < D; c0 += 512) {
+    float acc16[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
+    // 2x2 stride-8 cells in this quadrant, row-major
+#pragma unroll 1
+    for (int cy8 = 0; cy8 < 2; ++cy8) {
+#pragma unroll 1
+      for (int cx8 = 0; cx8 < 2; ++cx8) {
+        float acc8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
+        // 2x2 blocks of 4x4 pixels, row-major
+#pragma unroll 1
+        for (int by = 0; by < 2; ++by) {
+#pragma unroll 1
+          for (int bx = 0; bx < 2; ++bx) {
+            float acc4[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
+            const int py0 = qy * 16 + cy8 * 8 + by * 4, px0 = qx * 16 + cx8 * 8 + bx * 4;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+              uint4 raw[4];
+#pragma unroll
+              for (int dx = 0; dx < 4; ++dx) {
+                const int cell = sidx[(py0 + dy) * 32 + px0 + dx];
+                raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * D + c0);
+              }
+#pragma unroll
+              for (int dx = 0; dx < 4; ++dx) {
+                const __half2* h = reinterpret_cast<const __half2*>(&raw[dx]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float2 f = __half22float2(h[q]);
+                  acc4[2 * q] += f.x;
+                  acc4[2 * q + 1] += f.y;
+                }
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
+          }
+        }
+        float v8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          v8[q] = round_f16(acc8[q] * 0.25f);
+          acc16[q] += v8[q];
+        }
+        const int oy = ty * 4 + qy * 2 + cy8, ox = tx * 4 + qx * 2 + cx8;
+        float* o = p8 + ((size_t)oy * w8 + ox) * D + c0;
+        *reinterpret_cast<f32x4*>(o) = f32x4{v8[0], v8[1], v8[2], v8[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
+      }
+    }
+    float v16[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v16[q] = round_f16(acc16[q] * 0.25f);
+      s16[wave][c0 + q] = v16[q];
+    }
+    {
+      const int oy = ty * 2 + qy, ox = tx * 2 + qx;
+      float* o = p16 + ((size_t)oy * w16 + ox) * D + c0;
+      *reinterpret_cast<f32x4*>(o) = f32x4{v16[0], v16[1], v16[2], v16[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v16[4], v16[5], v16[6], v16[7]};
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < D; c += 256) {
+    const float s = ((s16[0][c] + s16[1][c]) + s16[2][c]) + s16[3][c];
+    p32[((size_t)ty * w32 + tx) * D + c] = round_f16(s * 0.25f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a16-a19 write path
+// ------------------------------------------------------------------------------------------------------
+struct MwWs {
+  int* inst_rows;   // [R_cap] unique proposal rows, ascending
+  int* k_u;         // [1]
+  unsigned char* cover;  // [P]
+  int* sel_pix;     // [P/8+1]
+  int* n_sel;       // [1]
+  int* cell_flag;   // [N] any pixel of the frame hit the cell
+  int* cell_mark;   // [N] a selected pixel hit the cell
+  int* cell_slot;   // [N]
+  int* slot_cell;   // [U_max]
+  int* n_slots;     // [1]
+  long long* acc;   // [U_max, D] fixed point 2^-32
+  int* slot_cnt;    // [U_max]
+  size_t bytes;
+};
+
+inline size_t up(size_t v) { return (v + 255) / 256 * 256; }
+
+MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap) {
+  MwWs w{};
+  char* b = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = b ? b + off : nullptr;
+    off += up(bytes);
+    return p;
+  };
+  const size_t P = (size_t)H * W;
+  const size_t smax = P / 8 + 1;
+  const size_t umax = smax < (size_t)n_cells ? smax : (size_t)n_cells;
+  w.inst_rows = (int*)take((size_t)R_cap * 4);
+  w.k_u = (int*)take(4);
+  w.cover = (unsigned char*)take(P);
+  w.sel_pix = (int*)take(smax * 4);
+  w.n_sel = (int*)take(4);
+  w.cell_flag = (int*)take((size_t)n_cells * 4);
+  w.cell_mark = (int*)take((size_t)n_cells * 4);
+  w.cell_slot = (int*)take((size_t)n_cells * 4);
+  w.slot_cell = (int*)take(umax * 4);
+  w.n_slots = (int*)take(4);
+  w.acc = (long long*)take(umax * (size_t)D * 8);
+  w.slot_cnt = (int*)take(umax * 4);
+  w.bytes = off;
+  return w;
+}
+
+// unique(det_rows) ascending (custom_rcnn.py:875); single block
+__global__ __launch_bounds__(512) void mw_unique_rows_kernel(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
+                                                              int R_cap, int* __restrict__ inst_rows, int* __restrict__ k_u,
+                                                              int* __restrict__ k_out) {
+  __shared__ int flag[512];
+  const int t = threadIdx.x;
+  flag[t] = 0;
+  __syncthreads();
+  int K = *det_count;
+  K = K < K_cap ? K : K_cap;
+  for (int i = t; i < K; i += blockDim.x) {
+    const int r = det_rows[i];
+    if (r >= 0 && r < R_cap) flag[r] = 1;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int n = 0;
+    for (int r = 0; r < R_cap; ++r)
+      if (flag[r]) inst_rows[n++] = r;
+    *k_u = n;
+    if (k_out) *k_out = n;
+  }
+}
+
+// mask test of one instance at pixel centre (x+0.5, y+0.5): same arithmetic as paste_masks_kernel
+__device__ __forceinline__ bool mask_hit(const float* __restrict__ m, float x0, float y0, float x1, float y1, int x, int y, float thr) {
+  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+  const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+  if (!(ix > -1.0f && ix < 28.0f && iy > -1.0f && iy < 28.0f)) return false;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int xw = (int)fx, yn = (int)fy;
+  const int xe = xw + 1, ys = yn + 1;
+  const float nw = ((float)xe - ix) * ((float)ys - iy);
+  const float ne = (ix - (float)xw) * ((float)ys - iy);
+  const float sw = ((float)xe - ix) * (iy - (float)yn);
+  const float se = (ix - (float)xw) * (iy - (float)yn);
+  const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u, ynv = (unsigned)yn < 28u, ysv = (unsigned)ys < 28u;
+  float v = 0.f;
+  if (xwv && ynv) v += m[yn * 28 + xw] * nw;
+  if (xev && ynv) v += m[yn * 28 + xe] * ne;
+  if (xwv && ysv) v += m[ys * 28 + xw] * sw;
+  if (xev && ysv) v += m[ys * 28 + xe] * se;
+  return v >= thr;
+}
+
+// per pixel: number of covering instances; marks every cell the frame hits (for the observation counters)
+__global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
+                                                           const int* __restrict__ proj, int H, int W, float thr,
+                                                           unsigned char* __restrict__ cover, int* __restrict__ cell_flag) {
+  const int K = *k_u;
+  if (K == 0) return;
+  const int total = H * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {
+      const int r = inst_rows[k];
+      const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
+      // quick reject: a sample more than one mask pixel outside the box is zero
+      const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
+      const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+      if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
+      if (mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr)) ++cnt;
+    }
+    cover[p] = (unsigned char)cnt;
+    cell_flag[proj[p]] = 1;
+  }
+}
+
+// single block: rank observed pixels in row-major order, keep every 8th (custom_rcnn.py:913-914)
+__global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
+                                                          const int* __restrict__ proj, int* __restrict__ sel_pix, int* __restrict__ n_sel,
+                                                          int* __restrict__ cell_mark) {
+  if (*k_u == 0) {
+    if (threadIdx.x == 0) *n_sel = 0;
+    return;
+  }
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (P + 1023) / 1024;
+  const int b = t * chunk, e = min(P, b + chunk);
+  int c = 0;
+  for (int p = b; p < e; ++p) c += cover[p] > 0;
+  part[t] = c;
+  __syncthreads();
+  // inclusive scan (Hillis-Steele)
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = 0;
+    if (t >= off) v = part[t - off];
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int rank = part[t] - c;
+  for (int p = b; p < e; ++p) {
+    if (cover[p] > 0) {
+      if ((rank & 7) == 0) {
+        sel_pix[rank >> 3] = p;
+        cell_mark[proj[p]] = 1;
+      }
+      ++rank;
+    }
+  }
+  if (t == 1023) *n_sel = (part[1023] + 7) >> 3;
+}
+
+// single block: slot ids for marked cells in ascending cell order
+__global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
+                                                         int* __restrict__ cell_slot, int* __restrict__ slot_cell, int* __restrict__ n_slots) {
+  if (*k_u == 0) {
+    if (threadIdx.x == 0) *n_slots = 0;
+    return;
+  }
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (N + 1023) / 1024;
+  const int b = t * chunk, e = min(N, b + chunk);
+  int c = 0;
+  for (int i = b; i < e; ++i) c += cell_mark[i] != 0;
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = 0;
+    if (t >= off) v = part[t - off];
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int rank = part[t] - c;
+  for (int i = b; i < e; ++i) {
+    if (cell_mark[i] != 0) {
+      cell_slot[i] = rank;
+      slot_cell[rank] = i;
+      ++rank;
+    }
+  }
+  if (t == 1023) *n_slots = part[1023];
+}
+
+__global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ acc, int* __restrict__ slot_cnt,
+                                                             const int* __restrict__ n_slots, int D) {
+  const size_t total = (size_t)(*n_slots) * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) acc[i] = 0;
+  const int ns = *n_slots;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) slot_cnt[i] = 0;
+}
+
+// one wave per selected pixel: mean of the covering instances' features (instance order), added exactly
+// (2^-32 fixed point, integer atomics: order independent, bitwise reproducible) to the pixel's cell slot
+__global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restrict__ featn, const float* __restrict__ boxes,
+                                                             const float* __restrict__ masks, const int* __restrict__ inst_rows,
+                                                             const int* __restrict__ k_u, const int* __restrict__ sel_pix,
+                                                             const int* __restrict__ n_sel, const unsigned char* __restrict__ cover,
+                                                             const int* __restrict__ proj, const int* __restrict__ cell_slot, int W,
+                                                             int D, float thr, long long* __restrict__ acc, int* __restrict__ slot_cnt) {
+  const int K = *k_u;
+  const int S = *n_sel;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int s = blockIdx.x * wpb + (threadIdx.x >> 6); s < S; s += gridDim.x * wpb) {
+    const int p = sel_pix[s];
+    const int y = p / W, x = p - y * W;
+    const float cnt = (float)cover[p];
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      int r = 0;
+      if (k < K) {
+        r = inst_rows[k];
+        const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
+        hit = mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr);
+      }
+      u64 bal = __ballot(hit);
+      while (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const int rr = __shfl(r, src, 64);
+        const float* f = featn + (size_t)rr * D + lane * 8;
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(f);
+        const f32x4 f1 = *reinterpret_cast<const f32x4*>(f + 4);
+        a[0] += f0.x; a[1] += f0.y; a[2] += f0.z; a[3] += f0.w;
+        a[4] += f1.x; a[5] += f1.y; a[6] += f1.z; a[7] += f1.w;
+      }
+    }
+    const int slot = cell_slot[proj[p]];
+    long long* dst = acc + (size_t)slot * D + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = a[q] / cnt;
+      const long long fx = (long long)llrintf(v * 4294967296.0f);
+      atomicAdd(reinterpret_cast<unsigned long long*>(dst + q), (unsigned long long)fx);
+    }
+    if (lane == 0) atomicAdd(slot_cnt + slot, 1);
+  }
+}
+
+// per slot: mean -> mem[cell] += mean  (semmap_features + semmap_update, custom_rcnn.py:738-743)
+__global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restrict__ acc, const int* __restrict__ slot_cnt,
+                                                        const int* __restrict__ slot_cell, const int* __restrict__ n_slots, int D,
+                                                        float* __restrict__ mem) {
+  const size_t total = (size_t)(*n_slots) * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int slot = (int)(i / D);
+    const int c = (int)(i - (size_t)slot * D);
+    const double sum = (double)acc[i] * (1.0 / 4294967296.0);
+    const float mean = (float)sum / (float)slot_cnt[slot];
+    float* m = mem + (size_t)slot_cell[slot] * D + c;
+    *m = *m + mean;
+  }
+}
+
+// observation counters (custom_rcnn.py:699-701,743) + reset of the per-frame cell flags
+__global__ __launch_bounds__(256) void mw_obs_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark, const int* __restrict__ k_u,
+                                                      int N, float* __restrict__ obs) {
+  if (*k_u == 0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (cell_flag[i]) {
+      obs[i] += 1.0f;
+      cell_flag[i] = 0;
+    }
+    cell_mark[i] = 0;
+  }
+}
+
+inline int blocks_for(size_t work, int per = 256, int cap = 4096) {
+  size_t b = (work + per - 1) / per;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int eod_unproject_grid_index(const float* depth, int H, int W, const float* T16, float fx, float fy, float cx, float cy,
+                                        const float* proj_shift3, const float* map_shift3, float cell, int map_w, int map_h, int order,
+                                        float* xyz_or_null, int32_t* idx, eod_stream_t stream) {
+  if (!depth || !T16 || !proj_shift3 || !map_shift3 || !idx) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || map_w <= 0 || map_h <= 0 || !(cell > 0.f) || (order != 0 && order != 1)) return EOD_ERR_BAD_DIMS;
+  if ((long)map_w * map_h >= (1L << 31)) return EOD_ERR_BAD_DIMS;
+  UnprojArgs a{};
+  for (int i = 0; i < 16; ++i) a.T[i] = T16[i];
+  a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+  for (int i = 0; i < 3; ++i) {
+    a.ps[i] = proj_shift3[i];
+    a.ms[i] = map_shift3[i];
+  }
+  a.cell = cell; a.map_w = map_w; a.map_h = map_h; a.order = order;
+  hipLaunchKernelGGL(unproject_kernel, dim3(blocks_for((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, depth, H, W, a, xyz_or_null,
+                     idx);
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_normalize_f16(const float* mem, const float* obs, uint16_t* out_f16, int n_cells, int D, eod_stream_t stream) {
+  if (!mem || !obs || !out_f16) return EOD_ERR_NULL;
+  if (n_cells <= 0 || D % 4 != 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(mem) || !eod_aligned16(out_f16)) return EOD_ERR_ALIGN;
+  hipLaunchKernelGGL(normalize_f16_kernel, dim3(blocks_for((size_t)n_cells * (D / 4))), dim3(256), 0, (hipStream_t)stream, mem, obs,
+                     reinterpret_cast<__half*>(out_f16), n_cells, D);
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, float* pooled8,
+                                      float* pooled16, float* pooled32, eod_stream_t stream) {
+  if (!mem_f16 || !proj || !pooled8 || !pooled16 || !pooled32) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled8) || !eod_aligned16(pooled16)) return EOD_ERR_ALIGN;
+  hipLaunchKernelGGL(gather_pool_kernel, dim3((H >> 5) * (W >> 5)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const __half*>(mem_f16), proj, H, W, D, pooled8, pooled16, pooled32);
+  return eod_launch_status();
+}
+
+extern "C" size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap) {
+  (void)K_cap;
+  return mw_carve(nullptr, H, W, D, n_cells, R_cap).bytes;
+}
+
+extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int R_cap,
+                                     eod_stream_t stream) {
+  // the per-frame cell flags must start at zero; every eod_memory_write leaves them zero again
+  if (!workspace) return EOD_ERR_NULL;
+  const MwWs w = mw_carve(workspace, H, W, D, n_cells, R_cap);
+  if (workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
+  if (hipMemsetAsync(w.cell_flag, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  if (hipMemsetAsync(w.cell_mark, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
+  if (!d || !d->featn || !d->prop_boxes || !d->prop_masks || !d->det_rows || !d->det_count || !d->proj || !d->mem || !d->obs ||
+      !d->workspace)
+    return EOD_ERR_NULL;
+  if (d->H <= 0 || d->W <= 0 || d->D != 512 || d->n_cells <= 0 || d->R_cap <= 0 || d->R_cap > 512 || d->K_cap <= 0)
+    return EOD_ERR_BAD_DIMS;
+  const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap);
+  if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = d->H * d->W;
+  hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, s, d->det_rows, d->det_count, d->K_cap, d->R_cap, w.inst_rows, w.k_u,
+                     d->k_out);
+  hipLaunchKernelGGL(mw_coverage_kernel, dim3(blocks_for((size_t)P)), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
+                     d->proj, d->H, d->W, d->mask_thresh, w.cover, w.cell_flag);
+  hipLaunchKernelGGL(mw_select_kernel, dim3(1), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, w.sel_pix, w.n_sel, w.cell_mark);
+  hipLaunchKernelGGL(mw_slots_kernel, dim3(1), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.cell_slot, w.slot_cell, w.n_slots);
+  hipLaunchKernelGGL(mw_zero_slots_kernel, dim3(1024), dim3(256), 0, s, w.acc, w.slot_cnt, w.n_slots, d->D);
+  hipLaunchKernelGGL(mw_accumulate_kernel, dim3(2048), dim3(256), 0, s, d->featn, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
+                     w.sel_pix, w.n_sel, w.cover, d->proj, w.cell_slot, d->W, d->D, d->mask_thresh, w.acc, w.slot_cnt);
+  hipLaunchKernelGGL(mw_apply_kernel, dim3(1024), dim3(256), 0, s, w.acc, w.slot_cnt, w.slot_cell, w.n_slots, d->D, d->mem);
+  hipLaunchKernelGGL(mw_obs_kernel, dim3(blocks_for((size_t)d->n_cells)), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u, d->n_cells,
+                     d->obs);
+  return eod_launch_status();
+}

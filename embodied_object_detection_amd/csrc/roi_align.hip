@@ -1,0 +1,133 @@
+// ROIAlignV2 (aligned=True, sampling_ratio=0) over the three FPN levels p3..p5, NHWC fp32.
+// Replaces detectron2 ROIPooler + torchvision roi_align as called by the cascade box heads
+// (Detic/detic/modeling/roi_heads/detic_roi_heads.py:332) and the mask pooler (:265); semantics per
+// SURVEY.md Appendix A7.
+//
+// One wave per output bin: the 4 bilinear taps of every sample point are wave-uniform scalars, each lane
+// owns 4 consecutive channels (C = 256 -> one 1 KiB coalesced read per tap), samples are accumulated in the
+// upstream order (iy outer, ix inner) and divided by the sample count.  HBM/L2-bound gather.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+
+namespace {
+
+struct RoiArgs {
+  const float* feat[3];
+  int h[3], w[3];
+  float scale[3];
+  int C;
+  const float* boxes;
+  const int* count;
+  int R_cap;
+  int S;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
+  int R = p.R_cap;
+  if (p.count) {
+    const int c = *p.count;
+    R = c < R ? c : R;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int bins = p.S * p.S;
+  const long total = (long)R * bins;
+  for (long wid = (long)blockIdx.x * wpb + (threadIdx.x >> 6); wid < total; wid += (long)gridDim.x * wpb) {
+    const int r = (int)(wid / bins);
+    const int b = (int)(wid - (long)r * bins);
+    const int ph = b / p.S, pw = b - ph * p.S;
+    const float bx1 = p.boxes[r * 4 + 0], by1 = p.boxes[r * 4 + 1], bx2 = p.boxes[r * 4 + 2], by2 = p.boxes[r * 4 + 3];
+    // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [3,5]
+    const float area = (bx2 - bx1) * (by2 - by1);
+    float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
+    lv = fminf(fmaxf(lv, 3.0f), 5.0f);
+    const int l = (int)lv - 3;
+    const float* feat = p.feat[l];
+    const int H = p.h[l], W = p.w[l];
+    const float sc = p.scale[l];
+    const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f, x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+    const float roi_w = x2 - x1, roi_h = y2 - y1;
+    const float bin_h = roi_h / (float)p.S, bin_w = roi_w / (float)p.S;
+    const float ghf = ceilf(roi_h / (float)p.S), gwf = ceilf(roi_w / (float)p.S);
+    // non-finite or absurd boxes (exploded deltas) produce an all-zero bin instead of an unbounded loop
+    const bool sane = (ghf == ghf) && (gwf == gwf) && ghf < 1.0e6f && gwf < 1.0e6f;
+    const int gh = sane ? (int)ghf : 0;
+    const int gw = sane ? (int)gwf : 0;
+    const float cnt = fmaxf((float)gh * (float)gw, 1.0f);
+    // samples outside [-1,H]x[-1,W] contribute 0: only walk the index range that can fall inside (+-1 margin)
+    int iy_lo = 0, iy_hi = gh - 1, ix_lo = 0, ix_hi = gw - 1;
+    if (gh > 0) {
+      const float ys = y1 + (float)ph * bin_h, st = bin_h / (float)gh;
+      iy_lo = max(0, (int)floorf((-1.0f - ys) / st - 0.5f) - 1);
+      iy_hi = min(gh - 1, (int)ceilf(((float)H - ys) / st - 0.5f) + 1);
+    }
+    if (gw > 0) {
+      const float xs = x1 + (float)pw * bin_w, st = bin_w / (float)gw;
+      ix_lo = max(0, (int)floorf((-1.0f - xs) / st - 0.5f) - 1);
+      ix_hi = min(gw - 1, (int)ceilf(((float)W - xs) / st - 0.5f) + 1);
+    }
+    for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+          float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          float yy = y;
+          if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+          if (yy <= 0.f) yy = 0.f;
+          if (x <= 0.f) x = 0.f;
+          int y_low = (int)yy, x_low = (int)x;
+          int y_high, x_high;
+          if (y_low >= H - 1) {
+            y_high = y_low = H - 1;
+            yy = (float)y_low;
+          } else {
+            y_high = y_low + 1;
+          }
+          if (x_low >= W - 1) {
+            x_high = x_low = W - 1;
+            x = (float)x_low;
+          } else {
+            x_high = x_low + 1;
+          }
+          const float ly = yy - (float)y_low, lx = x - (float)x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(feat + ((size_t)y_low * W + x_low) * p.C + c0);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(feat + ((size_t)y_low * W + x_high) * p.C + c0);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(feat + ((size_t)y_high * W + x_low) * p.C + c0);
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(feat + ((size_t)y_high * W + x_high) * p.C + c0);
+          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+      }
+      acc.x /= cnt;
+      acc.y /= cnt;
+      acc.z /= cnt;
+      acc.w /= cnt;
+      *reinterpret_cast<f32x4*>(p.out + ((size_t)r * bins + b) * p.C + c0) = acc;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C, const float* boxes,
+                             const int32_t* count, int R_cap, int out_size, float* out, eod_stream_t stream) {
+  if (!p3 || !p4 || !p5 || !boxes || !out) return EOD_ERR_NULL;
+  if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(p3) || !eod_aligned16(p4) || !eod_aligned16(p5) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
+  RoiArgs a{};
+  a.feat[0] = p3; a.feat[1] = p4; a.feat[2] = p5;
+  a.h[0] = h3; a.w[0] = w3; a.h[1] = h3 / 2; a.w[1] = w3 / 2; a.h[2] = h3 / 4; a.w[2] = w3 / 4;
+  a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
+  a.C = C; a.boxes = boxes; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
+  const long waves = (long)R_cap * out_size * out_size;
+  long blocks = (waves + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(roi_align_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}

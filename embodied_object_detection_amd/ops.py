@@ -1,0 +1,338 @@
+"""Thin host wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+Every function enqueues HIP kernels on torch's current stream and returns torch tensors that alias the
+buffers the kernels write.  No arithmetic is done with torch ops here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EodConvDesc, EodDetDesc, EodMemWriteDesc, EodProposalDesc, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EodError("HIP product path needs device tensors (no CPU fallback)")
+
+
+class Workspace:
+    """Grow-only scratch buffer per device (split-K slabs, selection scratch)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_conv_ws = Workspace()
+
+
+# ----------------------------------------------------------------------------------------------------
+# weight preparation (host, once per model build)
+# ----------------------------------------------------------------------------------------------------
+def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5):
+    """FrozenBatchNorm2d folded into the preceding bias-free conv."""
+    scale = bn_w / torch.sqrt(bn_var + eps)
+    return w * scale.view(-1, 1, 1, 1), bn_b - bn_mean * scale
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, cin_pad: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """OIHW -> [Cout, Kpad] with k = (ky, kx, c), c fastest; K padded with zeros to a multiple of 32."""
+    O, I, KH, KW = w_oihw.shape
+    w = w_oihw.permute(0, 2, 3, 1).contiguous()  # O,KH,KW,I
+    if cin_pad is not None and cin_pad != I:
+        wp = torch.zeros((O, KH, KW, cin_pad), dtype=w.dtype)
+        wp[..., :I] = w
+        w = wp
+    K = w.shape[1] * w.shape[2] * w.shape[3]
+    Kpad = (K + 31) // 32 * 32
+    out = torch.zeros((O, Kpad), dtype=torch.float32)
+    out[:, :K] = w.reshape(O, K)
+    return out.contiguous(), Kpad
+
+
+class Conv:
+    """One prepared conv / linear layer living on the device."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, pad: int = 0,
+                 device="cuda", cin_pad: Optional[int] = None, deconv: bool = False, name: str = ""):
+        self.name = name
+        if deconv:
+            # ConvTranspose2d(k=2, s=2) weight [Cin, Cout, 2, 2] -> rows n = (dy*2+dx)*Cout + co, K = Cin
+            Cin, Cout, kh, kw = w_oihw.shape
+            assert kh == 2 and kw == 2
+            w = w_oihw.permute(2, 3, 1, 0).reshape(4 * Cout, Cin, 1, 1).contiguous()
+            self.out_mode = 1
+            self.KH = self.KW = 1
+            self.stride, self.pad = 1, 0
+            self.Cin, self.Cout = Cin, 4 * Cout
+        else:
+            w = w_oihw
+            self.out_mode = 0
+            self.Cout, cin, self.KH, self.KW = w.shape
+            self.Cin = cin_pad or cin
+            self.stride, self.pad = stride, pad
+        packed, self.Kpad = pack_conv_weight(w, cin_pad)
+        self.tap4 = 1 if self.Cin == 4 else 0
+        if not self.tap4 and self.Cin % 32 != 0:
+            raise ValueError(f"{name}: Cin={self.Cin} must be a multiple of 32 (or 4 for the stem)")
+        self.w = packed.to(device)
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+        self.desc = EodConvDesc()
+        self._lib = _lib.load()
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def __call__(self, x: torch.Tensor, N: int, H: int, W: int, *, res: Optional[torch.Tensor] = None, res_mode: int = 0,
+                 relu: bool = False, in_relu: bool = False, out_scale: float = 1.0, m_count: Optional[torch.Tensor] = None,
+                 m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0) -> torch.Tensor:
+        _need_cuda(x, res, out)
+        OH, OW = self.out_hw(H, W)
+        if out is None:
+            if self.out_mode == 1:
+                out = torch.empty((N, 2 * OH, 2 * OW, self.Cout // 4), dtype=torch.float32, device=x.device)
+            else:
+                out = torch.empty((N, OH, OW, self.Cout), dtype=torch.float32, device=x.device)
+        d = self.desc
+        d.x, d.w, d.bias, d.res, d.y = x.data_ptr(), self.w.data_ptr(), _ptr(self.bias), _ptr(res), out.data_ptr()
+        d.m_count, d.m_unit = _ptr(m_count), m_unit
+        d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, self.Cin, OH, OW, self.Cout
+        d.KH, d.KW, d.stride, d.pad, d.Kpad = self.KH, self.KW, self.stride, self.pad, self.Kpad
+        d.relu, d.res_mode, d.in_relu, d.out_mode, d.tap4 = int(relu), res_mode, int(in_relu), self.out_mode, self.tap4
+        d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
+        d.workspace, d.workspace_bytes = None, 0
+        need = self._lib.eod_conv2d_workspace_bytes(C.byref(d))
+        if need:
+            ws = _conv_ws.get(need, x.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        check(self._lib.eod_conv2d(C.byref(d), _stream()), f"eod_conv2d[{self.name}]")
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# elementwise / pooling
+# ----------------------------------------------------------------------------------------------------
+def preprocess_image(img_u8_chw: torch.Tensor, mean: Sequence[float], std: Sequence[float], div: int = 32) -> Tuple[torch.Tensor, int, int]:
+    _need_cuda(img_u8_chw)
+    assert img_u8_chw.dtype == torch.uint8 and img_u8_chw.dim() == 3 and img_u8_chw.is_contiguous()
+    _, H, W = img_u8_chw.shape
+    Hp, Wp = (H + div - 1) // div * div, (W + div - 1) // div * div
+    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img_u8_chw.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_lib.load().eod_preprocess_image(img_u8_chw.data_ptr(), out.data_ptr(), H, W, Hp, Wp, m, s, _stream()),
+          "eod_preprocess_image")
+    return out, Hp, Wp
+
+
+def maxpool3x3s2(x: torch.Tensor, N: int, H: int, W: int, Cc: int) -> Tuple[torch.Tensor, int, int]:
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, OH, OW, Cc), dtype=torch.float32, device=x.device)
+    check(_lib.load().eod_maxpool3x3s2(x.data_ptr(), y.data_ptr(), N, H, W, Cc, OH, OW, _stream()), "eod_maxpool3x3s2")
+    return y, OH, OW
+
+
+def groupnorm_relu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, level_off: Sequence[int], Cc: int,
+                   stats: torch.Tensor, groups: int = 32, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    lo = (C.c_int32 * len(level_off))(*level_off)
+    check(_lib.load().eod_groupnorm_relu(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), lo, len(level_off) - 1,
+                                         Cc, groups, eps, stats.data_ptr(), _stream()), "eod_groupnorm_relu")
+    return out
+
+
+def mask_predictor_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: float, rows: int, Cc: int, count: Optional[torch.Tensor],
+                           unit_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.load().eod_mask_predictor_sigmoid(x.data_ptr(), w.data_ptr(), bias, out.data_ptr(), rows, Cc, _ptr(count),
+                                                 unit_rows, _stream()), "eod_mask_predictor_sigmoid")
+    return out
+
+
+def roi_align(p3, p4, p5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count: Optional[torch.Tensor], R_cap: int, S: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty((R_cap, S, S, Cc), dtype=torch.float32, device=p3.device)
+    check(_lib.load().eod_roi_align(p3.data_ptr(), p4.data_ptr(), p5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(count), R_cap, S,
+                                    out.data_ptr(), _stream()), "eod_roi_align")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# selection
+# ----------------------------------------------------------------------------------------------------
+class ProposalDecoder:
+    """CenterNet.inference on device (centernet.py:603-745)."""
+
+    def __init__(self, level_hw: Sequence[Tuple[int, int]], strides: Sequence[int], scales: Sequence[float], score_thresh: float,
+                 pre_nms_topk: int, post_nms_topk: int, nms_thresh: float, cap: int, device, head_stride: int = 5):
+        self.lib = _lib.load()
+        d = EodProposalDesc()
+        off = [0]
+        for (h, w) in level_hw:
+            off.append(off[-1] + h * w)
+        d.levels = len(level_hw)
+        for i, o in enumerate(off):
+            d.level_off[i] = o
+        for i, (h, w) in enumerate(level_hw):
+            d.level_w[i] = w
+            d.level_stride[i] = strides[i]
+            d.level_scale[i] = scales[i]
+        d.head_stride = head_stride
+        d.score_thresh, d.pre_nms_topk, d.post_nms_topk, d.nms_thresh, d.cap = score_thresh, pre_nms_topk, post_nms_topk, nms_thresh, cap
+        nbytes = self.lib.eod_proposals_workspace_bytes(off[-1], d.levels, pre_nms_topk)
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.boxes = torch.zeros((cap, 4), dtype=torch.float32, device=device)
+        self.scores = torch.zeros((cap,), dtype=torch.float32, device=device)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=device)
+        d.out_boxes, d.out_scores, d.out_count = self.boxes.data_ptr(), self.scores.data_ptr(), self.count.data_ptr()
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.desc = d
+        self.total = off[-1]
+        self.level_off = off
+
+    def __call__(self, head_out: torch.Tensor):
+        self.desc.head_out = head_out.data_ptr()
+        check(self.lib.eod_centernet_proposals(C.byref(self.desc), _stream()), "eod_centernet_proposals")
+        return self.boxes, self.scores, self.count
+
+
+class DetectionSelector:
+    """detectron2 fast_rcnn_inference (single image) on device."""
+
+    def __init__(self, R_cap: int, C1: int, topk: int, device):
+        self.lib = _lib.load()
+        self.R_cap, self.C1, self.topk = R_cap, C1, topk
+        nbytes = self.lib.eod_detections_workspace_bytes(R_cap, C1)
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.boxes = torch.zeros((topk, 4), dtype=torch.float32, device=device)
+        self.scores = torch.zeros((topk,), dtype=torch.float32, device=device)
+        self.classes = torch.zeros((topk,), dtype=torch.int32, device=device)
+        self.rows = torch.zeros((topk,), dtype=torch.int32, device=device)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=device)
+        d = EodDetDesc()
+        d.R_cap, d.C1, d.topk = R_cap, C1, topk
+        d.out_boxes, d.out_scores, d.out_classes = self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr()
+        d.out_rows, d.out_count = self.rows.data_ptr(), self.count.data_ptr()
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.desc = d
+
+    def __call__(self, boxes: torch.Tensor, scores: torch.Tensor, count: Optional[torch.Tensor], img_w: float, img_h: float,
+                 score_thresh: float, nms_thresh: float):
+        d = self.desc
+        d.boxes, d.scores, d.count = boxes.data_ptr(), scores.data_ptr(), _ptr(count)
+        d.img_w, d.img_h, d.score_thresh, d.nms_thresh = img_w, img_h, score_thresh, nms_thresh
+        check(self.lib.eod_fast_rcnn_inference(C.byref(d), _stream()), "eod_fast_rcnn_inference")
+        return self.boxes, self.scores, self.classes, self.rows, self.count
+
+
+def zs_classify(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: int, C1: int, temp: float = 50.0):
+    check(_lib.load().eod_zs_classify(feat.data_ptr(), zs.data_ptr(), prob_acc.data_ptr(), int(accumulate), _ptr(featn_out), _ptr(count),
+                                      R_cap, 512, C1, temp, _stream()), "eod_zs_classify")
+
+
+def apply_deltas(deltas, ld: int, boxes, out, count, R_cap: int, weights, clip: bool, img_w: float, img_h: float):
+    wx, wy, ww, wh = weights
+    check(_lib.load().eod_apply_deltas(deltas.data_ptr(), ld, boxes.data_ptr(), out.data_ptr(), _ptr(count), R_cap, wx, wy, ww, wh,
+                                       int(clip), img_w, img_h, _stream()), "eod_apply_deltas")
+
+
+def cascade_scores(prob_acc, prop_scores, count, R_cap: int, C1: int, inv_stages: float):
+    check(_lib.load().eod_cascade_scores(prob_acc.data_ptr(), prop_scores.data_ptr(), _ptr(count), R_cap, C1, inv_stages, _stream()),
+          "eod_cascade_scores")
+
+
+def memory_scores(featn, zs, prop_scores, scores_out, count, R_cap: int, C1: int):
+    check(_lib.load().eod_memory_scores(featn.data_ptr(), zs.data_ptr(), prop_scores.data_ptr(), scores_out.data_ptr(), _ptr(count),
+                                        R_cap, 512, C1, _stream()), "eod_memory_scores")
+
+
+def detector_postprocess(boxes, scores, classes, count, cap: int, sx: float, sy: float, out_w: float, out_h: float, ob, os_, oc, osrc,
+                         ocount):
+    check(_lib.load().eod_detector_postprocess(boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), _ptr(count), cap, sx, sy,
+                                               out_w, out_h, ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), osrc.data_ptr(),
+                                               ocount.data_ptr(), _stream()), "eod_detector_postprocess")
+
+
+def paste_masks(prob, boxes, rows, count, K_cap: int, H: int, W: int, thr: float, out: torch.Tensor):
+    check(_lib.load().eod_paste_masks(prob.data_ptr(), boxes.data_ptr(), _ptr(rows), _ptr(count), K_cap, H, W, thr, out.data_ptr(),
+                                      _stream()), "eod_paste_masks")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# spatial memory
+# ----------------------------------------------------------------------------------------------------
+def unproject_grid_index(depth: torch.Tensor, T: np.ndarray, intr, proj_shift, map_shift, cell: float, map_w: int, map_h: int,
+                         order: int = 0, want_xyz: bool = False):
+    _need_cuda(depth)
+    H, W = depth.shape
+    idx = torch.empty((H, W), dtype=torch.int32, device=depth.device)
+    xyz = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device) if want_xyz else None
+    T16 = (C.c_float * 16)(*np.asarray(T, dtype=np.float32).reshape(-1).tolist())
+    ps = (C.c_float * 3)(*np.asarray(proj_shift, dtype=np.float32).tolist())
+    ms = (C.c_float * 3)(*np.asarray(map_shift, dtype=np.float32).tolist())
+    fx, fy, cx, cy = [float(np.float32(v)) for v in intr]
+    check(_lib.load().eod_unproject_grid_index(depth.data_ptr(), H, W, T16, fx, fy, cx, cy, ps, ms, float(np.float32(cell)), map_w,
+                                               map_h, order, _ptr(xyz), idx.data_ptr(), _stream()), "eod_unproject_grid_index")
+    return (idx, xyz) if want_xyz else idx
+
+
+def memory_normalize_f16(mem: torch.Tensor, obs: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    N, D = mem.shape
+    if out is None:
+        out = torch.empty((N, D), dtype=torch.float16, device=mem.device)
+    check(_lib.load().eod_memory_normalize_f16(mem.data_ptr(), obs.data_ptr(), out.data_ptr(), N, D, _stream()),
+          "eod_memory_normalize_f16")
+    return out
+
+
+def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, outs=None):
+    N, D = mem_f16.shape
+    if outs is None:
+        outs = [torch.empty((1, H // s, W // s, D), dtype=torch.float32, device=mem_f16.device) for s in (8, 16, 32)]
+    check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, outs[0].data_ptr(), outs[1].data_ptr(),
+                                             outs[2].data_ptr(), _stream()), "eod_memory_gather_pool")
+    return outs
+
+
+class MemoryWriter:
+    """a16-a19 write path (custom_rcnn.py:681-760) on device."""
+
+    def __init__(self, H: int, W: int, n_cells: int, K_cap: int, R_cap: int, device, mask_thresh: float = 0.5):
+        self.lib = _lib.load()
+        nbytes = self.lib.eod_memory_write_workspace_bytes(H, W, 512, n_cells, K_cap, R_cap)
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        check(self.lib.eod_memory_write_init(self.ws.data_ptr(), nbytes, H, W, 512, n_cells, R_cap, _stream()), "eod_memory_write_init")
+        self.k_out = torch.zeros((1,), dtype=torch.int32, device=device)
+        d = EodMemWriteDesc()
+        d.K_cap, d.R_cap, d.H, d.W, d.D, d.n_cells, d.mask_thresh = K_cap, R_cap, H, W, 512, n_cells, mask_thresh
+        d.workspace, d.workspace_bytes, d.k_out = self.ws.data_ptr(), nbytes, self.k_out.data_ptr()
+        self.desc = d
+
+    def __call__(self, featn, prop_boxes, prop_masks, det_rows, det_count, proj, mem, obs):
+        d = self.desc
+        d.featn, d.prop_boxes, d.prop_masks = featn.data_ptr(), prop_boxes.data_ptr(), prop_masks.data_ptr()
+        d.det_rows, d.det_count, d.proj, d.mem, d.obs = det_rows.data_ptr(), det_count.data_ptr(), proj.data_ptr(), mem.data_ptr(), obs.data_ptr()
+        check(self.lib.eod_memory_write(C.byref(d), _stream()), "eod_memory_write")
+        return self.k_out

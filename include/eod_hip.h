@@ -1,0 +1,196 @@
+/* C ABI of libeod_hip.so  --  the MI355X (gfx950) kernels of the embodied-detector hot path.
+ *
+ * The reference (nhcha6/embodied-object-detection) has NO native code on this path: every op is a stock
+ * PyTorch / torchvision / detectron2 call made from Python.  There is therefore no
+ * reference FFI to mirror; each entry point below cites the reference Python call site whose arithmetic it
+ * replaces.  Contract for every function:
+ *   - the caller owns every buffer (device pointers, allocated by the host framework); kernels never
+ *     allocate, free or synchronise; work is enqueued on `stream`;
+ *   - returns 0 on success, a negative EOD_ERR_* code on bad dimensions / misalignment / launch failure;
+ *     never throws;
+ *   - thread-compatible (one host thread per process / GPU, as detectron2's `launch` runs it,
+ *     Detic/train_mp3d.py:850).
+ * All activations are NHWC fp32.  "count" pointers are device ints holding a dynamic number of valid rows
+ * (ROIs / detections) so that data-dependent sizes never force a host sync.
+ */
+#ifndef EOD_HIP_H
+#define EOD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* eod_stream_t; /* hipStream_t */
+
+#define EOD_OK 0
+#define EOD_ERR_BAD_DIMS (-1)
+#define EOD_ERR_ALIGN (-2)
+#define EOD_ERR_LAUNCH (-3)
+#define EOD_ERR_NULL (-4)
+#define EOD_ERR_CAPACITY (-5)
+
+int eod_abi_version(void);
+
+/* ---- dense contraction: implicit-GEMM convolution / linear layer on fp32 MFMA ------------------------
+ * Replaces every nn.Conv2d / nn.Linear / ConvTranspose2d(2,2) of the path: timm ResNet-50
+ * (Detic/detic/modeling/backbone/timm.py:277-299), FPN lateral/output convs (timm.py:118-136), memory 1x1
+ * projection + scale + sum fusion (timm.py:174-186), LastLevelP6P7_P5 (timm.py:359-364), CenterNetHead convs
+ * (centernet_head.py:141-161), FastRCNNConvFCHead / bbox_pred / cls linear
+ * (detic_fast_rcnn.py:437-466, zero_shot_classifier.py:78), mask head convs + deconv (d2
+ * MaskRCNNConvUpsampleHead via detic_roi_heads.py:257,268).
+ *   y[m][n] = act( (sum_k A[m][k] * w[n][k] + bias[n]) * out_scale + res[m][n] )
+ * A is the im2col view of x (NHWC), k ordered (ky, kx, c); w is [Cout][Kpad] with Kpad % 32 == 0.          */
+typedef struct EodConvDesc {
+  const float* x;      /* [N,H,W,Cin] */
+  const float* w;      /* [Cout,Kpad] */
+  const float* bias;   /* [Cout] or NULL ([Cout/4] for out_mode 1) */
+  const float* res;    /* residual or NULL */
+  float* y;            /* [N,OH,OW,Cout] (out_mode 0) / [N,2OH,2OW,Cout/4] (out_mode 1) */
+  float* workspace;    /* split-K slabs, >= workspace_bytes */
+  size_t workspace_bytes;
+  const int32_t* m_count; /* optional device int: number of valid units (each m_unit output rows) */
+  int32_t m_unit;
+  int32_t N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad;
+  int32_t relu;      /* ReLU on the output */
+  int32_t res_mode;  /* 0 none, 1 same-shape add, 2 add nearest-x2-upsampled res [N,OH/2,OW/2,Cout] */
+  int32_t in_relu;   /* ReLU applied to x on load (p7 = conv(relu(p6)), timm.py:362) */
+  int32_t out_mode;  /* 0 NHWC, 1 ConvTranspose2d(k2,s2) scatter: n = (dy*2+dx)*Cout/4 + co */
+  int32_t tap4;      /* 1: Cin == 4 (stem, RGB padded to 4): one float4 per tap */
+  int32_t force_tile; /* 0 auto, else 1=128x128 2=128x64 3=64x64 (benchmarks/tests) */
+  int32_t force_splitk; /* 0 auto */
+  float out_scale;
+} EodConvDesc;
+int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
+size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
+
+/* ---- small dense / elementwise ops -------------------------------------------------------------------- */
+/* d2 GeneralizedRCNN.preprocess_image (custom_rcnn.py:557): u8 CHW RGB -> (x-mean)/std, NHWC4 (4th channel
+ * 0), zero padded to [Hp,Wp]. */
+int eod_preprocess_image(const uint8_t* img_chw, float* out_nhwc4, int H, int W, int Hp, int Wp,
+                         const float* mean3, const float* std3, eod_stream_t stream);
+/* timm ResNet maxpool 3x3 s2 p1 (timm.py:281) */
+int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, eod_stream_t stream);
+/* GroupNorm(32)+ReLU over the 5 concatenated FPN levels (centernet_head.py:76-79); x,y [P,C], level l owns
+ * rows [level_off[l], level_off[l+1]). stats workspace: 2*levels*groups floats. */
+int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
+                       int levels, int C, int groups, float eps, float* stats, eod_stream_t stream);
+/* mask predictor 1x1 conv -> 1 channel + sigmoid (d2 mask head predictor + mask_rcnn_inference,
+ * custom_rcnn.py:574): x [R*784,C] -> prob [R*784] */
+int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,
+                               const int32_t* unit_count, int unit_rows, eod_stream_t stream);
+
+/* ---- ROIAlignV2 over p3..p5 (d2 ROIPooler, detic_roi_heads.py:332,265) -------------------------------- */
+int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C,
+                  const float* boxes /*[R,4]*/, const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/,
+                  eod_stream_t stream);
+
+/* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
+typedef struct EodProposalDesc {
+  const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */
+  int32_t head_stride;     /* 8 */
+  int32_t levels;          /* 5 */
+  int32_t level_off[6];    /* row offsets per level */
+  int32_t level_w[5];
+  int32_t level_stride[5];
+  float level_scale[5];    /* Scale module values (centernet_head.py:159) */
+  float score_thresh;      /* INFERENCE_TH */
+  int32_t pre_nms_topk;    /* 1000 */
+  int32_t post_nms_topk;   /* 256 */
+  float nms_thresh;        /* 0.9 */
+  int32_t cap;             /* capacity of out_* (>= post_nms_topk) */
+  float* out_boxes;        /* [cap,4] */
+  float* out_scores;       /* [cap] */
+  int32_t* out_count;      /* [1] */
+  void* workspace;         /* >= eod_proposals_workspace_bytes() */
+  size_t workspace_bytes;
+} EodProposalDesc;
+size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk);
+int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream);
+
+/* ---- cascade box head glue ---------------------------------------------------------------------------- */
+/* ZeroShotClassifier tail (zero_shot_classifier.py:86-106): x=50*feat/max(|feat|,1e-12); logits=x@zs [512,C1];
+ * prob_acc (+)= sigmoid(logits) (predict_probs, detic_fast_rcnn.py:325-339). */
+int eod_zs_classify(const float* feat /*[R,512]*/, const float* zs /*[512,C1]*/, float* prob_acc /*[R,C1]*/, int accumulate,
+                    float* feat_norm_out /*[R,512] or NULL*/, const int32_t* count, int R_cap, int D, int C1, float temp,
+                    eod_stream_t stream);
+/* Box2BoxTransform.apply_deltas + optional clip (detic_roi_heads.py:121-122,314) */
+int eod_apply_deltas(const float* deltas /*[R,ld]*/, int ld, const float* boxes, float* out, const int32_t* count, int R_cap,
+                     float wx, float wy, float ww, float wh, int clip, float img_w, float img_h, eod_stream_t stream);
+/* scores = sqrt(mean_k(prob) * proposal_score) (detic_roi_heads.py:164-173) in place on prob_acc */
+int eod_cascade_scores(float* prob_acc, const float* prop_scores, const int32_t* count, int R_cap, int C1, float inv_stages,
+                       eod_stream_t stream);
+
+/* d2 fast_rcnn_inference, single image (detic_roi_heads.py:214-221, custom_rcnn.py:862-869) */
+typedef struct EodDetDesc {
+  const float* boxes;     /* [R,4] class agnostic */
+  const float* scores;    /* [R,C1] (last column = background) */
+  const int32_t* count;   /* number of valid rows */
+  int32_t R_cap, C1;
+  float img_w, img_h, score_thresh, nms_thresh;
+  int32_t topk;
+  float* out_boxes;       /* [topk,4] clipped */
+  float* out_scores;      /* [topk] */
+  int32_t* out_classes;   /* [topk] */
+  int32_t* out_rows;      /* [topk] proposal row of each detection */
+  int32_t* out_count;     /* [1] */
+  void* workspace; size_t workspace_bytes;
+} EodDetDesc;
+size_t eod_detections_workspace_bytes(int R_cap, int C1);
+int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream);
+
+/* d2 detector_postprocess without the mask paste (custom_rcnn.py:579): scale, clip, drop empty boxes.
+ * out_src[q] = index of the kept detection in the input list. cap <= 512. */
+int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
+                             float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
+                             int32_t* out_classes, int32_t* out_src, int32_t* out_count, eod_stream_t stream);
+/* paste_masks_in_image (d2, inside detector_postprocess; custom_rcnn.py:579,880): out[k] = grid_sample(prob[rows[k]],
+ * box k) >= threshold, u8 [K,H,W].  rows NULL = identity. */
+int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap,
+                    int H, int W, float threshold, uint8_t* out, eod_stream_t stream);
+
+/* ---- spatial feature memory --------------------------------------------------------------------------- */
+/* a1+a2: ProjectorUtils.pixel_to_world_mapping (SMNet/projector/core.py:177-225) + grid-cell index
+ * (SMNet/build_memory_data.py:135-144, robot_demo.py:526-534).  INT result, bit-exact vs oracle/projector.c */
+int eod_unproject_grid_index(const float* depth, int H, int W, const float* T16_host, float fx, float fy, float cx, float cy,
+                             const float* proj_shift3_host, const float* map_shift3_host, float cell, int map_w, int map_h,
+                             int order, float* xyz_or_null, int32_t* idx, eod_stream_t stream);
+/* a4 + fp16 cast (custom_rcnn.py:762-774,1036): out_f16[n] = half(obs>1 ? mem/obs : mem) */
+int eod_memory_normalize_f16(const float* mem, const float* obs, uint16_t* out_f16, int n_cells, int D, eod_stream_t stream);
+/* a8 gather + cascaded average pooling (timm.py:147-168): pooled8/16/32 [h,w,512] hold fp16-rounded values as f32 */
+int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells,
+                           float* pooled8, float* pooled16, float* pooled32, eod_stream_t stream);
+/* a16 scoring of proposals in CLIP space (custom_rcnn.py:848-855): scores = sqrt(sigmoid(featn@zs)*ps) */
+int eod_memory_scores(const float* featn /*[R,512]*/, const float* zs, const float* prop_scores, float* scores /*[R,C1]*/,
+                      const int32_t* count, int R_cap, int D, int C1, eod_stream_t stream);
+/* a16-a19 write path (custom_rcnn.py:681-760,875-936) */
+typedef struct EodMemWriteDesc {
+  const float* featn;       /* [R,512] normalised x50 proposal features */
+  const float* prop_boxes;  /* [R,4] unclipped proposal boxes */
+  const float* prop_masks;  /* [R,28,28] mask probabilities */
+  const int32_t* det_rows;  /* [K_cap] proposal rows kept by fast_rcnn_inference (with duplicates) */
+  const int32_t* det_count; /* [1] */
+  int32_t K_cap, R_cap;
+  const int32_t* proj;      /* [H,W] */
+  int32_t H, W, D, n_cells;
+  float mask_thresh;
+  float* mem;               /* [N,512] accumulator (semmap_features / implicit_memory) */
+  float* obs;               /* [N] observation counts */
+  int32_t* k_out;           /* [1] number of unique instances written (diagnostic) */
+  void* workspace; size_t workspace_bytes;
+} EodMemWriteDesc;
+size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap);
+int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream);
+/* zero the per-frame cell flags inside the workspace once after allocation (eod_memory_write leaves them zero) */
+int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int R_cap,
+                          eod_stream_t stream);
+
+/* utility */
+int eod_fill_f32(float* p, float v, size_t n, eod_stream_t stream);
+int eod_fill_i32(int32_t* p, int32_t v, size_t n, eod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOD_HIP_H */

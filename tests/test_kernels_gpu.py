@@ -1,0 +1,446 @@
+"""Kernel-level parity: every HIP entry point (through the C ABI) against the CPU oracle on seeded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import memory as OM
+from oracle import model as M
+from oracle import ops as OO
+from oracle import projector as OP
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from embodied_object_detection_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def nhwc(x):  # NCHW cpu -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def close(a, b, rtol=2e-4, atol=2e-4):
+    a = a.detach().cpu().float()
+    b = b.detach().cpu().float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (|ref| max {b.abs().max().item():.3e})"
+
+
+# ------------------------------------------------------------------------------------------------
+# implicit-GEMM conv
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (1, 20, 24, 64, 64, 1, 1, 0),
+    (1, 20, 24, 64, 128, 3, 1, 1),
+    (1, 21, 19, 128, 96, 3, 2, 1),
+    (1, 16, 16, 256, 512, 1, 2, 0),
+    (3, 14, 14, 256, 256, 3, 1, 1),
+    (2, 7, 9, 32, 5, 3, 1, 1),
+    (1, 10, 10, 2048, 256, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2)])
+def test_conv_matches_f_conv2d(dev, case, tile, splitk):
+    from embodied_object_detection_amd import ops
+    N, H, W, Cin, Cout, k, stride, pad = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=3)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
+    y = conv(nhwc(x).to(dev), N, H, W, force_tile=tile, force_splitk=splitk)
+    close(nchw(y), ref)
+
+
+def test_conv_epilogues(dev):
+    from embodied_object_detection_amd import ops
+    N, H, W, Cin, Cout = 1, 12, 16, 64, 96
+    x = rnd(N, Cin, H, W, seed=4)
+    w = rnd(Cout, Cin, 3, 3, seed=5, scale=0.05)
+    b = rnd(Cout, seed=6)
+    res = rnd(N, Cout, H, W, seed=7)
+    conv = ops.Conv(w, b, stride=1, pad=1, device=dev)
+    xd = nhwc(x).to(dev)
+    # residual add + relu (bottleneck tail)
+    y = conv(xd, N, H, W, res=nhwc(res).to(dev), res_mode=1, relu=True)
+    close(nchw(y), F.relu(F.conv2d(x, w, b, padding=1) + res))
+    # nearest x2 upsampled residual (FPN top-down, timm.py:131-133)
+    res_small = rnd(N, Cout, H // 2, W // 2, seed=8)
+    y = conv(xd, N, H, W, res=nhwc(res_small).to(dev), res_mode=2)
+    close(nchw(y), F.conv2d(x, w, b, padding=1) + F.interpolate(res_small, scale_factor=2.0, mode="nearest"))
+    # (conv + bias) * weight + res (memory fusion, timm.py:174-182), also through split-K
+    for sk in (1, 3):
+        y = conv(xd, N, H, W, res=nhwc(res).to(dev), res_mode=1, out_scale=5.0, force_splitk=sk, force_tile=3)
+        close(nchw(y), F.conv2d(x, w, b, padding=1) * 5.0 + res, rtol=3e-4, atol=3e-4)
+    # relu on the input (p7 = conv(relu(p6)), timm.py:362)
+    y = conv(xd, N, H, W, in_relu=True)
+    close(nchw(y), F.conv2d(F.relu(x), w, b, padding=1))
+
+
+def test_conv_stem_tap4_with_bn_fold(dev):
+    from embodied_object_detection_amd import ops
+    H, W = 64, 96
+    x = rnd(1, 3, H, W, seed=9)
+    w = rnd(64, 3, 7, 7, seed=10, scale=0.1)
+    g = torch.rand(64) + 0.5
+    beta = rnd(64, seed=11, scale=0.1)
+    mean = rnd(64, seed=12, scale=0.1)
+    var = torch.rand(64) + 0.5
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, stride=2, padding=3), mean, var, g, beta, training=False, eps=1e-5))
+    wf, bf = ops.fold_bn(w, g, beta, mean, var)
+    conv = ops.Conv(wf, bf, stride=2, pad=3, device=dev, cin_pad=4)
+    x4 = torch.zeros((1, H, W, 4))
+    x4[..., :3] = nhwc(x)
+    y = conv(x4.to(dev), 1, H, W, relu=True)
+    close(nchw(y), ref)
+
+
+def test_linear_as_conv_and_dynamic_rows(dev):
+    from embodied_object_detection_amd import ops
+    R, K, O = 37, 12544, 1024
+    x = rnd(R, K, seed=13)
+    w = rnd(O, K, seed=14, scale=(1.0 / K) ** 0.5)
+    b = rnd(O, seed=15)
+    fc = ops.Conv(w.view(O, K, 1, 1), b, device=dev)
+    cnt = torch.tensor([29], dtype=torch.int32, device=dev)
+    out = torch.full((R, 1, 1, O), -7.0, device=dev)
+    fc(x.to(dev), R, 1, 1, relu=True, m_count=cnt, m_unit=1, out=out)
+    ref = F.relu(F.linear(x, w, b))
+    close(out.view(R, O)[:29], ref[:29])
+    assert bool((out.view(R, O)[29:] == -7.0).all()), "rows beyond the device-side count must not be written"
+
+
+def test_deconv2x2(dev):
+    from embodied_object_detection_amd import ops
+    R, Cc = 5, 256
+    x = rnd(R, Cc, 14, 14, seed=16)
+    w = rnd(Cc, Cc, 2, 2, seed=17, scale=0.05)
+    b = rnd(Cc, seed=18)
+    dc = ops.Conv(w, b, device=dev, deconv=True)
+    y = dc(nhwc(x).to(dev), R, 14, 14, relu=True)
+    assert tuple(y.shape) == (R, 28, 28, Cc)
+    close(nchw(y), F.relu(F.conv_transpose2d(x, w, b, stride=2)))
+
+
+def test_conv_rejects_bad_descriptors(dev):
+    from embodied_object_detection_amd import _lib, ops
+    w = rnd(8, 48, 1, 1)
+    with pytest.raises(ValueError):
+        ops.Conv(w, None, device=dev)  # Cin not a multiple of 32
+    conv = ops.Conv(rnd(8, 32, 1, 1), None, device=dev)
+    with pytest.raises(_lib.EodError):
+        conv(torch.zeros((1, 4, 4, 32)), 1, 4, 4)  # host tensor: no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------------------------
+def test_preprocess_maxpool(dev):
+    from embodied_object_detection_amd import ops
+    cfg = M.OracleCfg()
+    img = torch.randint(0, 256, (3, 50, 70), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    ref = M.preprocess_image(img, cfg)
+    out, Hp, Wp = ops.preprocess_image(img.to(dev), cfg.pixel_mean, cfg.pixel_std)
+    assert (Hp, Wp) == (64, 96)
+    close(nchw(out)[:, :3], ref, rtol=1e-6, atol=1e-6)
+    assert float(out[..., 3].abs().max()) == 0.0
+    x = rnd(2, 64, 33, 41, seed=2)
+    y, OH, OW = ops.maxpool3x3s2(nhwc(x).to(dev), 2, 33, 41, 64)
+    close(nchw(y), F.max_pool2d(x, 3, 2, 1), rtol=0, atol=0)
+
+
+def test_groupnorm_relu_multilevel(dev):
+    from embodied_object_detection_amd import ops
+    hw = [(8, 12), (4, 6), (2, 3), (1, 2), (1, 1)]
+    Cc = 256
+    xs = [rnd(1, Cc, h, w, seed=10 + i, scale=2.0) + 0.3 for i, (h, w) in enumerate(hw)]
+    gamma = torch.rand(Cc) + 0.5
+    beta = rnd(Cc, seed=20, scale=0.2)
+    flat = torch.cat([nhwc(x).reshape(-1, Cc) for x in xs]).to(dev)
+    off = [0]
+    for h, w in hw:
+        off.append(off[-1] + h * w)
+    stats = torch.empty((2 * 5 * 32,), device=dev)
+    y = ops.groupnorm_relu(flat, gamma.to(dev), beta.to(dev), off, Cc, stats).cpu()
+    for i, x in enumerate(xs):
+        ref = F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-5))
+        close(y[off[i]:off[i + 1]], nhwc(ref).reshape(-1, Cc), rtol=1e-4, atol=1e-4)
+
+
+def test_mask_predictor(dev):
+    from embodied_object_detection_amd import ops
+    rows, Cc = 3 * 784, 256
+    x = rnd(rows, Cc, seed=30)
+    w = rnd(Cc, seed=31, scale=0.1)
+    cnt = torch.tensor([2], dtype=torch.int32, device=dev)
+    out = torch.full((rows,), -1.0, device=dev)
+    ops.mask_predictor_sigmoid(x.to(dev), w.to(dev), 0.25, rows, Cc, cnt, 784, out=out)
+    ref = torch.sigmoid(x @ w + 0.25)
+    close(out[:2 * 784], ref[:2 * 784], rtol=1e-5, atol=1e-5)
+    assert bool((out[2 * 784:] == -1.0).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# ROIAlign
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [7, 14])
+def test_roi_align_matches_oracle(dev, S):
+    from embodied_object_detection_amd import ops
+    h3, w3, Cc = 16, 24, 256
+    feats = [rnd(1, Cc, h3 >> i, w3 >> i, seed=40 + i) for i in range(3)]
+    g = torch.Generator().manual_seed(5)
+    R = 24
+    ctr = torch.rand((R, 2), generator=g) * torch.tensor([w3 * 8.0, h3 * 8.0])
+    size = torch.exp(torch.rand((R, 2), generator=g) * 4.0 + 1.0)   # ~3 .. 150 px (all three levels)
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], dim=1)
+    boxes[0] = torch.tensor([-20.0, -30.0, 60.0, 50.0])             # sticks out of the image
+    boxes[1] = torch.tensor([10.0, 10.0, 10.01, 10.01])             # minimum-size proposal
+    ref = OO.roi_pool(feats, boxes, S)
+    cnt = torch.tensor([R - 2], dtype=torch.int32, device=dev)
+    out = ops.roi_align(*[nhwc(f).to(dev) for f in feats], h3, w3, Cc, boxes.to(dev), cnt, R, S)
+    close(nchw(out)[:R - 2], ref[:R - 2], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# selection
+# ------------------------------------------------------------------------------------------------
+def _head_case(level_hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    agn, reg = [], []
+    for (h, w) in level_hw:
+        agn.append(torch.randn((1, 1, h, w), generator=g) * 1.5 - 1.0)
+        reg.append(torch.randn((1, 4, h, w), generator=g) * 2.0 + 3.0)
+    return agn, reg
+
+
+@pytest.mark.parametrize("level_hw,topk,post", [
+    ([(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)], 1000, 256),
+    ([(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)], 1000, 256),   # level 0 > pre-NMS top-k
+    ([(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)], 100, 64),
+])
+def test_centernet_proposals_match_oracle(dev, level_hw, topk, post):
+    from embodied_object_detection_amd import ops
+    agn, reg = _head_case(level_hw, seed=3)
+    scales = [0.9, 1.0, 1.1, 1.2, 0.8]
+    cfg = M.OracleCfg(pre_nms_topk=topk, post_nms_topk=post)
+    # oracle consumes relu(scale * bbox_pred)
+    reg_o = [F.relu(r * s) for r, s in zip(reg, scales)]
+    rb, rs = M.centernet_proposals(agn, reg_o, cfg)
+    head = torch.cat([torch.cat([nhwc(a).reshape(-1, 1), nhwc(r).reshape(-1, 4)], dim=1) for a, r in zip(agn, reg)]).contiguous()
+    dec = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, scales, cfg.inference_th, topk, post, cfg.nms_th_proposal, cap=post + 64, device=dev)
+    b, s, c = dec(head.to(dev))
+    n = int(c.item())
+    assert n == rb.shape[0]
+    close(s[:n], rs, rtol=1e-6, atol=1e-6)
+    close(b[:n], rb, rtol=1e-5, atol=1e-4)
+
+
+def test_centernet_proposals_keep_ties(dev):
+    from embodied_object_detection_amd import ops
+    level_hw = [(12, 12), (6, 6), (3, 3), (2, 2), (1, 1)]
+    agn = [torch.full((1, 1, h, w), 0.5) for h, w in level_hw]      # every score identical
+    reg = [torch.full((1, 4, h, w), 0.2) for h, w in level_hw]      # tiny boxes: NMS removes nothing
+    cfg = M.OracleCfg(post_nms_topk=32)
+    rb, rs = M.centernet_proposals(agn, [F.relu(r) for r in reg], cfg)
+    assert rb.shape[0] == 144 + 36 + 9 + 4 + 1                      # '>= kth' keeps every tie
+    head = torch.cat([torch.cat([nhwc(a).reshape(-1, 1), nhwc(r).reshape(-1, 4)], dim=1) for a, r in zip(agn, reg)]).contiguous()
+    dec = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, [1.0] * 5, cfg.inference_th, 1000, 32, 0.9, cap=256, device=dev)
+    b, s, c = dec(head.to(dev))
+    assert int(c.item()) == rb.shape[0]
+    close(b[:rb.shape[0]], rb, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("thresh,topk,R", [(0.02, 300, 256), (0.3, 100, 256), (0.6, 50, 40), (0.999, 10, 16)])
+def test_fast_rcnn_inference_matches_oracle(dev, thresh, topk, R):
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(11)
+    ctr = torch.rand((R, 2), generator=g) * torch.tensor([200.0, 150.0])
+    size = torch.rand((R, 2), generator=g) * 80 + 4
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], dim=1)
+    scores = torch.rand((R, 21), generator=g)
+    scores[3, 5] = float("nan")                                     # non-finite rows are dropped
+    boxes[7, 2] = float("inf")
+    rb, rs, rc, rr = OO.fast_rcnn_inference_single(boxes, scores, (150, 200), thresh, 0.5, topk)
+    cap = 320
+    bp = torch.zeros((cap, 4)); bp[:R] = boxes
+    sp = torch.zeros((cap, 21)); sp[:R] = scores
+    sel = ops.DetectionSelector(cap, 21, topk, dev)
+    cnt = torch.tensor([R], dtype=torch.int32, device=dev)
+    b, s, c, r, n = sel(bp.to(dev), sp.to(dev), cnt, 200.0, 150.0, thresh, 0.5)
+    n = int(n.item())
+    assert n == rb.shape[0]
+    if n:
+        close(s[:n], rs, rtol=0, atol=0)
+        close(b[:n], rb, rtol=0, atol=0)
+        assert torch.equal(c[:n].cpu().long(), rc.long())
+        assert torch.equal(r[:n].cpu().long(), rr.long())
+
+
+def test_box_head_glue(dev):
+    from embodied_object_detection_amd import ops
+    from embodied_object_detection_amd.checkpoint import load_zs_weight
+    R, cap = 50, 64
+    zs = load_zs_weight()
+    feat = rnd(cap, 512, seed=21)
+    cnt = torch.tensor([R], dtype=torch.int32, device=dev)
+    prob = torch.zeros((cap, 21), device=dev)
+    featn = torch.zeros((cap, 512), device=dev)
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob, False, featn, cnt, cap, 21)
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob, True, None, cnt, cap, 21)
+    xn = 50.0 * F.normalize(feat, p=2, dim=1)
+    ref = torch.sigmoid(xn @ zs)
+    close(featn[:R], xn[:R], rtol=1e-5, atol=1e-5)
+    close(prob[:R], 2 * ref[:R], rtol=1e-5, atol=1e-5)
+    ps = torch.rand(cap)
+    ops.cascade_scores(prob, ps.to(dev), cnt, cap, 21, 0.5)
+    close(prob[:R], (ref[:R] * ps[:R, None]) ** 0.5, rtol=1e-5, atol=1e-6)
+    ms = torch.zeros((cap, 21), device=dev)
+    ps[4] = 1.0
+    ops.memory_scores(featn, zs.to(dev), ps.to(dev), ms, cnt, cap, 21)
+    ref_ms = (torch.sigmoid(xn @ zs) * ps[:, None]) ** 0.5
+    ref_ms[4] = 0
+    close(ms[:R], ref_ms[:R], rtol=1e-5, atol=1e-6)
+    # apply_deltas + clip
+    boxes = torch.rand((cap, 4)) * 100
+    boxes[:, 2:] += boxes[:, :2] + 1
+    deltas = rnd(cap, 4, seed=22, scale=3.0)
+    deltas[0, 2] = 100.0                                            # hits the log(1000/16) clamp
+    out = torch.zeros((cap, 4), device=dev)
+    ops.apply_deltas(deltas.to(dev), 4, boxes.to(dev), out, cnt, cap, (10.0, 10.0, 5.0, 5.0), True, 160.0, 120.0)
+    ref = OO.clip_boxes(OO.apply_deltas(deltas, boxes, (10.0, 10.0, 5.0, 5.0)), (120, 160))
+    close(out[:R], ref[:R], rtol=1e-5, atol=1e-4)
+
+
+def test_postprocess_and_paste_masks(dev):
+    from embodied_object_detection_amd import ops
+    K, H, W = 9, 96, 128
+    g = torch.Generator().manual_seed(31)
+    masks = torch.rand((K, 28, 28), generator=g)
+    ctr = torch.rand((K, 2), generator=g) * torch.tensor([float(W), float(H)])
+    size = torch.rand((K, 2), generator=g) * 60 + 3
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], dim=1)
+    boxes[2] = torch.tensor([-30.0, 10.0, -5.0, 40.0])             # fully outside -> empty after clip -> dropped
+    boxes = OO.clip_boxes(boxes, (H, W))
+    scores = torch.rand(K, generator=g)
+    classes = torch.randint(0, 20, (K,), generator=g)
+    ref = M.detector_postprocess(boxes, scores, classes, masks[:, None], (H, W), (H, W), M.OracleCfg())
+    cap = 16
+    bp = torch.zeros((cap, 4)); bp[:K] = boxes
+    sp = torch.zeros(cap); sp[:K] = scores
+    cp = torch.zeros(cap, dtype=torch.int32); cp[:K] = classes.int()
+    ob = torch.zeros((cap, 4), device=dev); os_ = torch.zeros(cap, device=dev)
+    oc = torch.zeros(cap, dtype=torch.int32, device=dev); osrc = torch.zeros(cap, dtype=torch.int32, device=dev)
+    ocnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    cnt = torch.tensor([K], dtype=torch.int32, device=dev)
+    ops.detector_postprocess(bp.to(dev), sp.to(dev), cp.to(dev), cnt, cap, 1.0, 1.0, float(W), float(H), ob, os_, oc, osrc, ocnt)
+    n = int(ocnt.item())
+    assert n == ref["pred_boxes"].shape[0] == K - 1
+    close(ob[:n], ref["pred_boxes"], rtol=0, atol=0)
+    mp = torch.zeros((cap, 28, 28)); mp[:K] = masks
+    out = torch.zeros((cap, H, W), dtype=torch.uint8, device=dev)
+    ops.paste_masks(mp.to(dev), ob, osrc, ocnt, cap, H, W, 0.5, out)
+    got = out[:n].cpu().bool()
+    mism = (got != ref["pred_masks"]).float().mean().item()
+    assert mism < 1e-4, f"pasted mask mismatch fraction {mism}"
+
+
+# ------------------------------------------------------------------------------------------------
+# spatial memory
+# ------------------------------------------------------------------------------------------------
+def test_unproject_grid_index_bit_exact(dev):
+    from embodied_object_detection_amd import ops
+    rng = np.random.RandomState(3)
+    H, W = 96, 160
+    depth = np.clip(3 + rng.randn(H, W) * 1.5, 0.0, 10).astype(np.float32)
+    depth[0, :5] = 0.0
+    T = OP.transform3d([2.0, 1.5, 2.5, 0.7, math.pi])
+    intr = OP.intrinsics_from_vfov(W, H, 67.5 * math.pi / 180)
+    for order, (mw, mh) in ((0, (50, 40)), (1, (200, 200))):
+        xyz_ref = OP.unproject_world(depth, T, *intr, proj_shift=(0.1, 0.0, -0.2))
+        idx_ref = OP.grid_index(xyz_ref, (-5, 0, -5), 0.2, mw, mh, order)
+        idx, xyz = ops.unproject_grid_index(torch.from_numpy(depth).to(dev), T, intr, (0.1, 0.0, -0.2), (-5, 0, -5), 0.2, mw, mh, order,
+                                            want_xyz=True)
+        assert np.array_equal(xyz.cpu().numpy(), xyz_ref), "world xyz must be bit-identical to oracle/projector.c"
+        assert np.array_equal(idx.cpu().numpy(), idx_ref), "grid-cell indices must be bit-exact"
+
+
+def test_memory_read_matches_oracle(dev):
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, H, W = 500, 64, 96
+    mem = torch.randn((N, 512), generator=g) * 30
+    obs = torch.randint(0, 6, (N,), generator=g).float()
+    proj = torch.randint(0, N, (H, W), generator=g)
+    blocky = ((torch.arange(H)[:, None] // 6) * 17 + (torch.arange(W)[None, :] // 9)) % N
+    proj = torch.where(torch.rand((H, W), generator=g) < 0.7, blocky, proj)
+    ref_norm = OM.create_implicit_memory(mem, obs).to(torch.half)
+    m16 = ops.memory_normalize_f16(mem.to(dev), obs.to(dev))
+    assert torch.equal(m16.cpu(), ref_norm), "obs-normalised fp16 memory must be bit-exact"
+    pooled_ref = M.memory_read_pooled(ref_norm, proj)
+    outs = ops.memory_gather_pool(m16, proj.int().to(dev), H, W)
+    for o, r in zip(outs, pooled_ref):
+        r32 = nhwc(r.float())
+        same = (o.cpu() == r32).float().mean().item()
+        assert same > 0.999, f"fp16-rounded pooled values differ on {1 - same:.2e} of elements"
+        close(o, r32, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("K,thresh", [(12, 0.5), (0, 0.5)])
+def test_memory_write_matches_oracle(dev, K, thresh):
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(17)
+    H, W, N, R = 64, 96, 300, 40
+    boxes = torch.zeros((R, 4))
+    ctr = torch.rand((R, 2), generator=g) * torch.tensor([float(W), float(H)])
+    size = torch.rand((R, 2), generator=g) * 40 + 6
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], dim=1)
+    masks = torch.rand((R, 28, 28), generator=g)
+    featn = 50 * F.normalize(torch.randn((R, 512), generator=g), dim=1)
+    proj = torch.randint(0, N, (H, W), generator=g)
+    det_rows = torch.randint(0, R, (max(K, 1),), generator=g)
+    mem0 = torch.randn((N, 512), generator=g)
+    obs0 = torch.randint(0, 3, (N,), generator=g).float()
+    # oracle
+    mem_ref, obs_ref = mem0.clone(), obs0.clone()
+    if K > 0:
+        rows = torch.unique(det_rows[:K])
+        pasted = OO.paste_masks(masks[rows], boxes[rows], (H, W), thresh)
+        mean, observed_mem = OM.memory_write_sparse(featn[rows], pasted, proj, N)
+        upd = torch.zeros((N, 512)); upd[observed_mem] = mean
+        mem_ref = mem_ref + upd
+        ou = torch.zeros(N); ou[torch.unique(proj)] = 1
+        obs_ref = obs_ref + ou
+    wr = ops.MemoryWriter(H, W, N, 100, R, dev, mask_thresh=thresh)
+    mem_d, obs_d = mem0.to(dev), obs0.to(dev)
+    dr = torch.zeros(100, dtype=torch.int32); dr[:max(K, 1)] = det_rows.int()
+    cnt = torch.tensor([K], dtype=torch.int32, device=dev)
+    for rep in range(2):   # second call must start from clean per-frame flags
+        mem_d, obs_d = mem0.to(dev), obs0.to(dev)
+        k_out = wr(featn.to(dev), boxes.to(dev), masks.to(dev), dr.to(dev), cnt, proj.int().to(dev), mem_d, obs_d)
+        assert int(k_out.item()) == (len(torch.unique(det_rows[:K])) if K else 0)
+        assert torch.equal(obs_d.cpu(), obs_ref), "observation counters are integers: exact"
+        touched_ref = (mem_ref != mem0).any(dim=1)
+        touched = (mem_d.cpu() != mem0).any(dim=1)
+        assert torch.equal(touched, touched_ref), "set of written cells must be bit-exact"
+        close(mem_d, mem_ref, rtol=1e-5, atol=1e-4)

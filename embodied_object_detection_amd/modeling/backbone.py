@@ -1,0 +1,148 @@
+"""Backbone of the recurrent detector on the HIP kernels: timm ResNet-50 trunk + FPN + spatial-memory fusion + P6/P7.
+
+Mirrors `build_p67_timm_fpn_backbone_recurrent` (`Detic/detic/modeling/backbone/timm.py:507-531`):
+`MapTIMM/CustomResNetMap.forward` (`timm.py:277-299`), `CustomRecurrentFPN.forward` (`timm.py:91-213`) and
+`LastLevelP6P7_P5` (`timm.py:347-364`).  Activations are NHWC fp32 device buffers; FrozenBatchNorm is folded
+into the convs at build time; the FPN top-down add, the memory projection scale + sum fusion and all ReLUs are
+epilogues of the implicit-GEMM kernel.  Outputs p3..p7 are written back-to-back into ONE [P_total, 256] buffer so
+the shared-weight CenterNet head can treat the pyramid as one row list.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..registry import BACKBONE_REGISTRY
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+
+
+class ResNet50Trunk:
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        base = "backbone.bottom_up.base"
+
+        def bn(p):
+            return sd[f"{p}.weight"], sd[f"{p}.bias"], sd[f"{p}.running_mean"], sd[f"{p}.running_var"]
+
+        w, b = ops.fold_bn(sd[f"{base}.conv1.weight"], *bn(f"{base}.bn1"))
+        self.stem = ops.Conv(w, b, stride=2, pad=3, device=device, cin_pad=4, name="stem")
+        self.blocks: List[Tuple] = []
+        for li, nblk in enumerate(RESNET50_LAYERS, start=1):
+            for bi in range(nblk):
+                p = f"{base}.layer{li}.{bi}"
+                stride = 2 if (bi == 0 and li > 1) else 1
+                w1, b1 = ops.fold_bn(sd[f"{p}.conv1.weight"], *bn(f"{p}.bn1"))
+                w2, b2 = ops.fold_bn(sd[f"{p}.conv2.weight"], *bn(f"{p}.bn2"))
+                w3, b3 = ops.fold_bn(sd[f"{p}.conv3.weight"], *bn(f"{p}.bn3"))
+                c1 = ops.Conv(w1, b1, device=device, name=f"{p}.conv1")
+                c2 = ops.Conv(w2, b2, stride=stride, pad=1, device=device, name=f"{p}.conv2")   # stride on the 3x3 (timm)
+                c3 = ops.Conv(w3, b3, device=device, name=f"{p}.conv3")
+                ds = None
+                if f"{p}.downsample.0.weight" in sd:
+                    wd, bd = ops.fold_bn(sd[f"{p}.downsample.0.weight"], *bn(f"{p}.downsample.1"))
+                    ds = ops.Conv(wd, bd, stride=stride, device=device, name=f"{p}.downsample")
+                self.blocks.append((li, c1, c2, c3, ds))
+
+    def forward(self, x4: torch.Tensor, H: int, W: int):
+        """x4: [1,H,W,4] normalised image -> {'layer3','layer4','layer5'}: (tensor, h, w)."""
+        x = self.stem(x4, 1, H, W, relu=True)
+        h, w = self.stem.out_hw(H, W)
+        x, h, w = ops.maxpool3x3s2(x, 1, h, w, 64)
+        feats = {}
+        cur_layer = 1
+        for (li, c1, c2, c3, ds) in self.blocks:
+            if li != cur_layer:
+                feats[f"layer{cur_layer + 1}"] = (x, h, w)
+                cur_layer = li
+            sc = x
+            if ds is not None:
+                sc = ds(x, 1, h, w)
+            o = c1(x, 1, h, w, relu=True)
+            o = c2(o, 1, h, w, relu=True)
+            h2, w2 = c2.out_hw(h, w)
+            x = c3(o, 1, h2, w2, res=sc, res_mode=1, relu=True)
+            h, w = h2, w2
+        feats[f"layer{cur_layer + 1}"] = (x, h, w)
+        return feats
+
+
+class CustomRecurrentFPN:
+    size_divisibility = 32
+
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device):
+        self.device = device
+        self.memory_type = cfg.MODEL.MEMORY_TYPE
+        self.feat_fusion = cfg.MODEL.MAP_FEAT_FUSION
+        self.map_feature_weight = float(cfg.MODEL.MAP_FEATURE_WEIGHT)
+        if self.memory_type == "implicit_memory" and self.feat_fusion not in ("sum", "mem_only", "image_only"):
+            raise ValueError(f"MODEL.MAP_FEAT_FUSION={self.feat_fusion!r} not supported (timm.py:181-186)")
+        self.bottom_up = ResNet50Trunk(sd, device)
+        self.lateral, self.output = {}, {}
+        for l in (3, 4, 5):
+            self.lateral[l] = ops.Conv(sd[f"backbone.fpn_lateral{l}.weight"], sd[f"backbone.fpn_lateral{l}.bias"], device=device,
+                                       name=f"fpn_lateral{l}")
+            self.output[l] = ops.Conv(sd[f"backbone.fpn_output{l}.weight"], sd[f"backbone.fpn_output{l}.bias"], pad=1, device=device,
+                                      name=f"fpn_output{l}")
+        self.p6 = ops.Conv(sd["backbone.top_block.p6.weight"], sd["backbone.top_block.p6.bias"], stride=2, pad=1, device=device, name="p6")
+        self.p7 = ops.Conv(sd["backbone.top_block.p7.weight"], sd["backbone.top_block.p7.bias"], stride=2, pad=1, device=device, name="p7")
+        self.merge = [ops.Conv(sd[f"backbone.map_merge_projection{i}.weight"], sd[f"backbone.map_merge_projection{i}.bias"],
+                               device=device, name=f"map_merge_projection{i}") for i in (1, 2, 3)]
+        self._plans = {}
+
+    def level_shapes(self, H: int, W: int) -> List[Tuple[int, int]]:
+        hw = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+        h6, w6 = self.p6.out_hw(*hw[2])
+        h7, w7 = self.p7.out_hw(h6, w6)
+        return hw + [(h6, w6), (h7, w7)]
+
+    def _plan(self, H: int, W: int):
+        key = (H, W)
+        if key not in self._plans:
+            shapes = self.level_shapes(H, W)
+            off = [0]
+            for (h, w) in shapes:
+                off.append(off[-1] + h * w)
+            feats = torch.empty((off[-1], 256), dtype=torch.float32, device=self.device)
+            views = [feats[off[i]:off[i + 1]].view(1, shapes[i][0], shapes[i][1], 256) for i in range(5)]
+            pooled = [torch.empty((1, H // s, W // s, 512), dtype=torch.float32, device=self.device) for s in (8, 16, 32)]
+            self._plans[key] = (shapes, off, feats, views, pooled)
+        return self._plans[key]
+
+    def forward(self, x4: torch.Tensor, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor]):
+        """-> (feats [P_total,256], level views, level shapes, level offsets)."""
+        shapes, off, feats, views, pooled = self._plan(H, W)
+        c = self.bottom_up.forward(x4, H, W)
+        (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
+        assert (h3, w3) == shapes[0] and (h5, w5) == shapes[2]
+        # top-down (timm.py:118-136): lateral 1x1, + nearest x2 of the coarser level, 3x3 output
+        lat5 = self.lateral[5](c5, 1, h5, w5)
+        self.output[5](lat5, 1, h5, w5, out=views[2])
+        lat4 = self.lateral[4](c4, 1, h4, w4, res=lat5, res_mode=2)
+        self.output[4](lat4, 1, h4, w4, out=views[1])
+        lat3 = self.lateral[3](c3, 1, h3, w3, res=lat4, res_mode=2)
+        self.output[3](lat3, 1, h3, w3, out=views[0])
+        # memory read + fusion (timm.py:142-192)
+        if self.memory_type == "implicit_memory" and self.feat_fusion != "image_only":
+            if memory_f16 is None or proj is None:
+                raise ValueError("implicit_memory needs the fp16 memory table and proj_indices")
+            ops.memory_gather_pool(memory_f16, proj, H, W, outs=pooled)
+            for i in range(3):
+                h, w = shapes[i]
+                if self.feat_fusion == "sum":
+                    self.merge[i](pooled[i], 1, h, w, res=views[i], res_mode=1, out_scale=self.map_feature_weight, out=views[i])
+                else:  # mem_only
+                    self.merge[i](pooled[i], 1, h, w, out_scale=self.map_feature_weight, out=views[i])
+        # top block on the fused p5 (timm.py:200-205, 359-364)
+        self.p6(views[2], 1, h5, w5, out=views[3])
+        self.p7(views[3], 1, shapes[3][0], shapes[3][1], in_relu=True, out=views[4])
+        return feats, views, shapes, off
+
+
+@BACKBONE_REGISTRY.register()
+def build_p67_timm_fpn_backbone_recurrent(cfg, sd, device):
+    if cfg.MODEL.TIMM.BASE_NAME != "resnet50_in21k_map":
+        # the reference crashes on an undefined `new_memory` for any other base (custom_rcnn.py:560-567,580)
+        raise ValueError("MODEL.TIMM.BASE_NAME must be 'resnet50_in21k_map' for the recurrent path")
+    return CustomRecurrentFPN(cfg, sd, device)

@@ -1,0 +1,236 @@
+"""`CustomRCNNRecurrent` (eval branch) on the HIP kernels: the recurrent state machine, the memory read-prep and
+the memory write.
+
+Mirrors `Detic/detic/modeling/meta_arch/custom_rcnn.py`: `forward` eval branch (435-546), `inference` (548-582),
+`create_implicit_memory` (762-774), `preprocess_spatial_memory` (1019-1042), `update_implicit_memory` (681-760),
+`inference_with_proposals` (825-882), `box_to_image_features` (884-901), `project_image_features` (903-936) and
+`CustomRCNN._postprocess` -> detectron2 `detector_postprocess` (579-580).
+
+Call convention: `model(batched_inputs: List[List[dict]]) -> List[dict]`; the module is stateful
+between calls.  The whole frame is enqueued on the current HIP stream with no host synchronisation; the only sync
+per frame is the read-back of the final detection count when the result `Instances` are materialised.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..checkpoint import fill_missing, load_checkpoint, load_zs_weight, reset_cls_test, synthetic_state_dict
+from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
+from ..structures import Boxes, Instances
+
+
+@META_ARCH_REGISTRY.register()
+class CustomRCNNRecurrent:
+    def __init__(self, cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        dev = str(cfg.MODEL.DEVICE)
+        if not dev.startswith("cuda"):
+            raise _lib.EodError(
+                f"MODEL.DEVICE={dev!r}: the product path is HIP-only (no CPU fallback). The CPU restatement lives in "
+                "oracle/ and is test infrastructure.")
+        if not torch.cuda.is_available():
+            raise _lib.EodError("no GPU visible: the HIP product path cannot run")
+        _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(dev if ":" in dev else "cuda:0")
+        torch.cuda.set_device(self.device)
+        self.map_conditioned = cfg.MODEL.TIMM.BASE_NAME == "resnet50_in21k_map"
+        self.memory_type = cfg.MODEL.MEMORY_TYPE
+        self.save_semmap = bool(cfg.MODEL.TEST_SAVE_SEMMAP)
+        self.output_dir = cfg.OUTPUT_DIR
+        self.cls_score_thresh = float(cfg.MODEL.MEMORY_CLS_SCORE_THRESH)
+        self.obs_score_thresh = float(cfg.MODEL.MEMORY_OBS_SCORE_THRESH)
+        self.test_type = cfg.MODEL.TEST_TYPE
+        if self.test_type not in ("default", "episodic", "longterm"):
+            raise ValueError(f"MODEL.TEST_TYPE={self.test_type!r}")
+        self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        self.mask_threshold = 0.5
+        self.training = False
+        # the memory write-back and the 256-proposal mask pass run for every MEMORY_TYPE in the reference
+        # (custom_rcnn.py:515,573); keep that for like-for-like timing
+        self.always_update_memory = True
+
+        num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+        if state_dict is None:
+            if cfg.MODEL.WEIGHTS and str(cfg.MODEL.WEIGHTS).endswith((".pth", ".pkl")) and __import__("os").path.exists(cfg.MODEL.WEIGHTS):
+                sd, _ = load_checkpoint(cfg.MODEL.WEIGHTS, num_classes)
+                state_dict = fill_missing(sd, 0, num_classes)
+            else:
+                state_dict = synthetic_state_dict(0, num_classes, cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH)
+        if cfg.MODEL.RESET_CLS_TESTS and cfg.MODEL.TEST_CLASSIFIERS:
+            import os
+            p = cfg.MODEL.TEST_CLASSIFIERS[0]
+            if not os.path.exists(p):
+                p = cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH
+            state_dict = dict(state_dict)
+            reset_cls_test(state_dict, p, int(cfg.MODEL.TEST_NUM_CLASSES[0]))          # utils.py:32-50
+        self.state_dict_ref = state_dict
+        # zs_weight of the meta-arch itself (custom_rcnn.py:375-382)
+        self.zs_weight = load_zs_weight(cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH).contiguous().to(self.device)
+        self.C1 = self.zs_weight.shape[1]
+
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, state_dict, self.device)
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, state_dict, self.device)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, state_dict, self.device, self.proposal_generator.cap)
+        R = self.proposal_generator.cap
+        self.mem_scores = torch.zeros((R, self.C1), dtype=torch.float32, device=self.device)
+        self.mem_selector = ops.DetectionSelector(R, self.C1, 100, self.device)
+        # recurrent state
+        self.implicit_memory: Optional[torch.Tensor] = None   # [N,512] f32  (== semmap_features)
+        self.observations: Optional[torch.Tensor] = None      # [N] f32      (== observation_count)
+        self.semmap = None
+        self._mem_f16: Optional[torch.Tensor] = None
+        self._writer = None
+        self._writer_key = None
+        self._post = None
+        self.last_stats: Dict[str, torch.Tensor] = {}
+
+    # detectron2 nn.Module surface used by the drivers
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __call__(self, batched_inputs):
+        return self.forward(batched_inputs)
+
+    # ---- state ----------------------------------------------------------------------------------------
+    def reset_memory(self, n_cells: int):
+        """`frame['memory_reset']` branch (custom_rcnn.py:470-479)."""
+        if self.implicit_memory is None or self.implicit_memory.shape[0] != n_cells:
+            self.implicit_memory = torch.empty((n_cells, 512), dtype=torch.float32, device=self.device)
+            self.observations = torch.empty((n_cells,), dtype=torch.float32, device=self.device)
+            self._mem_f16 = torch.empty((n_cells, 512), dtype=torch.float16, device=self.device)
+        lib = _lib.load()
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.eod_fill_f32(self.implicit_memory.data_ptr(), 0.0, self.implicit_memory.numel(), s), "fill")
+        _lib.check(lib.eod_fill_f32(self.observations.data_ptr(), 0.0, self.observations.numel(), s), "fill")
+        self.semmap = None
+
+    def _ensure_frame_buffers(self, H: int, W: int, n_cells: int):
+        key = (H, W, n_cells)
+        if self._writer_key != key:
+            self._writer = ops.MemoryWriter(H, W, n_cells, 100, self.proposal_generator.cap, self.device, mask_thresh=0.5)
+            self._writer_key = key
+        if self._post is None or self._post["hw"] != (H, W):
+            D = self.roi_heads.topk
+            dev = self.device
+            self._post = dict(
+                hw=(H, W),
+                boxes=torch.zeros((D, 4), dtype=torch.float32, device=dev), scores=torch.zeros((D,), dtype=torch.float32, device=dev),
+                classes=torch.zeros((D,), dtype=torch.int32, device=dev), src=torch.zeros((D,), dtype=torch.int32, device=dev),
+                count=torch.zeros((1,), dtype=torch.int32, device=dev),
+                masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev))
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, batched_inputs: List[List[dict]]):
+        """Sequential pass over sequences and frames; the memory persists across calls (custom_rcnn.py:435-546)."""
+        if self.training:
+            raise NotImplementedError("training forward is out of scope for the hot path (SURVEY §8f rank 4)")
+        batch_output = []
+        for input_seq in batched_inputs:
+            for i, frame in enumerate(input_seq):
+                n_cells = int(input_seq[0]["memory"].shape[0])
+                if frame["memory_reset"]:
+                    self.reset_memory(n_cells)
+                if self.implicit_memory is None:
+                    raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
+                refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
+                out = self.inference_frame(frame, refresh_memory_snapshot=refresh)
+                batch_output.append(out)
+        return batch_output
+
+    def _device_image(self, frame) -> torch.Tensor:
+        img = frame["image"]
+        if not torch.is_tensor(img):
+            img = torch.as_tensor(np.asarray(img))
+        if img.dtype != torch.uint8:
+            img = img.to(torch.uint8)
+        return img.to(self.device, non_blocking=True).contiguous()
+
+    def _device_proj(self, frame) -> torch.Tensor:
+        p = frame["proj_indices"]
+        if not torch.is_tensor(p):
+            p = torch.from_numpy(np.ascontiguousarray(p))
+        if p.dim() == 3:
+            p = p.squeeze(2)
+        if p.dtype != torch.int32:
+            p = p.to(torch.int32)
+        return p.to(self.device, non_blocking=True).contiguous()
+
+    def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True):
+        """One frame: `inference` (custom_rcnn.py:548-582) + `update_implicit_memory` (681-760)."""
+        image = self._device_image(frame)
+        _, H, W = image.shape
+        if H % 32 or W % 32:
+            raise ValueError("H and W must be multiples of 32 (proj_indices is not padded: SURVEY §8 notation)")
+        proj = self._device_proj(frame)
+        if tuple(proj.shape) != (H, W):
+            raise ValueError(f"proj_indices shape {tuple(proj.shape)} != image {(H, W)}")
+        n_cells = self.implicit_memory.shape[0]
+        self._ensure_frame_buffers(H, W, n_cells)
+
+        # a4 + fp16 cast (create_implicit_memory + preprocess_spatial_memory)
+        mem_f16 = None
+        if self.memory_type == "implicit_memory":
+            if refresh_memory_snapshot:
+                ops.memory_normalize_f16(self.implicit_memory, self.observations, out=self._mem_f16)
+            mem_f16 = self._mem_f16
+
+        x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
+        feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj)
+        prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
+        det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
+            views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+        prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
+
+        # detector_postprocess (custom_rcnn.py:579-580)
+        out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
+        if (out_h, out_w) != (H, W):
+            raise NotImplementedError("output size != input size is not used on this path (train_mp3d.py:487-490)")
+        P = self._post
+        ops.detector_postprocess(det_boxes, det_scores, det_classes, det_count, self.roi_heads.topk, out_w / W, out_h / H,
+                                 float(out_w), float(out_h), P["boxes"], P["scores"], P["classes"], P["src"], P["count"])
+        ops.paste_masks(self.roi_heads.det_masks, P["boxes"], P["src"], P["count"], self.roi_heads.topk, out_h, out_w,
+                        self.mask_threshold, P["masks"])
+
+        # memory update (custom_rcnn.py:515)
+        if self.memory_type == "implicit_memory" or self.always_update_memory:
+            self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W))
+        self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
+        if not materialize:
+            return None
+        return {"instances": self._materialize((out_h, out_w))}
+
+    def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw):
+        H, W = image_hw
+        R = self.proposal_generator.cap
+        featn = self.roi_heads.featn0
+        ops.memory_scores(featn, self.zs_weight, prop_scores, self.mem_scores, prop_count, R, self.C1)
+        _, _, _, rows, cnt = self.mem_selector(prop_boxes, self.mem_scores, prop_count, float(W), float(H), self.cls_score_thresh, 0.5)
+        self._writer(featn, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations)
+
+    def _materialize(self, out_hw) -> Instances:
+        """Slice the fixed-capacity device buffers by the detection count (the frame's only host sync)."""
+        P = self._post
+        n = int(P["count"].item())
+        inst = Instances(out_hw)
+        inst.pred_boxes = Boxes(P["boxes"][:n].clone())
+        inst.scores = P["scores"][:n].clone()
+        inst.pred_classes = P["classes"][:n].to(torch.int64)
+        inst.pred_masks = P["masks"][:n].to(torch.bool)
+        return inst
+
+    # ---- introspection used by tests / bench -----------------------------------------------------------
+    def proposals_snapshot(self):
+        n = int(self.proposal_generator._plans[next(iter(self.proposal_generator._plans))][3].count.item())
+        dec = self.proposal_generator._plans[next(iter(self.proposal_generator._plans))][3]
+        return dict(proposal_boxes=dec.boxes[:n].cpu(), scores=dec.scores[:n].cpu(),
+                    feat=self.roi_heads.feat0.view(-1, 512)[:n].cpu(), featn=self.roi_heads.featn0[:n].cpu(),
+                    pred_masks=self.roi_heads.prop_masks[:n].cpu())

@@ -1,0 +1,134 @@
+"""DeticCascadeROIHeads (inference) on the HIP kernels.
+
+Mirrors `_forward_box/_run_stage/_create_proposals_from_boxes/forward/forward_mask_memory`
+(`Detic/detic/modeling/roi_heads/detic_roi_heads.py:88-349`), detectron2's `ROIPooler`(ROIAlignV2),
+`FastRCNNConvFCHead`, `MaskRCNNConvUpsampleHead`, `Box2BoxTransform`, `fast_rcnn_inference`,
+`DeticFastRCNNOutputLayers.forward/predict_probs` (`detic_fast_rcnn.py:437-466,325-339`) and `ZeroShotClassifier.forward`
+(`zero_shot_classifier.py:71-111`).  ROI lists have a fixed capacity and a device-side count; there is no host sync
+anywhere in here.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from .. import ops
+from ..registry import ROI_HEADS_REGISTRY
+
+
+@ROI_HEADS_REGISTRY.register()
+class DeticCascadeROIHeads:
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device, prop_cap: int):
+        self.device = device
+        rb = cfg.MODEL.ROI_BOX_HEAD
+        if not (rb.USE_ZEROSHOT_CLS and rb.CLS_AGNOSTIC_BBOX_REG and rb.USE_SIGMOID_CE and rb.MULT_PROPOSAL_SCORE):
+            raise NotImplementedError("hot path covers the zero-shot, class-agnostic, sigmoid, mult-proposal-score cascade")
+        if rb.NUM_FC != 2 or rb.POOLER_RESOLUTION != 7 or cfg.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION != 14:
+            raise NotImplementedError("unsupported ROI head geometry")
+        if not cfg.MODEL.ROI_MASK_HEAD.CLS_AGNOSTIC_MASK or cfg.MODEL.ROI_MASK_HEAD.NUM_CONV != 4:
+            raise NotImplementedError("unsupported mask head")
+        self.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+        self.C1 = self.num_classes + 1
+        self.norm_temp = float(rb.NORM_TEMP)
+        self.cascade_weights = [tuple(float(v) for v in w) for w in cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS]
+        self.num_stages = len(self.cascade_weights)
+        self.score_thresh = float(cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST)
+        self.nms_thresh = float(cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST)
+        self.topk = int(cfg.TEST.DETECTIONS_PER_IMAGE)
+        self.add_feature_to_prop = bool(rb.ADD_FEATURE_TO_PROP)
+        self.R = prop_cap                       # proposal capacity
+        self.Dcap = (self.topk + 31) // 32 * 32  # detection capacity for the mask head
+        self.stages = []
+        for k in range(self.num_stages):
+            fc1_w = sd[f"roi_heads.box_head.{k}.fc1.weight"]
+            # flatten order: reference (C,7,7) -> ours (7,7,C)
+            fc1_w = fc1_w.view(-1, 256, 7, 7).permute(0, 2, 3, 1).reshape(fc1_w.shape[0], -1, 1, 1).contiguous()
+            p = f"roi_heads.box_predictor.{k}"
+            st = dict(
+                fc1=ops.Conv(fc1_w, sd[f"roi_heads.box_head.{k}.fc1.bias"], device=device, name=f"box_head.{k}.fc1"),
+                fc2=ops.Conv(sd[f"roi_heads.box_head.{k}.fc2.weight"][:, :, None, None], sd[f"roi_heads.box_head.{k}.fc2.bias"],
+                             device=device, name=f"box_head.{k}.fc2"),
+                cls=ops.Conv(sd[f"{p}.cls_score.linear.weight"][:, :, None, None], sd[f"{p}.cls_score.linear.bias"], device=device,
+                             name=f"box_predictor.{k}.cls_score.linear"),
+                bb0=ops.Conv(sd[f"{p}.bbox_pred.0.weight"][:, :, None, None], sd[f"{p}.bbox_pred.0.bias"], device=device,
+                             name=f"box_predictor.{k}.bbox_pred.0"),
+                bb2=ops.Conv(sd[f"{p}.bbox_pred.2.weight"][:, :, None, None], sd[f"{p}.bbox_pred.2.bias"], device=device,
+                             name=f"box_predictor.{k}.bbox_pred.2"),
+                zs=sd[f"{p}.cls_score.zs_weight"].contiguous().to(device),
+            )
+            assert st["zs"].shape[1] == self.C1, (st["zs"].shape, self.C1)
+            self.stages.append(st)
+        m = "roi_heads.mask_head"
+        self.mask_convs = [ops.Conv(sd[f"{m}.mask_fcn{i}.weight"], sd[f"{m}.mask_fcn{i}.bias"], pad=1, device=device, name=f"mask_fcn{i}")
+                           for i in range(1, 5)]
+        self.deconv = ops.Conv(sd[f"{m}.deconv.weight"], sd[f"{m}.deconv.bias"], device=device, deconv=True, name="mask_deconv")
+        self.pred_w = sd[f"{m}.predictor.weight"].reshape(-1).contiguous().to(device)
+        self.pred_b = float(sd[f"{m}.predictor.bias"].item())
+        # persistent buffers
+        R, D = self.R, self.Dcap
+        f32 = dict(dtype=torch.float32, device=device)
+        self.pool7 = torch.empty((R, 7, 7, 256), **f32)
+        self.h1 = torch.empty((R, 1, 1, 1024), **f32)
+        self.h2 = torch.empty((R, 1, 1, 1024), **f32)
+        self.hb = torch.empty((R, 1, 1, 1024), **f32)
+        self.feat = torch.empty((R, 1, 1, 512), **f32)
+        self.feat0 = torch.empty((R, 1, 1, 512), **f32)        # stage-0 CLIP-space feature = proposals.feat
+        self.featn0 = torch.zeros((R, 512), **f32)            # 50 * normalize(feat0): what the memory stores
+        self.deltas = torch.empty((R, 1, 1, 4), **f32)
+        self.prob = torch.zeros((R, self.C1), **f32)
+        self.boxes = [torch.zeros((R, 4), **f32) for _ in range(self.num_stages + 1)]
+        M = max(R, D)
+        self.mpool = torch.empty((M, 14, 14, 256), **f32)
+        self.mbuf = torch.empty((M, 14, 14, 256), **f32)
+        self.mup = torch.empty((M, 28, 28, 256), **f32)
+        self.det_masks = torch.zeros((D, 28, 28), **f32)
+        self.prop_masks = torch.zeros((R, 28, 28), **f32)
+        self.selector = ops.DetectionSelector(R, self.C1, self.topk, device)
+
+    # ---- cascade box heads ------------------------------------------------------------------------
+    def forward_box(self, views: List[torch.Tensor], shapes, prop_boxes: torch.Tensor, prop_scores: torch.Tensor, count: torch.Tensor,
+                    image_hw: Tuple[int, int]):
+        h3, w3 = shapes[0]
+        H, W = image_hw
+        R = self.R
+        boxes = prop_boxes
+        for k, st in enumerate(self.stages):
+            ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, R, 7, out=self.pool7)
+            st["fc1"](self.pool7, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h1)
+            st["fc2"](self.h1, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h2)
+            feat = self.feat0 if k == 0 else self.feat
+            st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
+            ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp)
+            st["bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.hb)
+            st["bb2"](self.hb, R, 1, 1, m_count=count, m_unit=1, out=self.deltas)
+            last = k == self.num_stages - 1
+            # next-stage proposals are clipped to the image (detic_roi_heads.py:314); the final boxes are clipped by
+            # fast_rcnn_inference itself
+            ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
+            boxes = self.boxes[k + 1]
+        ops.cascade_scores(self.prob, prop_scores, count, R, self.C1, 1.0 / self.num_stages)
+        return self.selector(boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
+
+    # ---- mask head ----------------------------------------------------------------------------------
+    def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor):
+        h3, w3 = shapes[0]
+        ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=self.mpool)
+        src, dst = self.mpool, self.mbuf
+        for conv in self.mask_convs:
+            conv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=dst)
+            src, dst = dst, src
+        self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=self.mup)
+        ops.mask_predictor_sigmoid(self.mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out)
+        return out
+
+    def forward(self, views, shapes, prop_boxes, prop_scores, prop_count, image_hw):
+        """-> detections (boxes, scores, classes, rows, count) + det masks; proposals get feat/featn and masks."""
+        det = self.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, image_hw)
+        det_boxes, det_scores, det_classes, det_rows, det_count = det
+        self.forward_mask(views, shapes, det_boxes, det_count, self.topk, self.det_masks)      # forward_with_given_boxes
+        return det
+
+    def forward_mask_memory(self, views, shapes, prop_boxes, prop_count):
+        """`forward_mask_memory` + `mask_rcnn_inference` on ALL proposals (custom_rcnn.py:573-574)."""
+        return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks)

@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the per-frame recurrent inference path on synthetic 640x640 sequences,
+MODEL.MEMORY_TYPE implicit_memory, MAP_FEAT_FUSION sum (BASELINE.json metric / configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one frame through the whole hot path (memory read -> backbone -> proposals -> cascade -> masks x2 ->
+post-process -> memory write), inputs (u8 image, int32 proj_indices) already resident in HBM.  One process per GPU,
+independent scenes per rank (weak scaling, no data-path collective); after the timed region the ranks exchange their
+per-rank detection records with ONE RCCL all-reduce (fixed-shape buffer, each rank fills its slice) for the aggregate
+AP50, as the north star asks.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=2, default=[640, 640], metavar=("H", "W"))
+    ap.add_argument("--grid", type=int, nargs=2, default=[200, 200], metavar=("MAP_W", "MAP_H"))
+    ap.add_argument("--cell", type=float, default=0.2)
+    ap.add_argument("--memory-thresh", type=float, default=0.3, help="MODEL.MEMORY_CLS_SCORE_THRESH (0.0 = worst-case write path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
+    return ap.parse_args()
+
+
+def available_cores() -> int:
+    """Cores this process may really use: affinity mask and cgroup quota, not the host's total."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, q // int(fh2.read().split()[0])))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 32))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd, frames, args, budget_s):
+    """The CPU oracle (a port: the reference's own CPU mode cannot run) timed on the host cores."""
+    from oracle import memory as OM
+    from oracle import model as M
+    torch.set_num_threads(available_cores())
+    log(f'cpu baseline on {torch.get_num_threads()} threads')
+    ocfg = M.OracleCfg(memory_cls_score_thresh=args.memory_thresh, map_feature_weight=5.0)
+    oracle = OM.RecurrentOracle(sd, ocfg)
+    t0 = time.perf_counter()
+    n = 0
+    times = []
+    for i, f in enumerate(frames):
+        t = time.perf_counter()
+        oracle.step(f, i, frames)
+        times.append(time.perf_counter() - t)
+        log(f'cpu baseline frame {i}: {times[-1]:.1f} s')
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    tot = sum(times)
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(n / tot, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} consecutive frame(s) of the same synthetic sequence (incl. the first, memory empty), "
+                      f"oracle/ torch fp32, {tot:.1f} s", "cpu_model": model_name}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        print(f"[bench] warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from embodied_object_detection_amd import build_model, ops, setup_cfg
+    from embodied_object_detection_amd.checkpoint import synthetic_state_dict
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.evaluation.coco_ap import DetectionRecords, evaluate_records
+
+    H, W = args.size
+    map_w, map_h = args.grid
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "MODEL.MEMORY_CLS_SCORE_THRESH", args.memory_thresh, "MODEL.DEVICE", f"cuda:{local_rank}"])
+    sd = synthetic_state_dict(0)
+    model = build_model(cfg, sd)
+    log('model built')
+
+    n_frames = args.steps + args.warmup
+    seq = SyntheticSequence(rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell,
+                            projector=None)
+    host_frames = [seq.frame(i) for i in range(n_frames)]
+    # inputs resident in HBM before the timed region
+    frames = []
+    for f in host_frames:
+        g = dict(f)
+        g["image"] = f["image"].to(dev)
+        g["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
+        frames.append(g)
+    torch.cuda.synchronize()
+    log(f'{n_frames} frames resident on device')
+
+    # dominant-kernel instrumentation: events around every mask-head 3x3 conv launch (fp32 MFMA implicit GEMM)
+    ev = []
+    if not args.no_kernel_events:
+        for conv in model.roi_heads.mask_convs:
+            conv.event_log = ev
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    counts = []
+
+    def step(i, record):
+        if frames[i]["memory_reset"]:
+            model.reset_memory(seq.n_cells)      # custom_rcnn.py:470-479
+        out = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=False)
+        if record:
+            counts.append((model.last_stats["prop_count"].clone(), model.last_stats["det_count"].clone(),
+                           model.last_stats["mem_k"].clone()))
+        return out
+
+    for i in range(args.warmup):
+        step(i, False)
+        torch.cuda.synchronize()
+        log(f'warmup frame {i} done')
+    ev.clear()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_frames):
+        step(i, True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f'timed region: {elapsed:.3f} s for {args.steps} frames')
+    for conv in model.roi_heads.mask_convs:
+        conv.event_log = None
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
+    rec = DetectionRecords(world, max_dets=4 * 100, max_gt=4 * 8, device=dev)
+    for j, i in enumerate(range(args.warmup, n_frames)):
+        if j % max(1, args.steps // 4) == 0 and j // max(1, args.steps // 4) < 4:
+            inst = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=True)["instances"]
+            rec.add_image(rank, host_frames[i]["image_id"], inst, host_frames[i]["instances"])
+    t_ar = time.perf_counter()
+    if distributed:
+        dist.all_reduce(rec.buffer, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    t_ar = time.perf_counter() - t_ar
+    ap = evaluate_records(rec.buffer.cpu().numpy(), num_classes=20) if rank == 0 else None
+
+    # ---- dominant kernel roofline ----------------------------------------------------------------------------------
+    roofline = None
+    if ev:
+        # (start, end, m_count) recorded by ops.Conv around every mask_fcn launch of the timed region
+        durs = [s.elapsed_time(e) for (s, e, _c) in ev]
+        rows = [int(c.item()) if c is not None else 0 for (_s, _e, c) in ev]
+        flops = [2.0 * r * 196 * 256 * 2304 for r in rows]
+        tot_ms = sum(durs)
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<128,128> (mask_fcn 3x3, M=rois*196, N=256, K=2304)",
+                    "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": len(durs), "avg_launch_ms": round(tot_ms / len(durs), 4),
+                    "algorithmic_flop_per_launch": round(sum(flops) / len(flops), 1)}
+
+    result = None
+    if rank == 0:
+        pc = [int(c[0].item()) for c in counts]
+        dc = [int(c[1].item()) for c in counts]
+        mk = [int(c[2].item()) for c in counts]
+        total_frames = args.steps * world
+        result = {
+            "metric": "frames/sec (640x640, implicit_memory); frames/sec/GPU = value / n_gpus",
+            "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"recurrent per-frame inference, MEMORY_TYPE implicit_memory, MAP_FEAT_FUSION sum, "
+                                   f"{H}x{W} synthetic sequence, memory grid {map_w}x{map_h} @ {args.cell} m, one scene per GPU "
+                                   f"(BASELINE.json configs[2]/[3])",
+                       "image": f"{H}x{W}", "memory_cells": map_w * map_h, "weights": "random-init (synthetic_state_dict seed 0)",
+                       "memory_cls_score_thresh": args.memory_thresh,
+                       "proposals_per_frame_mean": round(float(np.mean(pc)), 1), "detections_per_frame_mean": round(float(np.mean(dc)), 1),
+                       "memory_instances_per_frame_mean": round(float(np.mean(mk)), 1)},
+            "roofline": roofline,
+            "eval_allreduce_ms": round(t_ar * 1e3, 3),
+            "ap50_synthetic": None if ap is None else round(ap["AP50"], 3),
+        }
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, host_frames[:8], args, args.cpu_budget_s)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

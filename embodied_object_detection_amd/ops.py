@@ -97,6 +97,7 @@ class Conv:
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
         self.desc = EodConvDesc()
         self._lib = _lib.load()
+        self.event_log = None   # bench.py: list that receives (start_event, end_event, m_count) per launch
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -123,6 +124,13 @@ class Conv:
         if need:
             ws = _conv_ws.get(need, x.device)
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if self.event_log is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(self._lib.eod_conv2d(C.byref(d), _stream()), f"eod_conv2d[{self.name}]")
+            e1.record()
+            self.event_log.append((e0, e1, None if m_count is None else m_count.clone()))
+            return out
         check(self._lib.eod_conv2d(C.byref(d), _stream()), f"eod_conv2d[{self.name}]")
         return out
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "eod_preprocess_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     "eod_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "eod_groupnorm_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "eod_groupnorm_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                      C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

@@ -267,17 +267,11 @@ struct Plan {
 Plan make_plan(const EodConvDesc* d, int M, int nchunks) {
   static const int cfg[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   Plan pl{};
+  // Measured on MI355X (tools/conv_bench.py, profiles/r01_conv_bench.log): the 64x64 tile (7 waves/SIMD, finest
+  // tile quantisation over 256 CUs) is the fastest or ties on every shape of this path, including the
+  // 50k x 256 x 2304 mask-head GEMM (107 vs 92 TFLOP/s for 128x128).  The larger tiles stay selectable.
   int pick = 2;
-  if (d->force_tile >= 1 && d->force_tile <= 3) {
-    pick = d->force_tile - 1;
-  } else {
-    for (int c = 0; c < 3; ++c) {
-      const int bm = cfg[c][0], bn = cfg[c][1];
-      if (bn == 128 && d->Cout <= 64) continue;
-      const long tiles = (long)((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);
-      if (tiles >= 448) { pick = c; break; }
-    }
-  }
+  if (d->force_tile >= 1 && d->force_tile <= 3) pick = d->force_tile - 1;
   pl.tile = pick + 1;
   pl.bm = cfg[pick][0];
   pl.bn = cfg[pick][1];

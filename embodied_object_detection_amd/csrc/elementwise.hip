@@ -59,42 +59,64 @@ struct LevelOff {
   int levels;
 };
 
-// one block per (level, group): two-pass mean / variance over rows x (C/groups) channels
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, LevelOff lo, int C, int groups, float eps,
-                                                        float* __restrict__ stats) {
-  const int level = blockIdx.x / groups;
-  const int g = blockIdx.x - level * groups;
+// GroupNorm statistics in two launches.  (1) one block per 32-row chunk of one level: thread = channel (coalesced
+// 1 KiB rows), double accumulation of sum / sum of squares, 8-lane shuffle reduce to the group -> partial[chunk][group].
+// (2) one thread per (level, group) adds its level's chunk partials in chunk order (deterministic) and emits mean, rstd.
+#define GN_ROWS 32
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, LevelOff lo, int C, int groups,
+                                                          double* __restrict__ partial) {
+  // chunk -> level
+  int level = 0, first_chunk = 0;
+  for (;;) {
+    const int rows = lo.off[level + 1] - lo.off[level];
+    const int nch = (rows + GN_ROWS - 1) / GN_ROWS;
+    if ((int)blockIdx.x < first_chunk + nch || level + 1 >= lo.levels) break;
+    first_chunk += nch;
+    ++level;
+  }
+  const int r0 = lo.off[level] + ((int)blockIdx.x - first_chunk) * GN_ROWS;
+  const int r1 = min(r0 + GN_ROWS, lo.off[level + 1]);
   const int cpg = C / groups;
-  const int r0 = lo.off[level], r1 = lo.off[level + 1];
-  const int n = (r1 - r0) * cpg;
-  __shared__ float red[4];
-  __shared__ float bc;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int r = i / cpg, c = i - r * cpg;
-    s += x[(size_t)(r0 + r) * C + g * cpg + c];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const double v = (double)x[(size_t)r * C + c];
+      s += v;
+      q += v * v;
+    }
+    // reduce over the cpg (power of two, <= 64) consecutive channels of the group
+    for (int off = 1; off < cpg; off <<= 1) {
+      s += __shfl_xor(s, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    if ((c % cpg) == 0) {
+      const int g = c / cpg;
+      partial[((size_t)blockIdx.x * groups + g) * 2 + 0] = s;
+      partial[((size_t)blockIdx.x * groups + g) * 2 + 1] = q;
+    }
   }
-  s = wave_reduce_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) bc = (red[0] + red[1] + red[2] + red[3]) / (float)n;
-  __syncthreads();
-  const float mean = bc;
-  float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int r = i / cpg, c = i - r * cpg;
-    const float d = x[(size_t)(r0 + r) * C + g * cpg + c] - mean;
-    v += d * d;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, LevelOff lo, int C, int groups, float eps,
+                                                           float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lo.levels * groups) return;
+  const int level = i / groups, g = i - level * groups;
+  int first_chunk = 0;
+  for (int l = 0; l < level; ++l) first_chunk += (lo.off[l + 1] - lo.off[l] + GN_ROWS - 1) / GN_ROWS;
+  const int rows = lo.off[level + 1] - lo.off[level];
+  const int nch = (rows + GN_ROWS - 1) / GN_ROWS;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nch; ++c) {
+    s += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
+    q += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
   }
-  v = wave_reduce_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)n;
-    stats[(level * groups + g) * 2 + 0] = mean;
-    stats[(level * groups + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
-  }
+  const double n = (double)rows * (C / groups);
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2 + 0] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -183,6 +205,13 @@ extern "C" int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, i
   return eod_launch_status();
 }
 
+extern "C" size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, int levels, int groups) {
+  if (!level_off_host || levels < 1 || levels > 8) return 0;
+  size_t chunks = 0;
+  for (int i = 0; i < levels; ++i) chunks += (size_t)(level_off_host[i + 1] - level_off_host[i] + GN_ROWS - 1) / GN_ROWS;
+  return ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8 + chunks * groups * 2 * sizeof(double);
+}
+
 extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
                                   int levels, int C, int groups, float eps, float* stats, eod_stream_t stream) {
   if (!x || !y || !gamma || !beta || !level_off_host || !stats) return EOD_ERR_NULL;
@@ -192,7 +221,15 @@ extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, 
   for (int i = 0; i <= levels; ++i) lo.off[i] = level_off_host[i];
   for (int i = 0; i < levels; ++i)
     if (lo.off[i + 1] <= lo.off[i]) return EOD_ERR_BAD_DIMS;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(levels * groups), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, eps, stats);
+  int chunks = 0;
+  for (int i = 0; i < levels; ++i) chunks += (lo.off[i + 1] - lo.off[i] + GN_ROWS - 1) / GN_ROWS;
+  // stats layout: [2*levels*groups floats | pad to 8 B | chunks*groups*2 doubles]
+  double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8);
+  const int cpg = C / groups;
+  if (cpg > 64 || (cpg & (cpg - 1)) != 0 || 256 % cpg != 0) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((levels * groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, lo, C, groups,
+                     eps, stats);
   hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)lo.off[levels] * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
                      gamma, beta, lo, C, groups, stats);
   return eod_launch_status();

@@ -160,28 +160,46 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
   __syncthreads();
   const float x0 = boxes[k * 4 + 0], y0 = boxes[k * 4 + 1], x1 = boxes[k * 4 + 2], y1 = boxes[k * 4 + 3];
   const int total = H * W;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
-    const int y = p / W, x = p - y * W;
-    const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
-    const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
-    const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-    const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
-    float v = 0.f;
-    if (ix > -1.0f && ix < 28.0f && iy > -1.0f && iy < 28.0f) {  // also false for NaN
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int xw = (int)fx, yn = (int)fy;
-      const int xe = xw + 1, ys = yn + 1;
-      const float nw = ((float)xe - ix) * ((float)ys - iy);
-      const float ne = (ix - (float)xw) * ((float)ys - iy);
-      const float sw = ((float)xe - ix) * (iy - (float)yn);
-      const float se = (ix - (float)xw) * (iy - (float)yn);
-      const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u, ynv = (unsigned)yn < 28u, ysv = (unsigned)ys < 28u;
-      if (xwv && ynv) v += m[yn * 28 + xw] * nw;
-      if (xev && ynv) v += m[yn * 28 + xe] * ne;
-      if (xwv && ysv) v += m[ys * 28 + xw] * sw;
-      if (xev && ysv) v += m[ys * 28 + xe] * se;
+  // each thread produces 16 consecutive pixels of one row and writes them with ONE 16-byte store (W % 16 == 0)
+  const int groups = total >> 4;
+  // a sample further than one mask pixel outside the box is exactly 0: whole 16-pixel runs out there skip the sampling
+  const float mx = fabsf(x1 - x0) * (1.0f / 14.0f), my = fabsf(y1 - y0) * (1.0f / 14.0f);
+  const bool degenerate = !(x1 > x0) || !(y1 > y0);
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
+    const int p0 = g << 4;
+    const int y = p0 / W, xb = p0 - y * W;
+    unsigned wv[4] = {0u, 0u, 0u, 0u};
+    const float fy0 = (float)y + 0.5f;
+    const bool row_out = !degenerate && (fy0 < y0 - my || fy0 > y1 + my || (float)xb + 16.0f < x0 - mx || (float)xb > x1 + mx);
+    if (!row_out) {
+      const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+      const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int x = xb + j;
+        const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+        const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+        float v = 0.f;
+        if (ix > -1.0f && ix < 28.0f && iy > -1.0f && iy < 28.0f) {  // also false for NaN
+          const float fx = floorf(ix), fy = floorf(iy);
+          const int xw = (int)fx, yn = (int)fy;
+          const int xe = xw + 1, ys = yn + 1;
+          const float nw = ((float)xe - ix) * ((float)ys - iy);
+          const float ne = (ix - (float)xw) * ((float)ys - iy);
+          const float sw = ((float)xe - ix) * (iy - (float)yn);
+          const float se = (ix - (float)xw) * (iy - (float)yn);
+          const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u, ynv = (unsigned)yn < 28u, ysv = (unsigned)ys < 28u;
+          if (xwv && ynv) v += m[yn * 28 + xw] * nw;
+          if (xev && ynv) v += m[yn * 28 + xe] * ne;
+          if (xwv && ysv) v += m[ys * 28 + xw] * sw;
+          if (xev && ysv) v += m[ys * 28 + xe] * se;
+        }
+        if (v >= thr) wv[j >> 2] |= 1u << ((j & 3) * 8);
+      }
     }
-    out[(size_t)k * total + p] = (v >= thr) ? 1 : 0;
+    uint4 pk;
+    pk.x = wv[0]; pk.y = wv[1]; pk.z = wv[2]; pk.w = wv[3];
+    *reinterpret_cast<uint4*>(out + (size_t)k * total + p0) = pk;
   }
 }
 
@@ -236,8 +254,9 @@ extern "C" int eod_detector_postprocess(const float* boxes, const float* scores,
 extern "C" int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap, int H, int W,
                                float threshold, uint8_t* out, eod_stream_t stream) {
   if (!prob || !boxes || !out) return EOD_ERR_NULL;
-  if (K_cap <= 0 || H <= 0 || W <= 0) return EOD_ERR_BAD_DIMS;
-  int tiles = (H * W + 256 * 8 - 1) / (256 * 8);
+  if (K_cap <= 0 || H <= 0 || W <= 0 || (W & 15)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(out)) return EOD_ERR_ALIGN;
+  int tiles = (H * W / 16 + 256 * 2 - 1) / (256 * 2);
   hipLaunchKernelGGL(paste_masks_kernel, dim3(tiles, K_cap), dim3(256), 0, (hipStream_t)stream, prob, boxes, rows, count, K_cap, H, W,
                      threshold, out);
   return eod_launch_status();

@@ -205,6 +205,8 @@ struct MwWs {
   int* n_slots;     // [1]
   long long* acc;   // [U_max, D] fixed point 2^-32
   int* slot_cnt;    // [U_max]
+  int* blk_pix;     // [ceil(P/4096)]
+  int* blk_cell;    // [ceil(N/4096)]
   size_t bytes;
 };
 
@@ -234,6 +236,8 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap) {
   w.n_slots = (int*)take(4);
   w.acc = (long long*)take(umax * (size_t)D * 8);
   w.slot_cnt = (int*)take(umax * 4);
+  w.blk_pix = (int*)take(((P + 4095) / 4096 + 1) * 4);
+  w.blk_cell = (int*)take((((size_t)n_cells + 4095) / 4096 + 1) * 4);
   w.bytes = off;
   return w;
 }
@@ -310,74 +314,133 @@ __global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restric
   }
 }
 
-// single block: rank observed pixels in row-major order, keep every 8th (custom_rcnn.py:913-914)
+// Stream compaction in two launches: per-block counts, then per-block local scan + prefix of the block counts.
+// Block = 1024 threads x 4 consecutive elements.  Used for (a) observed pixels -> every 8th in row-major order
+// (custom_rcnn.py:913-914) and (b) marked cells -> slot ids in ascending cell order.
+#define SCAN_ELEMS 4096
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
+  __shared__ int wsum[16];
+  __shared__ int wtot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int t = wsum[i];
+      wsum[i] = run;
+      run += t;
+    }
+    wtot = run;
+  }
+  __syncthreads();
+  *total = wtot;
+  return wsum[wave] + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void mw_count_pixels_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
+                                                                int* __restrict__ block_cnt) {
+  if (*k_u == 0) return;
+  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < P) c += cover[base + j] > 0;
+  int total;
+  block_exclusive_scan_1024(c, &total);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
 __global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
-                                                          const int* __restrict__ proj, int* __restrict__ sel_pix, int* __restrict__ n_sel,
-                                                          int* __restrict__ cell_mark) {
+                                                          const int* __restrict__ proj, const int* __restrict__ block_cnt,
+                                                          int* __restrict__ sel_pix, int* __restrict__ n_sel, int* __restrict__ cell_mark) {
   if (*k_u == 0) {
-    if (threadIdx.x == 0) *n_sel = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_sel = 0;
     return;
   }
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int chunk = (P + 1023) / 1024;
-  const int b = t * chunk, e = min(P, b + chunk);
-  int c = 0;
-  for (int p = b; p < e; ++p) c += cover[p] > 0;
-  part[t] = c;
-  __syncthreads();
-  // inclusive scan (Hillis-Steele)
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = 0;
-    if (t >= off) v = part[t - off];
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  __shared__ int sh_off;
+  if (threadIdx.x < 64) {
+    int s = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) s += block_cnt[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) sh_off = s;
   }
-  int rank = part[t] - c;
-  for (int p = b; p < e; ++p) {
-    if (cover[p] > 0) {
+  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  int c = 0;
+  bool ob[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ob[j] = (base + j < P) && cover[base + j] > 0;
+    c += ob[j];
+  }
+  int total;
+  int rank = block_exclusive_scan_1024(c, &total) + sh_off;   // the scan's barriers also publish sh_off
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ob[j]) {
       if ((rank & 7) == 0) {
-        sel_pix[rank >> 3] = p;
-        cell_mark[proj[p]] = 1;
+        sel_pix[rank >> 3] = base + j;
+        cell_mark[proj[base + j]] = 1;
       }
       ++rank;
     }
   }
-  if (t == 1023) *n_sel = (part[1023] + 7) >> 3;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_sel = (sh_off + total + 7) >> 3;
 }
 
-// single block: slot ids for marked cells in ascending cell order
+__global__ __launch_bounds__(1024) void mw_count_cells_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
+                                                               int* __restrict__ block_cnt) {
+  if (*k_u == 0) return;
+  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < N) c += cell_mark[base + j] != 0;
+  int total;
+  block_exclusive_scan_1024(c, &total);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
 __global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
-                                                         int* __restrict__ cell_slot, int* __restrict__ slot_cell, int* __restrict__ n_slots) {
+                                                         const int* __restrict__ block_cnt, int* __restrict__ cell_slot,
+                                                         int* __restrict__ slot_cell, int* __restrict__ n_slots) {
   if (*k_u == 0) {
-    if (threadIdx.x == 0) *n_slots = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_slots = 0;
     return;
   }
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int chunk = (N + 1023) / 1024;
-  const int b = t * chunk, e = min(N, b + chunk);
-  int c = 0;
-  for (int i = b; i < e; ++i) c += cell_mark[i] != 0;
-  part[t] = c;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = 0;
-    if (t >= off) v = part[t - off];
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  __shared__ int sh_off;
+  if (threadIdx.x < 64) {
+    int s = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) s += block_cnt[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) sh_off = s;
   }
-  int rank = part[t] - c;
-  for (int i = b; i < e; ++i) {
-    if (cell_mark[i] != 0) {
-      cell_slot[i] = rank;
-      slot_cell[rank] = i;
+  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  int c = 0;
+  bool mk[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mk[j] = (base + j < N) && cell_mark[base + j] != 0;
+    c += mk[j];
+  }
+  int total;
+  int rank = block_exclusive_scan_1024(c, &total) + sh_off;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (mk[j]) {
+      cell_slot[base + j] = rank;
+      slot_cell[rank] = base + j;
       ++rank;
     }
   }
-  if (t == 1023) *n_slots = part[1023];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_slots = sh_off + total;
 }
 
 __global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ acc, int* __restrict__ slot_cnt,
@@ -404,6 +467,7 @@ __global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restr
     const int p = sel_pix[s];
     const int y = p / W, x = p - y * W;
     const float cnt = (float)cover[p];
+    // lane owns channels q*64 + lane: every wave-instruction (load and atomic) covers 64 consecutive elements
     float a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = 0.f;
@@ -421,20 +485,18 @@ __global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restr
         const int src = __ffsll((long long)bal) - 1;
         bal &= bal - 1;
         const int rr = __shfl(r, src, 64);
-        const float* f = featn + (size_t)rr * D + lane * 8;
-        const f32x4 f0 = *reinterpret_cast<const f32x4*>(f);
-        const f32x4 f1 = *reinterpret_cast<const f32x4*>(f + 4);
-        a[0] += f0.x; a[1] += f0.y; a[2] += f0.z; a[3] += f0.w;
-        a[4] += f1.x; a[5] += f1.y; a[6] += f1.z; a[7] += f1.w;
+        const float* f = featn + (size_t)rr * D + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += f[q * 64];
       }
     }
     const int slot = cell_slot[proj[p]];
-    long long* dst = acc + (size_t)slot * D + lane * 8;
+    long long* dst = acc + (size_t)slot * D + lane;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float v = a[q] / cnt;
       const long long fx = (long long)llrintf(v * 4294967296.0f);
-      atomicAdd(reinterpret_cast<unsigned long long*>(dst + q), (unsigned long long)fx);
+      atomicAdd(reinterpret_cast<unsigned long long*>(dst + q * 64), (unsigned long long)fx);
     }
     if (lane == 0) atomicAdd(slot_cnt + slot, 1);
   }
@@ -545,8 +607,13 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
                      d->k_out);
   hipLaunchKernelGGL(mw_coverage_kernel, dim3(blocks_for((size_t)P)), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
                      d->proj, d->H, d->W, d->mask_thresh, w.cover, w.cell_flag);
-  hipLaunchKernelGGL(mw_select_kernel, dim3(1), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, w.sel_pix, w.n_sel, w.cell_mark);
-  hipLaunchKernelGGL(mw_slots_kernel, dim3(1), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.cell_slot, w.slot_cell, w.n_slots);
+  const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS, cb = (d->n_cells + SCAN_ELEMS - 1) / SCAN_ELEMS;
+  hipLaunchKernelGGL(mw_count_pixels_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, w.blk_pix);
+  hipLaunchKernelGGL(mw_select_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, w.blk_pix, w.sel_pix, w.n_sel,
+                     w.cell_mark);
+  hipLaunchKernelGGL(mw_count_cells_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell);
+  hipLaunchKernelGGL(mw_slots_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell, w.cell_slot, w.slot_cell,
+                     w.n_slots);
   hipLaunchKernelGGL(mw_zero_slots_kernel, dim3(1024), dim3(256), 0, s, w.acc, w.slot_cnt, w.n_slots, d->D);
   hipLaunchKernelGGL(mw_accumulate_kernel, dim3(2048), dim3(256), 0, s, d->featn, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
                      w.sel_pix, w.n_sel, w.cover, d->proj, w.cell_slot, d->W, d->D, d->mask_thresh, w.acc, w.slot_cnt);

@@ -45,7 +45,6 @@ class CenterNet:
         b = torch.cat([sd[f"{h}.agn_hm.bias"], sd[f"{h}.bbox_pred.bias"]], dim=0)
         self.out_conv = ops.Conv(w, b, pad=1, device=device, name="agn_hm+bbox_pred")
         self.scales = [float(sd[f"{h}.scales.{l}.scale"].item()) for l in range(5)]
-        self.gn_stats = torch.empty((2 * 5 * 32,), dtype=torch.float32, device=device)
         self._plans = {}
 
     def _plan(self, shapes: List[Tuple[int, int]], off: List[int]):
@@ -57,7 +56,7 @@ class CenterNet:
             head = torch.empty((P, 5), dtype=torch.float32, device=self.device)
             dec = ops.ProposalDecoder(shapes, self.strides, self.scales, self.score_thresh, self.pre_nms_topk, self.post_nms_topk,
                                       self.nms_thresh, self.cap, self.device, head_stride=5)
-            self._plans[key] = (a, b, head, dec)
+            self._plans[key] = (a, b, head, dec, ops.groupnorm_workspace(off, self.device))
         return self._plans[key]
 
     def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int):
@@ -66,11 +65,11 @@ class CenterNet:
 
     def forward(self, feats: torch.Tensor, shapes, off):
         """feats [P_total,256] -> (boxes [cap,4], scores [cap], count [1]) device buffers, sorted by score."""
-        a, b, head, dec = self._plan(shapes, off)
+        a, b, head, dec, gn_ws = self._plan(shapes, off)
         src = feats
         for (conv, gamma, beta) in self.tower:
             self._per_level(conv, src, a, shapes, off, 256)
-            ops.groupnorm_relu(a, gamma, beta, off, 256, self.gn_stats, out=b)   # stream order: `a` is free again
+            ops.groupnorm_relu(a, gamma, beta, off, 256, gn_ws, out=b)   # stream order: `a` is free again
             src = b
         self._per_level(self.out_conv, src, head, shapes, off, 5)
         return dec(head)

@@ -229,8 +229,8 @@ class CustomRCNNRecurrent:
 
     # ---- introspection used by tests / bench -----------------------------------------------------------
     def proposals_snapshot(self):
-        n = int(self.proposal_generator._plans[next(iter(self.proposal_generator._plans))][3].count.item())
         dec = self.proposal_generator._plans[next(iter(self.proposal_generator._plans))][3]
+        n = int(dec.count.item())
         return dict(proposal_boxes=dec.boxes[:n].cpu(), scores=dec.scores[:n].cpu(),
                     feat=self.roi_heads.feat0.view(-1, 512)[:n].cpu(), featn=self.roi_heads.featn0[:n].cpu(),
                     pred_masks=self.roi_heads.prop_masks[:n].cpu())

@@ -158,6 +158,12 @@ def maxpool3x3s2(x: torch.Tensor, N: int, H: int, W: int, Cc: int) -> Tuple[torc
     return y, OH, OW
 
 
+def groupnorm_workspace(level_off: Sequence[int], device, groups: int = 32) -> torch.Tensor:
+    lo = (C.c_int32 * len(level_off))(*level_off)
+    n = _lib.load().eod_groupnorm_workspace_bytes(lo, len(level_off) - 1, groups)
+    return torch.empty(((n + 7) // 8,), dtype=torch.float64, device=device)
+
+
 def groupnorm_relu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, level_off: Sequence[int], Cc: int,
                    stats: torch.Tensor, groups: int = 32, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:

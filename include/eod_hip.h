@@ -73,7 +73,9 @@ int eod_preprocess_image(const uint8_t* img_chw, float* out_nhwc4, int H, int W,
 /* timm ResNet maxpool 3x3 s2 p1 (timm.py:281) */
 int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, eod_stream_t stream);
 /* GroupNorm(32)+ReLU over the 5 concatenated FPN levels (centernet_head.py:76-79); x,y [P,C], level l owns
- * rows [level_off[l], level_off[l+1]). stats workspace: 2*levels*groups floats. */
+ * rows [level_off[l], level_off[l+1]). stats: 8-byte aligned workspace of eod_groupnorm_workspace_bytes() bytes
+ * (mean/rstd per (level, group) followed by per-chunk double partial sums). */
+size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, int levels, int groups);
 int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
                        int levels, int C, int groups, float eps, float* stats, eod_stream_t stream);
 /* mask predictor 1x1 conv -> 1 channel + sigmoid (d2 mask head predictor + mask_rcnn_inference,

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the implicit-GEMM conv kernel on the shapes of the hot path (GPU box only)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from embodied_object_detection_amd import ops
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+
+def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=(0,), deconv=False, iters=20):
+    x = torch.randn((N, H, W, Cin), generator=g).to(dev)
+    if deconv:
+        w = torch.randn((Cin, Cout, 2, 2), generator=g) * 0.05
+        conv = ops.Conv(w, torch.zeros(Cout), device=dev, deconv=True)
+        flops = 2.0 * N * H * W * Cin * Cout * 4
+    else:
+        w = torch.randn((Cout, Cin, k, k), generator=g) * 0.05
+        conv = ops.Conv(w, torch.zeros(Cout), stride=stride, pad=pad, device=dev)
+        OH, OW = conv.out_hw(H, W)
+        flops = 2.0 * N * OH * OW * Cout * Cin * k * k
+    for t in tiles:
+        for sk in splitks:
+            try:
+                out = conv(x, N, H, W, relu=True, force_tile=t, force_splitk=sk)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    conv(x, N, H, W, relu=True, force_tile=t, force_splitk=sk, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / iters
+                print(f"{name:28s} tile={t} splitk={sk}  {ms*1e3:9.1f} us  {flops/ms/1e9:7.1f} TFLOP/s", flush=True)
+            except Exception as ex:
+                print(name, t, sk, "ERR", ex)
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "mask"):
+    bench("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1)
+    bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1)
+    bench("deconv 256 rois", 256, 14, 14, 256, 256, 2, 1, 0, deconv=True)
+if which in ("all", "resnet"):
+    bench("l1 conv2 3x3 64 160x160", 1, 160, 160, 64, 64, 3, 1, 1)
+    bench("l1 conv3 1x1 64->256", 1, 160, 160, 64, 256, 1, 1, 0)
+    bench("l2 conv2 3x3 128 80x80", 1, 80, 80, 128, 128, 3, 1, 1)
+    bench("l3 conv2 3x3 256 40x40", 1, 40, 40, 256, 256, 3, 1, 1, splitks=(0, 1, 2, 4))
+    bench("l4 conv2 3x3 512 20x20", 1, 20, 20, 512, 512, 3, 1, 1, splitks=(0, 1, 4, 8))
+    bench("l4 conv3 1x1 512->2048", 1, 20, 20, 512, 2048, 1, 1, 0, splitks=(0, 1, 2))
+    bench("tower 3x3 256 80x80", 1, 80, 80, 256, 256, 3, 1, 1)
+    bench("fc1 256x12544->1024", 256, 1, 1, 12544, 1024, 1, 1, 0, tiles=(0, 2, 3), splitks=(0, 4, 7, 14))
+    bench("fc2 256x1024->1024", 256, 1, 1, 1024, 1024, 1, 1, 0, tiles=(0, 3), splitks=(0, 1, 2, 4))

@@ -85,19 +85,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, ntiles);
-  const int tile_m = t / p.tiles_n;
-  const int tile_n = t - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
   int M = p.M;
   if (p.m_count) {
     const int c = *p.m_count;
     const int lim = c * p.m_unit;
     M = lim < M ? lim : M;
   }
-  if (m0 >= M) return;
+  // Only the tiles that hold valid rows do work; the XCD remap is taken over THAT count so that a short dynamic
+  // row count (e.g. 256 of 320 ROI slots) still spreads evenly over the 8 XCDs instead of idling the last ones.
+  const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int z = blockIdx.y;
   const int c_begin = z * p.cps;

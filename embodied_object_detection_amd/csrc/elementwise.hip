@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, LevelOff lo, int C, int groups, float eps,
                                                            float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per (level, group): lanes stride over the chunks, fixed-shape shuffle tree -> deterministic
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= lo.levels * groups) return;
   const int level = i / groups, g = i - level * groups;
   int first_chunk = 0;
@@ -107,10 +109,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   const int rows = lo.off[level + 1] - lo.off[level];
   const int nch = (rows + GN_ROWS - 1) / GN_ROWS;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < nch; ++c) {
+  for (int c = lane; c < nch; c += 64) {
     s += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
     q += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if (lane != 0) return;
   const double n = (double)rows * (C / groups);
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -228,7 +235,7 @@ extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, 
   const int cpg = C / groups;
   if (cpg > 64 || (cpg & (cpg - 1)) != 0 || 256 % cpg != 0) return EOD_ERR_BAD_DIMS;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((levels * groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, lo, C, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((levels * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, lo, C, groups,
                      eps, stats);
   hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)lo.off[levels] * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
                      gamma, beta, lo, C, groups, stats);

@@ -25,22 +25,61 @@ __device__ __forceinline__ u64 make_key(float score, unsigned idx) {
 __device__ __forceinline__ unsigned key_index(u64 k) { return 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull); }
 __device__ __forceinline__ float key_score(u64 k) { return __uint_as_float((unsigned)(k >> 32)); }
 
-// descending in-LDS bitonic sort, n power of two, all threads of the block participate
-__device__ void bitonic_sort_desc(u64* keys, int n) {
-  for (int k = 2; k <= n; k <<= 1) {
+// Descending bitonic sort of 1024*E keys held E per thread: thread t owns elements [t*E, t*E + E) of the
+// sequence.  Of the log2(N)(log2(N)+1)/2 compare-exchange stages only those with partner distance j >= 64*E need
+// the LDS exchange buffer and barriers (10 of 91 stages for N = 8192); distances E <= j < 64*E are wave shuffles
+// and j < E stay inside the thread's registers.  Block size must be 1024.
+template <int E, int J>
+__device__ __forceinline__ void sort_stage_intra(u64 (&v)[E], int base_i, int k) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((e & J) == 0) {
+      const bool desc = ((base_i + e) & k) == 0;
+      const u64 a = v[e], b = v[e | J];
+      const bool sw = desc ? (a < b) : (a > b);
+      v[e] = sw ? b : a;
+      v[e | J] = sw ? a : b;
+    }
+  }
+}
+
+template <int E>
+__device__ void block_sort_desc_reg(u64 (&v)[E], u64* xch) {
+  const int t = threadIdx.x;
+  const int base_i = t * E;
+  constexpr int N = 1024 * E;
+  for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const u64 a = keys[i], b = keys[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (a < b) : (a > b)) {
-            keys[i] = b;
-            keys[ixj] = a;
-          }
+      if (j < E) {
+        if (j == 1) sort_stage_intra<E, 1>(v, base_i, k);
+        else if (j == 2) sort_stage_intra<E, 2>(v, base_i, k);
+        else if (j == 4) sort_stage_intra<E, (E > 4 ? 4 : 1)>(v, base_i, k);
+        else sort_stage_intra<E, (E > 8 ? 8 : 1)>(v, base_i, k);
+      } else {
+        const int tj = j / E;  // partner thread = t ^ tj, same element slot
+        const bool lower = (t & tj) == 0;
+        if (tj >= 64) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) xch[e * 1024 + t] = v[e];
+          __syncthreads();
         }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          u64 b;
+          if (tj < 64) {
+            const unsigned lo = __shfl_xor((unsigned)(v[e] & 0xFFFFFFFFull), tj, 64);
+            const unsigned hi = __shfl_xor((unsigned)(v[e] >> 32), tj, 64);
+            b = ((u64)hi << 32) | lo;
+          } else {
+            b = xch[e * 1024 + (t ^ tj)];
+          }
+          const bool desc = ((base_i + e) & k) == 0;
+          const u64 a = v[e];
+          const u64 mx = a > b ? a : b, mn = a > b ? b : a;
+          v[e] = (lower == desc) ? mx : mn;
+        }
+        if (tj >= 64) __syncthreads();
       }
-      __syncthreads();
     }
   }
 }
@@ -225,16 +264,19 @@ struct CnArgs {
 
 // one block per level: per-level top-k by score
 __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
-  __shared__ u64 keys[EOD_SORT_MAX];
+  constexpr int E = EOD_SORT_MAX / 1024;
+  __shared__ u64 xch[EOD_SORT_MAX];
   __shared__ int sh_cnt;
   const int level = blockIdx.x;
   const int r0 = p.level_off[level];
   const int n = p.level_off[level + 1] - r0;
-  const int np2 = next_pow2(n);
   if (threadIdx.x == 0) sh_cnt = 0;
   __syncthreads();
+  u64 v[E];
   int local = 0;
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = threadIdx.x * E + e;
     u64 k = 0;
     if (i < n) {
       const float heat = eod_sigmoid_precise(p.head[(size_t)(r0 + i) * p.head_stride]);
@@ -243,39 +285,49 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
         ++local;
       }
     }
-    keys[i] = k;
+    v[e] = k;
   }
-  atomicAdd(&sh_cnt, local);
+  if (local) atomicAdd(&sh_cnt, local);
+  block_sort_desc_reg<E>(v, xch);
   __syncthreads();
-  bitonic_sort_desc(keys, np2);
   const int cnt = sh_cnt;
   const int take = cnt < p.topk ? cnt : p.topk;
-  for (int r = threadIdx.x; r < p.topk; r += blockDim.x) {
-    u64 k = 0;
-    if (r < take) {
-      const u64 src = keys[r];
-      const float heat = key_score(src);
-      const unsigned i = key_index(src);
-      k = make_key(sqrtf(heat), (unsigned)(r0 + (int)i));
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = threadIdx.x * E + e;
+    if (r < p.topk) {
+      u64 k = 0;
+      if (r < take) {
+        const float heat = key_score(v[e]);
+        const unsigned i = key_index(v[e]);
+        k = make_key(sqrtf(heat), (unsigned)(r0 + (int)i));
+      }
+      p.cand_keys[level * p.topk + r] = k;
     }
-    p.cand_keys[level * p.topk + r] = k;
   }
   if (threadIdx.x == 0) p.cand_cnt[level] = take;
 }
 
 // single block: merge the per-level lists, sort by sqrt-score, decode boxes
 __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_sorted) {
-  __shared__ u64 keys[8192];
+  constexpr int E = 8;
+  __shared__ u64 xch[1024 * E];
   const int total_slots = p.levels * p.topk;
-  const int np2 = next_pow2(total_slots);
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < total_slots ? p.cand_keys[i] : 0ull;
-  __syncthreads();
-  bitonic_sort_desc(keys, np2);
+  u64 v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = threadIdx.x * E + e;
+    v[e] = i < total_slots ? p.cand_keys[i] : 0ull;
+  }
+  block_sort_desc_reg<E>(v, xch);
   int n = 0;
   for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
   if (threadIdx.x == 0) *n_sorted = n;
-  for (int r = threadIdx.x; r < n; r += blockDim.x) {
-    const u64 k = keys[r];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = threadIdx.x * E + e;
+    if (r >= n) continue;
+    const u64 k = v[e];
     const int g = (int)key_index(k);
     int level = 0;
     while (level + 1 < p.levels && g >= p.level_off[level + 1]) ++level;
@@ -311,7 +363,8 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
                                                                const int* __restrict__ count, int R_cap, int C1, float img_w,
                                                                float img_h, float thr, float* sorted_boxes, float* sorted_scores,
                                                                int* sorted_labels, int* sorted_rows, int* n_sorted) {
-  __shared__ u64 keys[8192];
+  constexpr int E = 8;
+  __shared__ u64 xch[1024 * E];
   __shared__ int sh_cnt;
   int R = R_cap;
   if (count) {
@@ -320,11 +373,13 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
   }
   const int C = C1 - 1;
   const int slots = R_cap * C;
-  const int np2 = next_pow2(slots);
   if (threadIdx.x == 0) sh_cnt = 0;
   __syncthreads();
+  u64 v[E];
   int local = 0;
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = threadIdx.x * E + e;
     u64 k = 0;
     if (i < slots) {
       const int r = i / C, c = i - r * C;
@@ -339,15 +394,18 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
         }
       }
     }
-    keys[i] = k;
+    v[e] = k;
   }
-  atomicAdd(&sh_cnt, local);
+  if (local) atomicAdd(&sh_cnt, local);
+  block_sort_desc_reg<E>(v, xch);
   __syncthreads();
-  bitonic_sort_desc(keys, np2);
   const int n = sh_cnt;
   if (threadIdx.x == 0) *n_sorted = n;
-  for (int q = threadIdx.x; q < n; q += blockDim.x) {
-    const u64 k = keys[q];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int q = threadIdx.x * E + e;
+    if (q >= n) continue;
+    const u64 k = v[e];
     const int i = (int)key_index(k);
     const int r = i / C, c = i - r * C;
     sorted_boxes[q * 4 + 0] = fminf(fmaxf(boxes[r * 4 + 0], 0.f), img_w);

@@ -123,7 +123,8 @@ def main():
     from embodied_object_detection_amd import build_model, ops, setup_cfg
     from embodied_object_detection_amd.checkpoint import synthetic_state_dict
     from embodied_object_detection_amd.data.synthetic import SyntheticSequence
-    from embodied_object_detection_amd.evaluation.coco_ap import DetectionRecords, evaluate_records
+    from embodied_object_detection_amd.engine.eval_loop import (KIND_DET, KIND_GT, RecordBuffer, evaluate_gathered, gather_records,
+                                                                 gt_to_coco_xyxy)
 
     H, W = args.size
     map_w, map_h = args.grid
@@ -191,17 +192,23 @@ def main():
         elapsed = float(t.item())
 
     # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
-    rec = DetectionRecords(world, max_dets=4 * 100, max_gt=4 * 8, device=dev)
+    rec = RecordBuffer(max_rows=4 * 108)
     for j, i in enumerate(range(args.warmup, n_frames)):
         if j % max(1, args.steps // 4) == 0 and j // max(1, args.steps // 4) < 4:
             inst = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=True)["instances"]
-            rec.add_image(rank, host_frames[i]["image_id"], inst, host_frames[i]["instances"])
+            n = min(len(inst), 100)
+            b, sc, cl = inst.pred_boxes.tensor[:n].cpu().numpy(), inst.scores[:n].cpu().numpy(), inst.pred_classes[:n].cpu().numpy()
+            for q in range(n):
+                rec.add([KIND_DET, rank, j, float(cl[q]), float(sc[q]), *b[q].tolist(), 0])
+            gt = host_frames[i]["instances"]
+            gb = gt_to_coco_xyxy(gt["gt_boxes"])
+            for q, c in enumerate(gt["gt_classes"].tolist()):
+                rec.add([KIND_GT, rank, j, float(c), 0.0, *gb[q].tolist(), 0])
+    torch.cuda.synchronize()
     t_ar = time.perf_counter()
-    if distributed:
-        dist.all_reduce(rec.buffer, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
+    buf = gather_records(rec, rank, world, dev)          # ONE all_reduce(SUM) over RCCL when world > 1
     t_ar = time.perf_counter() - t_ar
-    ap = evaluate_records(rec.buffer.cpu().numpy(), num_classes=20) if rank == 0 else None
+    ap = evaluate_gathered(buf, 20)["all"] if rank == 0 else None
 
     # ---- dominant kernel roofline ----------------------------------------------------------------------------------
     roofline = None

@@ -1,0 +1,150 @@
+"""Eval driver of the hot path: episode loop, every-5th-frame evaluation, quartile bucketing, scene sharding and the
+single-collective aggregation.
+
+Mirrors `mp3d_inference_on_dataset` (`Detic/train_mp3d.py:85-363`) and `do_test` (`380-450`): per episode `model([inputs])`,
+keep every 5th frame's output (`187-188`), rebuild the GT as integer-truncated XYWH boxes with `area: 0` (`232-238`),
+bucket images into quartiles by `idx % 100` (`210-217`), evaluate the four quartiles and the whole set (`301-358`).
+
+Multi-GPU: scenes are sharded `scene -> rank = scene_index % world`, all episodes of a scene stay on one rank in
+order (the memory is per scene, `Detic/SMNet/loader.py:289-291`).  detectron2's `InferenceSampler` contiguous split is NOT used:
+it would cut scenes across ranks and hit unset memory state (`custom_rcnn.py:485`).  Results are combined with ONE
+`all_reduce(SUM)` of a fixed-shape record buffer (evaluation/coco_ap.py) instead of detectron2's pickle gather.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..evaluation.coco_ap import KIND_DET, KIND_GT, coco_eval
+
+ROW = 10  # kind, scene id, frame index in scene, class, score, x1, y1, x2, y2, global episode index
+
+
+def shard_scenes(n_scenes: int, rank: int, world: int) -> List[int]:
+    """Scene ids owned by `rank` (round-robin by scene id)."""
+    return [s for s in range(n_scenes) if s % world == rank]
+
+
+def gt_to_coco_xyxy(gt_boxes: torch.Tensor) -> np.ndarray:
+    """The driver's GT: [int(x1), int(y1), int(x2-x1), int(y2-y1)] XYWH (train_mp3d.py:237) back to xyxy."""
+    out = []
+    for b in gt_boxes.tolist():
+        x, y, w, h = int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])
+        out.append([x, y, x + w, y + h])
+    return np.asarray(out, dtype=np.float64).reshape(-1, 4)
+
+
+class RecordBuffer:
+    """Host-side staging of this rank's records; `to_tensor` pads to the fixed [rows, ROW] shape of the collective."""
+
+    def __init__(self, max_rows: int):
+        self.max_rows = max_rows
+        self.rows: List[List[float]] = []
+        self.dropped = 0
+
+    def add(self, row: Sequence[float]):
+        if len(self.rows) < self.max_rows:
+            self.rows.append(list(row))
+        else:
+            self.dropped += 1
+
+    def to_tensor(self, device) -> torch.Tensor:
+        t = torch.zeros((self.max_rows, ROW), dtype=torch.float32)
+        if self.rows:
+            t[:len(self.rows)] = torch.tensor(self.rows, dtype=torch.float32)
+        return t.to(device)
+
+
+def episode_offsets(frames_per_scene: Sequence[int], episode_len: int = 20) -> List[int]:
+    """Global dataloader index of the first episode of every scene (dataset order = scene order, loader.py:97-105)."""
+    off, run = [], 0
+    for n in frames_per_scene:
+        off.append(run)
+        run += (n + episode_len - 1) // episode_len
+    return off
+
+
+def inference_on_scenes(model, scenes: Iterable, rank: int = 0, max_rows: int = 1 << 16, every: int = 5,
+                        on_episode: Optional[Callable] = None, scene_episode_offset: Optional[Dict[int, int]] = None) -> Dict:
+    """Run this rank's scenes; returns {'records': RecordBuffer, 'frames': n, 'seconds': t}.
+
+    `scenes`: iterable of objects with `.seq_id` and `.episodes()` yielding lists of frame dicts (data/synthetic.py schema).
+    Records carry (scene id, frame index) and the GLOBAL episode index, so the aggregate is identical however the scenes are
+    sharded (COCO's stable sorts break score ties by image order)."""
+    rec = RecordBuffer(max_rows)
+    frames = 0
+    t0 = time.perf_counter()
+    for scene in scenes:
+        sid = int(scene.seq_id)
+        idx = (scene_episode_offset or {}).get(sid, 0)
+        im_id = 0
+        for inputs in scene.episodes():
+            outputs = model([inputs])                                      # train_mp3d.py:186
+            frames += len(inputs)
+            outs = [outputs[i] for i in range(0, len(outputs), every)]     # :187-188
+            ins = [inputs[i] for i in range(0, len(inputs), every)]
+            for inp, out in zip(ins, outs):
+                inst = out["instances"]
+                n = min(len(inst), 100)                                     # COCO maxDets
+                if n:
+                    b = inst.pred_boxes.tensor[:n].float().cpu().numpy()
+                    s = inst.scores[:n].float().cpu().numpy()
+                    c = inst.pred_classes[:n].cpu().numpy()
+                    for j in range(n):
+                        rec.add([KIND_DET, sid, im_id, float(c[j]), float(s[j]), *b[j].tolist(), idx])
+                gt = inp.get("instances")
+                if gt is not None:
+                    gb = gt_to_coco_xyxy(gt["gt_boxes"])
+                    gc = gt["gt_classes"].tolist()
+                    for j in range(len(gc)):
+                        rec.add([KIND_GT, sid, im_id, float(gc[j]), 0.0, *gb[j].tolist(), idx])
+                im_id += 1
+            if on_episode is not None:
+                on_episode(idx, inputs, outputs)
+            idx += 1
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return {"records": rec, "frames": frames, "seconds": time.perf_counter() - t0}
+
+
+def gather_records(rec: RecordBuffer, rank: int, world: int, device) -> np.ndarray:
+    """ONE collective: every rank writes its slice of a zero [world, rows, ROW] buffer, all_reduce(SUM)."""
+    local = rec.to_tensor(device)
+    if world == 1:
+        return local.cpu().numpy()[None]
+    import torch.distributed as dist
+    buf = torch.zeros((world,) + tuple(local.shape), dtype=torch.float32, device=device)
+    buf[rank] = local
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf.cpu().numpy()
+
+
+def evaluate_gathered(buf: np.ndarray, num_classes: int) -> Dict[str, Dict[str, float]]:
+    """Quartile + overall COCO bbox results (train_mp3d.py:301-358) from the gathered [world, rows, ROW] records."""
+    dets, gts, quart = {}, {}, {}
+    for r in range(buf.shape[0]):
+        rows = buf[r]
+        rows = rows[rows[:, 0] > 0]
+        for row in rows:
+            uid = int(row[1]) * 1_000_000 + int(row[2])                   # canonical image order: (scene, frame)
+            store = dets if row[0] == KIND_DET else gts
+            e = store.setdefault(uid, {"boxes": [], "scores": [], "classes": []})
+            e["boxes"].append(row[5:9])
+            e["scores"].append(row[4])
+            e["classes"].append(int(row[3]))
+            quart[uid] = min(3, int(row[9]) % 100 // 25)                  # idx % 100 buckets (:210-217)
+    for store in (dets, gts):
+        for e in store.values():
+            e["boxes"] = np.asarray(e["boxes"], dtype=np.float64).reshape(-1, 4)
+            e["scores"] = np.asarray(e["scores"], dtype=np.float64)
+            e["classes"] = np.asarray(e["classes"], dtype=np.int64)
+    all_ids = sorted(set(dets) | set(gts))
+    results = {"all": coco_eval(dets, gts, num_classes, image_ids=all_ids)}
+    for qi, name in enumerate(("first_quartile", "second_quartile", "third_quartile", "fourth_quartile")):
+        ids = [u for u in all_ids if quart.get(u) == qi]
+        if ids:
+            results[name] = coco_eval(dets, gts, num_classes, image_ids=ids)
+    return results

@@ -1,5 +1,4 @@
-"""COCO bbox AP / AP50 as the reference's eval uses it, plus the fixed-shape record buffer that replaces
-detectron2's pickle gather with ONE all-reduce.
+"""COCO bbox AP / AP50 as the reference's eval uses it (the record buffer / collective live in engine/eval_loop.py).
 
 Reference call sites: `Detic/train_mp3d.py:246,301-358` (`COCOEvaluator` -> pycocotools `COCOeval`; neither package
 is vendored: semantics per SURVEY.md Appendix A14).  Host-side numpy: this is evaluation bookkeeping, not the hot path.
@@ -105,56 +104,3 @@ def coco_eval(dets: Dict[int, dict], gts: Dict[int, dict], num_classes: int, max
 
     return {"AP": mean_valid(ap_per_cat), "AP50": mean_valid(ap_per_cat[0]), "AP75": mean_valid(ap_per_cat[5]),
             "num_images": len(imgs)}
-
-
-class DetectionRecords:
-    """`[world, rows, 8]` fp32 device buffer; row = (kind, local image index, class, score, x1, y1, x2, y2)."""
-
-    def __init__(self, world: int, max_dets: int, max_gt: int, device):
-        self.world, self.rows = world, max_dets + max_gt
-        self.buffer = torch.zeros((world, self.rows, 8), dtype=torch.float32, device=device)
-        self._n = 0
-        self._img = 0
-
-    def _put(self, rank: int, rows: torch.Tensor):
-        n = rows.shape[0]
-        if n == 0:
-            return
-        n = min(n, self.rows - self._n)
-        self.buffer[rank, self._n:self._n + n] = rows[:n].to(self.buffer.device)
-        self._n += n
-
-    def add_image(self, rank: int, image_id: int, instances, gt: dict, max_dets: int = 100):
-        idx = float(self._img)
-        self._img += 1
-        if len(instances):
-            b = instances.pred_boxes.tensor[:max_dets].float()
-            n = b.shape[0]
-            rows = torch.cat([torch.full((n, 1), KIND_DET, device=b.device), torch.full((n, 1), idx, device=b.device),
-                              instances.pred_classes[:n, None].float(), instances.scores[:n, None].float(), b], dim=1)
-            self._put(rank, rows)
-        gb = gt["gt_boxes"].float()
-        if len(gb):
-            n = gb.shape[0]
-            rows = torch.cat([torch.full((n, 1), KIND_GT), torch.full((n, 1), idx), gt["gt_classes"][:, None].float(),
-                              torch.zeros((n, 1)), gb], dim=1)
-            self._put(rank, rows)
-
-
-def records_to_coco(buf: np.ndarray):
-    dets, gts = {}, {}
-    for r in range(buf.shape[0]):
-        rows = buf[r]
-        for kind, store in ((KIND_DET, dets), (KIND_GT, gts)):
-            sel = rows[rows[:, 0] == kind]
-            for li in np.unique(sel[:, 1]):
-                s = sel[sel[:, 1] == li]
-                uid = r * 1_000_000 + int(li)
-                store[uid] = {"boxes": s[:, 4:8].astype(np.float64), "scores": s[:, 3].astype(np.float64),
-                              "classes": s[:, 2].astype(np.int64)}
-    return dets, gts
-
-
-def evaluate_records(buf: np.ndarray, num_classes: int) -> Dict[str, float]:
-    dets, gts = records_to_coco(buf)
-    return coco_eval(dets, gts, num_classes)

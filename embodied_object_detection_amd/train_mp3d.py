@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""`train_mp3d.py --eval-only` for the MI355X build: same flags and trailing `KEY VALUE` overrides as
+`Detic/train_mp3d.py:757-857` (`--config-file --eval-only --num-gpus --num-machines --machine-rank --dist-url --resume`).
+
+    python -m embodied_object_detection_amd.train_mp3d --num-gpus 1 --eval-only \
+        --config-file <pkg>/configs/Detic_LCOCOI21k_CLIP_R5021k_640b32_4x_ft4x_max-size_mp3d_recurrent.yaml \
+        MODEL.MAP_FEAT_FUSION sum MODEL.MEMORY_TYPE implicit_memory MODEL.MAP_FEATURE_WEIGHT 5
+
+One process per GPU (detectron2 `launch` semantics): either started by `torch.distributed.run` (RANK / WORLD_SIZE in the
+environment) or spawned here for `--num-gpus N`; backend `nccl` (= RCCL over xGMI) on GPUs.  Training (`do_train`) is out
+of scope of the hot path.  The real `mp3d_example` needs the h5 reader (not built yet): without it the
+driver evaluates the deterministic synthetic scenes of SURVEY §8d.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+
+def default_argument_parser():
+    p = argparse.ArgumentParser(description="embodied detector eval (MI355X build)")
+    p.add_argument("--config-file", default="", metavar="FILE")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--eval-only", action="store_true")
+    p.add_argument("--num-gpus", type=int, default=1)
+    p.add_argument("--num-machines", type=int, default=1)
+    p.add_argument("--machine-rank", type=int, default=0)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:29512")
+    p.add_argument("--synthetic-scenes", type=int, default=2, help="number of synthetic scenes (no real data offline)")
+    p.add_argument("--synthetic-frames", type=int, default=40)
+    p.add_argument("--synthetic-size", type=int, nargs=2, default=[640, 640])
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
+    return p
+
+
+def do_test(cfg, model, args, rank: int, world: int):
+    from .data.synthetic import SyntheticSequence
+    from .engine.eval_loop import (episode_offsets, evaluate_gathered, gather_records, inference_on_scenes, shard_scenes)
+    H, W = args.synthetic_size
+    mine = shard_scenes(args.synthetic_scenes, rank, world)
+    scenes = [SyntheticSequence(s, H=H, W=W, n_frames=args.synthetic_frames) for s in mine]
+    offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
+    res = inference_on_scenes(model, scenes, rank, scene_episode_offset=offs)
+    buf = gather_records(res["records"], rank, world, model.device)
+    out = None
+    if rank == 0:
+        out = evaluate_gathered(buf, int(cfg.MODEL.ROI_HEADS.NUM_CLASSES))
+        for name, r in out.items():
+            print(f"[eval] {name}: AP {r['AP']:.3f} AP50 {r['AP50']:.3f} AP75 {r['AP75']:.3f} ({r['num_images']} images)")
+    print(f"[rank {rank}] {res['frames']} frames in {res['seconds']:.2f} s = {res['frames'] / max(res['seconds'], 1e-9):.1f} frames/s")
+    return out
+
+
+def main(args, rank: int = 0, world: int = 1, local_rank: int = 0):
+    from . import build_model, setup_cfg
+    if not args.eval_only:
+        raise NotImplementedError("only --eval-only is in scope (training forward: SURVEY §8f rank 4)")
+    opts = list(args.opts or [])
+    if opts and opts[0] == "--":
+        opts = opts[1:]
+    opts += ["MODEL.DEVICE", f"cuda:{local_rank}"]
+    cfg = setup_cfg(args.config_file or None, opts)
+    model = build_model(cfg)
+    return do_test(cfg, model, args, rank, world)
+
+
+def _worker(local_rank: int, args, world: int):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", args.dist_url.rsplit(":", 1)[-1])
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=local_rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    try:
+        main(args, local_rank, world, local_rank)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch(args):
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        import torch.distributed as dist
+        rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{lr}"))
+        try:
+            return main(args, rank, world, lr)
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    if args.num_gpus > 1:
+        import torch.multiprocessing as mp
+        mp.spawn(_worker, args=(args, args.num_gpus), nprocs=args.num_gpus, join=True)
+        return None
+    return main(args)
+
+
+if __name__ == "__main__":
+    launch(default_argument_parser().parse_args())

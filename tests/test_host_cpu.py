@@ -1,0 +1,296 @@
+"""CPU-side tests (no GPU): the C ABI surface, the config / registry / checkpoint boundary, the evaluator, scene sharding and
+the single-collective aggregation over a world_size-2 gloo group."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------------------
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "eod_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"^(?:int|size_t)\s+(eod_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()                                   # hipcc cross-compiles gfx950 without a GPU
+    from embodied_object_detection_amd import _lib
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and include/eod_hip.h must list the same entry points"
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.eod_abi_version() == 1                         # host-only call, no GPU needed
+
+
+def test_conv_descriptor_validation_without_gpu():
+    """Bad descriptors are rejected by the host-side checks before anything touches a device."""
+    import ctypes as C
+    from embodied_object_detection_amd import _lib
+    lib = _lib.load()
+    d = _lib.EodConvDesc()
+    assert lib.eod_conv2d(C.byref(d), None) == -4             # EOD_ERR_NULL
+    buf = (C.c_float * 64)()
+    d.x = d.w = d.y = C.addressof(buf)
+    d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Kpad = 1, 4, 4, 48, 4, 4, 8, 1, 1, 1, 0, 64
+    assert lib.eod_conv2d(C.byref(d), None) == -1             # Cin % 32 != 0 -> EOD_ERR_BAD_DIMS
+    assert lib.eod_conv2d_workspace_bytes(C.byref(d)) == 0
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
+    from embodied_object_detection_amd import _lib, build_model, setup_cfg
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(_lib.EodError):
+        build_model(setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory"]))
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libeod_hip.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.EodError, match="not built"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "embodied_object_detection_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config / registry / checkpoint
+# ---------------------------------------------------------------------------------------------------------
+def test_config_base_chain_and_overrides():
+    from embodied_object_detection_amd import setup_cfg
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEATURE_WEIGHT", "5", "MODEL.MAP_FEAT_FUSION", "sum",
+                           "MODEL.TEST_TYPE", "longterm"])
+    # from the base file through _BASE_
+    assert cfg.MODEL.META_ARCHITECTURE == "CustomRCNNRecurrent"
+    assert cfg.MODEL.BACKBONE.NAME == "build_p67_timm_fpn_backbone_recurrent"
+    assert cfg.MODEL.PROPOSAL_GENERATOR.NAME == "CenterNet" and cfg.MODEL.ROI_HEADS.NAME == "DeticCascadeROIHeads"
+    assert cfg.MODEL.CENTERNET.POST_NMS_TOPK_TEST == 256 and cfg.MODEL.CENTERNET.INFERENCE_TH == pytest.approx(1e-4)
+    assert cfg.TEST.DETECTIONS_PER_IMAGE == 300 and cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST == pytest.approx(0.02)
+    # from the child file
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 20 and cfg.MODEL.TIMM.BASE_NAME == "resnet50_in21k_map"
+    # defaults of detic/config.py that no YAML sets
+    assert cfg.MODEL.MEMORY_CLS_SCORE_THRESH == pytest.approx(0.3) and cfg.MODEL.MEMORY_OBS_SCORE_THRESH == pytest.approx(0.4)
+    # KEY VALUE overrides (strings are literal-evaluated and coerced to the default's type)
+    assert cfg.MODEL.MEMORY_TYPE == "implicit_memory" and cfg.MODEL.TEST_TYPE == "longterm"
+    assert cfg.MODEL.MAP_FEATURE_WEIGHT == 5 and cfg.MODEL.MAP_FEAT_FUSION == "sum"
+    assert os.path.exists(cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH)
+    assert cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS[2] == (30.0, 30.0, 15.0, 15.0)
+
+
+def test_registries_carry_the_reference_names():
+    import embodied_object_detection_amd.modeling  # noqa: F401
+    from embodied_object_detection_amd import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY,
+                                               ROI_HEADS_REGISTRY)
+    assert "CustomRCNNRecurrent" in META_ARCH_REGISTRY
+    assert "build_p67_timm_fpn_backbone_recurrent" in BACKBONE_REGISTRY
+    assert "CenterNet" in PROPOSAL_GENERATOR_REGISTRY
+    assert "DeticCascadeROIHeads" in ROI_HEADS_REGISTRY
+    with pytest.raises(KeyError):
+        META_ARCH_REGISTRY.get("DeformableDetr")
+
+
+def test_checkpoint_keys_loader_and_synthetic_weights(tmp_path):
+    from embodied_object_detection_amd.checkpoint import (expected_shapes, fill_missing, load_checkpoint, reset_cls_test,
+                                                           synthetic_state_dict)
+    shapes = expected_shapes(20)
+    h = "proposal_generator.centernet_head"
+    assert sum(k.startswith(h) for k in shapes) == 25                       # 25 tensors
+    assert shapes["roi_heads.box_head.0.fc1.weight"] == (1024, 12544)
+    assert shapes["backbone.map_merge_projection2.weight"] == (256, 512, 1, 1)
+    assert shapes["roi_heads.mask_head.deconv.weight"] == (256, 256, 2, 2)
+    sd = synthetic_state_dict(0)
+    sd2 = synthetic_state_dict(0)
+    assert list(sd) == list(shapes) and all(torch.equal(sd[k], sd2[k]) for k in ("backbone.fpn_output3.weight", f"{h}.agn_hm.bias"))
+    zs = sd["roi_heads.box_predictor.1.cls_score.zs_weight"]
+    assert zs.shape == (512, 21) and torch.allclose(zs[:, :20].norm(dim=0), torch.ones(20), atol=1e-5) and float(zs[:, 20].abs().max()) == 0
+    # d2-style .pth: {'model': ...}; LVIS-sized classifier is skipped (shape mismatch), map_merge_* missing (plain Detic checkpoint)
+    model = {k: v for k, v in sd.items() if "map_merge_projection" not in k}
+    model["roi_heads.box_predictor.0.cls_score.zs_weight"] = torch.zeros((512, 1204))
+    model["backbone.bottom_up.base.fc.weight"] = torch.zeros((10, 2048))
+    path = str(tmp_path / "model_final.pth")
+    torch.save({"model": model, "iteration": 7}, path)
+    loaded, rep = load_checkpoint(path, 20, verbose=False)
+    assert len(rep["missing"]) == 6 and all("map_merge_projection" in k for k in rep["missing"])
+    assert rep["shape_mismatch"][0][0] == "roi_heads.box_predictor.0.cls_score.zs_weight"
+    assert rep["unexpected"] == ["backbone.bottom_up.base.fc.weight"]
+    full = fill_missing(loaded, 0, 20)
+    assert list(full) == list(shapes)
+    reset_cls_test(full, os.path.join(ROOT, "embodied_object_detection_amd", "metadata", "mp3d_clip.npy"), 20)
+    assert full["roi_heads.box_predictor.0.cls_score.zs_weight"].shape == (512, 21)
+
+
+def test_weight_packing_layouts():
+    from embodied_object_detection_amd.ops import fold_bn, pack_conv_weight
+    w = torch.arange(2 * 3 * 2 * 2, dtype=torch.float32).view(2, 3, 2, 2)
+    packed, kpad = pack_conv_weight(w, cin_pad=4)
+    assert kpad == 32 and packed.shape == (2, 32)
+    # k = (ky, kx, c) with c fastest, channel 3 is the zero pad
+    assert packed[1, (1 * 2 + 0) * 4 + 2] == w[1, 2, 1, 0] and packed[0, 3] == 0 and float(packed[:, 16:].abs().sum()) == 0
+    wf, bf = fold_bn(torch.ones(2, 1, 1, 1), torch.tensor([2.0, 4.0]), torch.tensor([1.0, 1.0]), torch.tensor([0.5, 0.0]),
+                     torch.tensor([1.0 - 1e-5, 4.0 - 1e-5]))
+    assert torch.allclose(wf.flatten(), torch.tensor([2.0, 2.0])) and torch.allclose(bf, torch.tensor([0.0, 1.0]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# evaluator
+# ---------------------------------------------------------------------------------------------------------
+def test_coco_ap_known_answers():
+    from embodied_object_detection_amd.evaluation.coco_ap import coco_eval
+    g = {0: {"boxes": np.array([[0, 0, 10, 10], [20, 20, 40, 40.0]]), "classes": np.array([0, 0])}}
+    perfect = {0: {"boxes": g[0]["boxes"].copy(), "scores": np.array([0.9, 0.8]), "classes": np.array([0, 0])}}
+    r = coco_eval(perfect, g, 3)
+    assert r["AP"] == pytest.approx(100.0) and r["AP50"] == pytest.approx(100.0)
+    # one TP (IoU 0.81 -> counts up to the 0.80 threshold), one FP ranked first, one miss
+    d = {0: {"boxes": np.array([[50, 50, 60, 60], [0, 0, 9, 9.0]]), "scores": np.array([0.9, 0.8]), "classes": np.array([0, 0])}}
+    r = coco_eval(d, g, 3)
+    # precision at recall<=0.5 is 1/2, beyond 0 -> 51 of 101 recall points at 0.5
+    assert r["AP50"] == pytest.approx(100 * 51 * 0.5 / 101, abs=1e-6)
+    assert r["AP75"] == pytest.approx(100 * 51 * 0.5 / 101, abs=1e-6)
+    assert r["AP"] == pytest.approx(100 * (7 / 10) * 51 * 0.5 / 101, abs=1e-6)      # thresholds .5 ... .8 match
+    # a class with no GT is excluded, a class with GT but no detections counts 0
+    g2 = {0: {"boxes": np.array([[0, 0, 10, 10], [0, 0, 5, 5.0]]), "classes": np.array([0, 1])}}
+    d2 = {0: {"boxes": np.array([[0, 0, 10, 10.0]]), "scores": np.array([0.5]), "classes": np.array([0])}}
+    assert coco_eval(d2, g2, 3)["AP50"] == pytest.approx(50.0)
+
+
+def test_gt_truncation_and_sharding():
+    from embodied_object_detection_amd.engine.eval_loop import gt_to_coco_xyxy, shard_scenes
+    b = gt_to_coco_xyxy(torch.tensor([[1.9, 2.2, 10.7, 8.1]]))
+    assert b.tolist() == [[1.0, 2.0, 9.0, 7.0]]                                  # int(x), int(y), int(w), int(h) -> xyxy
+    assert shard_scenes(5, 0, 2) == [0, 2, 4] and shard_scenes(5, 1, 2) == [1, 3]
+    assert sorted(sum((shard_scenes(11, r, 4) for r in range(4)), [])) == list(range(11))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# driver with a stub model + the collective (gloo, world 2)
+# ---------------------------------------------------------------------------------------------------------
+class _StubModel:
+    """Host-logic stand-in: returns the frame's own GT boxes as detections (score by box index)."""
+    device = torch.device("cpu")
+
+    def __call__(self, batched):
+        from embodied_object_detection_amd import Boxes, Instances
+        out = []
+        for seq in batched:
+            for f in seq:
+                gt = f["instances"]
+                n = len(gt["gt_classes"])
+                keep = max(1, n - (f["image_id"] % 2))                          # drop one box on odd frames
+                inst = Instances((f["height"], f["width"]))
+                b = gt["gt_boxes"][:keep].clone()
+                b[:, :] = torch.floor(b)                                       # the driver truncates GT the same way
+                inst.pred_boxes = Boxes(b)
+                inst.scores = torch.linspace(0.9, 0.5, keep)
+                inst.pred_classes = gt["gt_classes"][:keep].clone()
+                out.append({"instances": inst})
+        return out
+
+
+def _cpu_projector():
+    from oracle import projector as OP
+    return lambda depth, T, intr, ps, ms, cell, mw, mh, order=0: OP.depth_to_proj_indices(depth, T, intr, ps, ms, cell, mw, mh, order)
+
+
+def _run_rank(rank, world, port, n_scenes, q):
+    import torch.distributed as dist
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.engine.eval_loop import (episode_offsets, evaluate_gathered, gather_records,
+                                                                 inference_on_scenes, shard_scenes)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    scenes = [SyntheticSequence(s, H=32, W=32, n_frames=25, map_w=10, map_h=10, projector=_cpu_projector())
+              for s in shard_scenes(n_scenes, rank, world)]
+    offs = dict(enumerate(episode_offsets([25] * n_scenes)))
+    res = inference_on_scenes(_StubModel(), scenes, rank, max_rows=4096, scene_episode_offset=offs)
+    buf = gather_records(res["records"], rank, world, torch.device("cpu"))
+    if rank == 0:
+        q.put((evaluate_gathered(buf, 20), res["frames"]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_eval_world2_equals_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q1 = ctx.Queue()
+    _run_rank(0, 1, 0, 3, q1)
+    single, frames = q1.get()
+    assert frames == 75 and single["all"]["num_images"] == 15                  # every 5th frame of 3 x 25
+    assert 50.0 < single["all"]["AP50"] <= 100.0
+    q2 = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_rank, args=(r, 2, port, 3, q2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sharded, _ = q2.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sharded["all"]["num_images"] == single["all"]["num_images"]
+    for k in ("AP", "AP50", "AP75"):
+        assert sharded["all"][k] == pytest.approx(single["all"][k], abs=1e-9), "sharding must not change the aggregate AP"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# synthetic loader schema
+# ---------------------------------------------------------------------------------------------------------
+def test_synthetic_sequence_schema_and_reset_rule():
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    seq = SyntheticSequence(3, H=64, W=96, n_frames=45, map_w=30, map_h=20, projector=_cpu_projector())
+    eps = list(seq.episodes())
+    assert [len(e) for e in eps] == [20, 20, 5]
+    f0, f1 = eps[0][0], eps[1][0]
+    assert f0["memory_reset"] is True and not any(f["memory_reset"] for e in eps for f in e[1:]) and f1["memory_reset"] is False
+    assert f0["image"].dtype == torch.uint8 and tuple(f0["image"].shape) == (3, 64, 96)
+    assert f0["proj_indices"].dtype == np.int32 and f0["proj_indices"].shape == (64, 96, 1)
+    assert f0["memory"].shape[0] == 600 and 0 <= f0["proj_indices"].min() and f0["proj_indices"].max() < 600
+    assert f0["observations"] is None and f0["sequence_name"] == "synthetic_00003" and f0["height"] == 64 and f0["width"] == 96
+    again = SyntheticSequence(3, H=64, W=96, n_frames=45, map_w=30, map_h=20, projector=_cpu_projector()).frame(7)
+    assert torch.equal(again["image"], eps[0][7]["image"]) and np.array_equal(again["proj_indices"], eps[0][7]["proj_indices"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# oracle properties (the checker itself)
+# ---------------------------------------------------------------------------------------------------------
+def test_oracle_nms_and_roi_align_properties():
+    from oracle import ops as OO
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.0]])
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.9])
+    keep = OO.nms(boxes, scores, 0.5)
+    assert keep.tolist() == [0, 2]                                              # tie -> lower index first, dup suppressed
+    keep = OO.batched_nms(boxes, scores, torch.tensor([0, 1, 0, 1]), 0.5)
+    assert keep.tolist() == [0, 3, 2]                                           # per class; box 3 suppresses box 1
+    # ROIAlign of a constant map is that constant; of a linear ramp it is the ramp at the bin centres
+    feat = torch.full((1, 4, 16, 16), 3.0)
+    out = OO.roi_align_single(feat[0], torch.tensor([16.0, 16.0, 80.0, 80.0]), 1.0 / 8, 7)
+    assert torch.allclose(out, torch.full_like(out, 3.0))
+    ramp = torch.arange(16.0).view(1, 1, 16).expand(1, 16, 16).contiguous()
+    out = OO.roi_align_single(ramp, torch.tensor([32.0, 32.0, 88.0, 88.0]), 1.0 / 8, 7)
+    expect = 4.0 - 0.5 + (torch.arange(7.0) + 0.5)                            # x1*s-0.5 + (pw+0.5)*bin, bin = 1
+    assert torch.allclose(out[0, 0], expect, atol=1e-5)
+    lv = OO.assign_boxes_to_levels(torch.tensor([[0, 0, 10, 10], [0, 0, 224, 224], [0, 0, 600, 600.0]]))
+    assert lv.tolist() == [0, 1, 2]

@@ -31,7 +31,8 @@ class EodConvDesc(C.Structure):
         ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("Kpad", C.c_int32), ("relu", C.c_int32), ("res_mode", C.c_int32), ("in_relu", C.c_int32),
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
-        ("out_scale", C.c_float),
+        ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
+        ("level_w", C.c_int32 * 5),
     ]
 
 
@@ -104,6 +105,8 @@ SIGNATURES = {
     "eod_memory_write_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "eod_memory_write_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_write": (C.c_int, [C.POINTER(EodMemWriteDesc), C.c_void_p]),
+    "eod_semmap_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "eod_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]),
     "eod_fill_i32": (C.c_int, [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p]),
 }

@@ -37,6 +37,9 @@ struct ConvArgs {
   int relu, res_mode, in_relu, out_mode;
   int tiles_m, tiles_n;
   float out_scale;
+  // multi-level mode (shared-weight head over the FPN pyramid): rows [lv_off[l], lv_off[l+1]) form an lv_h[l] x lv_w[l] image
+  int nlv;
+  int lv_off[6], lv_h[5], lv_w[5];
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
   p.y[oidx] = v;
 }
 
-template <int BM, int BN, bool TAP4>
+template <int BM, int BN, bool TAP4, bool MULTI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int LS = 36;  // LDS row stride in floats
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -107,21 +110,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   const int lr = tid >> 3, lq = tid & 7;
   int a_off[AR], a_iy[AR], a_ix[AR];
+  int a_h[MULTI ? AR : 1], a_w[MULTI ? AR : 1];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + lr + 32 * i;
     if (m < M) {
-      const int ox = m % p.OW;
-      const int t2 = m / p.OW;
-      const int oy = t2 % p.OH;
-      const int img = t2 / p.OH;
-      a_iy[i] = oy * p.stride - p.pad;
-      a_ix[i] = ox * p.stride - p.pad;
-      a_off[i] = img * p.H * p.W;
+      if (MULTI) {
+        int l = 0;
+        while (l + 1 < p.nlv && m >= p.lv_off[l + 1]) ++l;
+        const int local = m - p.lv_off[l];
+        const int w = p.lv_w[l];
+        const int oy = local / w;
+        a_iy[i] = oy - p.pad;
+        a_ix[i] = (local - oy * w) - p.pad;
+        a_off[i] = p.lv_off[l];
+        a_h[i] = p.lv_h[l];
+        a_w[i] = w;
+      } else {
+        const int ox = m % p.OW;
+        const int t2 = m / p.OW;
+        const int oy = t2 % p.OH;
+        const int img = t2 / p.OH;
+        a_iy[i] = oy * p.stride - p.pad;
+        a_ix[i] = ox * p.stride - p.pad;
+        a_off[i] = img * p.H * p.W;
+      }
     } else {
       a_iy[i] = -(1 << 28);
       a_ix[i] = 0;
       a_off[i] = 0;
+      if (MULTI) {
+        a_h[i] = 1;
+        a_w[i] = 1;
+      }
     }
   }
   const float* wrow[BR];
@@ -144,9 +165,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-        const bool ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+        const int hh = MULTI ? a_h[i] : p.H, ww = MULTI ? a_w[i] : p.W;
+        const bool ok = ((unsigned)iy < (unsigned)hh) && ((unsigned)ix < (unsigned)ww);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * p.W + ix) * p.Cin + c0 + 4 * lq);
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * ww + ix) * p.Cin + c0 + 4 * lq);
         ar[i] = v;
       }
     } else {
@@ -294,9 +316,12 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks) {
   return pl;
 }
 
+int total_rows(const EodConvDesc* d) { return d->levels > 0 ? d->level_off[d->levels] : d->N * d->OH * d->OW; }
+
 int check_desc(const EodConvDesc* d) {
   if (!d || !d->x || !d->w || !d->y) return EOD_ERR_NULL;
-  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->levels <= 0 && (d->H <= 0 || d->W <= 0 || d->OH <= 0 || d->OW <= 0)) return EOD_ERR_BAD_DIMS;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return EOD_ERR_BAD_DIMS;
   if (d->Kpad % 32 != 0 || d->Kpad < d->KH * d->KW * d->Cin) return EOD_ERR_BAD_DIMS;
   if (d->tap4) {
@@ -304,10 +329,20 @@ int check_desc(const EodConvDesc* d) {
   } else {
     if (d->Cin % 32 != 0 || d->Kpad != d->KH * d->KW * d->Cin) return EOD_ERR_BAD_DIMS;
   }
-  if (d->OH != (d->H + 2 * d->pad - d->KH) / d->stride + 1) return EOD_ERR_BAD_DIMS;
-  if (d->OW != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return EOD_ERR_BAD_DIMS;
-  if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return EOD_ERR_BAD_DIMS;
-  if ((long)d->N * d->OH * d->OW * d->Cout >= (1L << 31)) return EOD_ERR_BAD_DIMS;
+  if (d->levels > 0) {
+    // pyramid mode: stride-1 'same' conv over up to 5 level images stored back to back
+    if (d->levels > 5 || d->N != 1 || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2 || d->tap4 || d->out_mode != 0 ||
+        d->res_mode == 2 || d->level_off[0] != 0)
+      return EOD_ERR_BAD_DIMS;
+    for (int l = 0; l < d->levels; ++l)
+      if (d->level_h[l] <= 0 || d->level_w[l] <= 0 || d->level_off[l + 1] - d->level_off[l] != d->level_h[l] * d->level_w[l])
+        return EOD_ERR_BAD_DIMS;
+  } else {
+    if (d->OH != (d->H + 2 * d->pad - d->KH) / d->stride + 1) return EOD_ERR_BAD_DIMS;
+    if (d->OW != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return EOD_ERR_BAD_DIMS;
+  }
+  if (d->levels <= 0 && (long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return EOD_ERR_BAD_DIMS;
+  if ((long)total_rows(d) * (d->Cout > d->Cin ? d->Cout : d->Cin) >= (1L << 31)) return EOD_ERR_BAD_DIMS;
   if (d->out_mode == 1 && (d->Cout % 4 != 0)) return EOD_ERR_BAD_DIMS;
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
@@ -319,16 +354,18 @@ int check_desc(const EodConvDesc* d) {
 template <int BM, int BN>
 void launch_tile(const ConvArgs& a, bool tap4, dim3 grid, hipStream_t s) {
   if (tap4)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a);
+  else if (a.nlv > 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
 
 extern "C" size_t eod_conv2d_workspace_bytes(const EodConvDesc* d) {
   if (check_desc(d) != EOD_OK) return 0;
-  const int M = d->N * d->OH * d->OW;
+  const int M = total_rows(d);
   const int nchunks = d->Kpad / 32;
   const Plan pl = make_plan(d, M, nchunks);
   if (pl.splitk <= 1) return 0;
@@ -345,7 +382,14 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.m_count = d->m_count; a.m_unit = d->m_unit;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
-  a.M = d->N * d->OH * d->OW;
+  a.M = total_rows(d);
+  a.nlv = d->levels > 0 ? d->levels : 0;
+  for (int l = 0; l < a.nlv; ++l) {
+    a.lv_off[l] = d->level_off[l];
+    a.lv_h[l] = d->level_h[l];
+    a.lv_w[l] = d->level_w[l];
+  }
+  if (a.nlv) a.lv_off[a.nlv] = d->level_off[a.nlv];
   a.nchunks = d->Kpad / 32;
   a.relu = d->relu; a.res_mode = d->res_mode; a.in_relu = d->in_relu; a.out_mode = d->out_mode;
   a.out_scale = d->out_scale;

@@ -622,3 +622,80 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
                      d->obs);
   return eod_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------
+// a20: explicit semantic map from the implicit memory (custom_rcnn.py:745-756, 938-1017); evaluated lazily
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+// one wave per cell: label = argmax_c<C of (temp * mem/|mem|) . zs[:,c] (softmax is monotonic), intensity = mean|mem| (/obs if obs>1)
+__global__ __launch_bounds__(256) void semmap_cell_kernel(const float* __restrict__ mem, const float* __restrict__ obs,
+                                                           const float* __restrict__ zs, int n_cells, int D, int C1,
+                                                           float* __restrict__ intensity, int* __restrict__ labels,
+                                                           unsigned* __restrict__ minmax) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int cell = blockIdx.x * wpb + (threadIdx.x >> 6); cell < n_cells; cell += gridDim.x * wpb) {
+    float x[8];
+    float ss = 0.f, sa = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      x[q] = mem[(size_t)cell * D + q * 64 + lane];
+      ss += x[q] * x[q];
+      sa += fabsf(x[q]);
+    }
+    ss = wave_reduce_sum(ss);
+    sa = wave_reduce_sum(sa);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    float best = -INFINITY;
+    int besti = 0;
+    for (int c = 0; c < C1 - 1; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += (50.0f * (x[q] / denom)) * zs[(size_t)(q * 64 + lane) * C1 + c];
+      s = wave_reduce_sum(s);
+      if (s > best) {
+        best = s;
+        besti = c;
+      }
+    }
+    if (lane == 0) {
+      float inten = sa / (float)D;
+      const float o = obs[cell];
+      if (o > 1.0f) inten = inten / o;
+      intensity[cell] = inten;
+      labels[cell] = besti;
+      // non-negative floats order like their bit patterns
+      atomicMin(minmax + 0, __float_as_uint(inten));
+      atomicMax(minmax + 1, __float_as_uint(inten));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void semmap_threshold_kernel(const float* __restrict__ intensity, const unsigned* __restrict__ minmax,
+                                                                int n_cells, float thresh, int* __restrict__ labels) {
+  const float lo = __uint_as_float(minmax[0]), hi = __uint_as_float(minmax[1]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += gridDim.x * blockDim.x) {
+    const float v = (intensity[i] - lo) / (hi - lo);   // NaN when hi == lo: nothing is thresholded (reference quirk, :751)
+    if (v < thresh) labels[i] = -1;
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_semmap_labels(const float* mem, const float* obs, const float* zs, int n_cells, int D, int C1, float thresh,
+                                 int32_t* labels, float* workspace, eod_stream_t stream) {
+  if (!mem || !obs || !zs || !labels || !workspace) return EOD_ERR_NULL;
+  if (n_cells <= 0 || D != 512 || C1 < 2) return EOD_ERR_BAD_DIMS;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* minmax = reinterpret_cast<unsigned*>(workspace);
+  float* intensity = workspace + 4;
+  static const unsigned init[2] = {0x7F800000u, 0u};   // +inf, 0 (static: outlives the async copy)
+  if (hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return EOD_ERR_LAUNCH;
+  int blocks = (n_cells + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(semmap_cell_kernel, dim3(blocks), dim3(256), 0, s, mem, obs, zs, n_cells, D, C1, intensity, labels, minmax);
+  hipLaunchKernelGGL(semmap_threshold_kernel, dim3((n_cells + 255) / 256 > 1024 ? 1024 : (n_cells + 255) / 256), dim3(256), 0, s, intensity,
+                     minmax, n_cells, thresh, labels);
+  return eod_launch_status();
+}

@@ -60,8 +60,8 @@ class CenterNet:
         return self._plans[key]
 
     def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int):
-        for l, (h, w) in enumerate(shapes):
-            conv(src[off[l]:off[l + 1]], 1, h, w, out=dst[off[l]:off[l + 1]].view(1, h, w, cout))
+        # one launch over the whole pyramid (weights are shared across levels, centernet_head.py:144-160)
+        conv(src, 1, 0, 0, out=dst, levels=(off, shapes))
 
     def forward(self, feats: torch.Tensor, shapes, off):
         """feats [P_total,256] -> (boxes [cap,4], scores [cap], count [1]) device buffers, sorted by score."""

@@ -227,6 +227,12 @@ class CustomRCNNRecurrent:
         inst.pred_masks = P["masks"][:n].to(torch.bool)
         return inst
 
+    def semantic_map(self) -> torch.Tensor:
+        """a20, evaluated lazily: the explicit map `self.semmap` the reference recomputes (and syncs to the host) every
+        frame (custom_rcnn.py:756) but only consumes when MODEL.TEST_SAVE_SEMMAP dumps it (518-530)."""
+        self.semmap = ops.semmap_labels(self.implicit_memory, self.observations, self.zs_weight, self.obs_score_thresh)
+        return self.semmap
+
     # ---- introspection used by tests / bench -----------------------------------------------------------
     def proposals_snapshot(self):
         dec = self.proposal_generator._plans[next(iter(self.proposal_generator._plans))][3]

@@ -104,9 +104,13 @@ class Conv:
 
     def __call__(self, x: torch.Tensor, N: int, H: int, W: int, *, res: Optional[torch.Tensor] = None, res_mode: int = 0,
                  relu: bool = False, in_relu: bool = False, out_scale: float = 1.0, m_count: Optional[torch.Tensor] = None,
-                 m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0) -> torch.Tensor:
+                 m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0,
+                 levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None) -> torch.Tensor:
+        """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list."""
         _need_cuda(x, res, out)
-        OH, OW = self.out_hw(H, W)
+        OH, OW = self.out_hw(H, W) if levels is None else (0, 0)
+        if levels is not None and out is None:
+            out = torch.empty((levels[0][-1], self.Cout), dtype=torch.float32, device=x.device)
         if out is None:
             if self.out_mode == 1:
                 out = torch.empty((N, 2 * OH, 2 * OW, self.Cout // 4), dtype=torch.float32, device=x.device)
@@ -119,6 +123,15 @@ class Conv:
         d.KH, d.KW, d.stride, d.pad, d.Kpad = self.KH, self.KW, self.stride, self.pad, self.Kpad
         d.relu, d.res_mode, d.in_relu, d.out_mode, d.tap4 = int(relu), res_mode, int(in_relu), self.out_mode, self.tap4
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
+        if levels is not None:
+            off, shapes = levels
+            d.levels = len(shapes)
+            for i, o in enumerate(off):
+                d.level_off[i] = o
+            for i, (h, w) in enumerate(shapes):
+                d.level_h[i], d.level_w[i] = h, w
+        else:
+            d.levels = 0
         d.workspace, d.workspace_bytes = None, 0
         need = self._lib.eod_conv2d_workspace_bytes(C.byref(d))
         if need:
@@ -350,3 +363,13 @@ class MemoryWriter:
         d.det_rows, d.det_count, d.proj, d.mem, d.obs = det_rows.data_ptr(), det_count.data_ptr(), proj.data_ptr(), mem.data_ptr(), obs.data_ptr()
         check(self.lib.eod_memory_write(C.byref(d), _stream()), "eod_memory_write")
         return self.k_out
+
+
+def semmap_labels(mem: torch.Tensor, obs: torch.Tensor, zs: torch.Tensor, thresh: float) -> torch.Tensor:
+    """a20 (custom_rcnn.py:745-756,938-1017): int32 [N] labels, -1 below the observation-intensity threshold."""
+    N, D = mem.shape
+    labels = torch.empty((N,), dtype=torch.int32, device=mem.device)
+    ws = torch.empty((N + 4,), dtype=torch.float32, device=mem.device)
+    check(_lib.load().eod_semmap_labels(mem.data_ptr(), obs.data_ptr(), zs.data_ptr(), N, D, zs.shape[1], thresh, labels.data_ptr(),
+                                        ws.data_ptr(), _stream()), "eod_semmap_labels")
+    return labels

@@ -61,6 +61,12 @@ typedef struct EodConvDesc {
   int32_t force_tile; /* 0 auto, else 1=128x128 2=128x64 3=64x64 (benchmarks/tests) */
   int32_t force_splitk; /* 0 auto */
   float out_scale;
+  /* pyramid mode (levels > 0): x / y are [level_off[levels], C] row lists, level l is a level_h[l] x level_w[l] image;
+   * stride-1 'same' convolution with weights shared across levels (CenterNetHead, centernet_head.py:141-161). N must be 1. */
+  int32_t levels;
+  int32_t level_off[6];
+  int32_t level_h[5];
+  int32_t level_w[5];
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
@@ -187,6 +193,12 @@ int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream);
 /* zero the per-frame cell flags inside the workspace once after allocation (eod_memory_write leaves them zero) */
 int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int R_cap,
                           eod_stream_t stream);
+
+/* a20: explicit semantic map from the implicit memory (custom_rcnn.py:745-756,938-1017), evaluated lazily (only
+ * consumed when TEST_SAVE_SEMMAP): labels[c] = argmax over the first C1-1 classes of (50*mem/|mem|)@zs, or -1 where the
+ * min-max normalised observation intensity mean|mem| (/obs if obs>1) is below thresh.  workspace >= n_cells + 4 floats. */
+int eod_semmap_labels(const float* mem, const float* obs, const float* zs, int n_cells, int D, int C1, float thresh,
+                      int32_t* labels, float* workspace, eod_stream_t stream);
 
 /* utility */
 int eod_fill_f32(float* p, float v, size_t n, eod_stream_t stream);

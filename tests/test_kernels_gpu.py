@@ -444,3 +444,39 @@ def test_memory_write_matches_oracle(dev, K, thresh):
         touched = (mem_d.cpu() != mem0).any(dim=1)
         assert torch.equal(touched, touched_ref), "set of written cells must be bit-exact"
         close(mem_d, mem_ref, rtol=1e-5, atol=1e-4)
+
+
+def test_semmap_labels_match_oracle(dev):
+    from embodied_object_detection_amd import ops
+    from embodied_object_detection_amd.checkpoint import load_zs_weight
+    g = torch.Generator().manual_seed(23)
+    N = 700
+    zs = load_zs_weight()
+    mem = torch.randn((N, 512), generator=g) * torch.rand((N, 1), generator=g) * 30
+    mem[::9] = 0                                   # never-written cells
+    obs = torch.randint(0, 5, (N,), generator=g).float()
+    ref = OM.semmap_labels(mem, obs, zs, 0.4)
+    got = ops.semmap_labels(mem.to(dev), obs.to(dev), zs.to(dev), 0.4).cpu()
+    agree = (got == ref).float().mean().item()
+    assert agree > 0.995, f"semantic-map labels agree on {agree:.4f} of the cells"
+    assert (got == -1).sum().item() > 0 and (got >= 0).sum().item() > 0
+
+
+@pytest.mark.parametrize("cout,splitk", [(256, 0), (5, 0), (64, 3)])
+def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk):
+    """One launch over the 5 FPN levels with shared weights == five per-level 'same' convolutions."""
+    from embodied_object_detection_amd import ops
+    hw = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]
+    Cin = 64
+    xs = [rnd(1, Cin, h, w, seed=50 + i) for i, (h, w) in enumerate(hw)]
+    w = rnd(cout, Cin, 3, 3, seed=60, scale=0.05)
+    b = rnd(cout, seed=61)
+    off = [0]
+    for h, ww in hw:
+        off.append(off[-1] + h * ww)
+    flat = torch.cat([nhwc(x).reshape(-1, Cin) for x in xs]).contiguous().to(dev)
+    conv = ops.Conv(w, b, pad=1, device=dev)
+    y = conv(flat, 1, 0, 0, relu=True, levels=(off, hw), force_splitk=splitk).cpu()
+    for i, x in enumerate(xs):
+        ref = F.relu(F.conv2d(x, w, b, padding=1))
+        close(y[off[i]:off[i + 1]], nhwc(ref).reshape(-1, cout))

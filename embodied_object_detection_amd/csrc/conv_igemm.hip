@@ -20,6 +20,7 @@
 // epilogue: deterministic, no atomics.
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -74,11 +75,14 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
   p.y[oidx] = v;
 }
 
-template <int BM, int BN, bool TAP4, bool MULTI>
+template <int BM, int BN, int BK, bool TAP4, bool MULTI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
-  constexpr int LS = 36;  // LDS row stride in floats
+  constexpr int LS = BK + 4;  // LDS row stride in floats (+4: conflict-free 16-lane groups of ds_read_b128)
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AR = BM / 32, BR = BN / 32;
+  constexpr int QPR = BK / 4;        // float4 per tile row
+  constexpr int RPP = 256 / QPR;     // tile rows staged per pass of the 256 threads
+  constexpr int AR = BM / RPP, BR = BN / RPP;
+  static_assert(!TAP4 || BK == 32, "the stem path stages one 7x7 tap per float4: BK must be 32");
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LS];
   float* As = lds;
   float* Bs = lds + BM * LS;
@@ -108,12 +112,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   int c_end = c_begin + p.cps;
   if (c_end > p.nchunks) c_end = p.nchunks;
 
-  const int lr = tid >> 3, lq = tid & 7;
+  const int lr = tid / QPR, lq = tid % QPR;
   int a_off[AR], a_iy[AR], a_ix[AR];
   int a_h[MULTI ? AR : 1], a_w[MULTI ? AR : 1];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int m = m0 + lr + 32 * i;
+    const int m = m0 + lr + RPP * i;
     if (m < M) {
       if (MULTI) {
         int l = 0;
@@ -149,14 +153,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   bool wvalid[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
-    const int n = n0 + lr + 32 * j;
+    const int n = n0 + lr + RPP * j;
     wvalid[j] = n < p.Cout;
     wrow[j] = p.w + (size_t)(wvalid[j] ? n : 0) * p.Kpad + 4 * lq;
   }
 
   f32x4 ar[AR], br[BR];
   auto load_chunk = [&](int chunk) {
-    const int k0 = chunk * 32;
+    const int k0 = chunk * BK;
     if (!TAP4) {
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
@@ -218,13 +222,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   load_chunk(c_begin);
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + 32 * i) * LS + 4 * lq) = ar[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + RPP * i) * LS + 4 * lq) = ar[i];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + 32 * j) * LS + 4 * lq) = br[j];
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + RPP * j) * LS + 4 * lq) = br[j];
     __syncthreads();
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
@@ -282,19 +286,34 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
+inline int default_bk() {
+  static const int v = [] {
+    const char* e = getenv("EOD_CONV_BK");
+    return (e && atoi(e) == 32) ? 32 : 64;   // measured: BK=64 (half the barriers) +16 % on the mask GEMM
+  }();
+  return v;
+}
+
 struct Plan {
   int tile;  // 1=128x128 2=128x64 3=64x64
-  int bm, bn, tiles_m, tiles_n, splitk, cps;
+  int bk;    // K chunk staged per barrier pair: 32 or 64
+  int bm, bn, tiles_m, tiles_n, splitk, cps, nchunks;
 };
 
-Plan make_plan(const EodConvDesc* d, int M, int nchunks) {
+Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   static const int cfg[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   Plan pl{};
   // Measured on MI355X (tools/conv_bench.py, profiles/r01_conv_bench.log): the 64x64 tile (7 waves/SIMD, finest
   // tile quantisation over 256 CUs) is the fastest or ties on every shape of this path, including the
   // 50k x 256 x 2304 mask-head GEMM (107 vs 92 TFLOP/s for 128x128).  The larger tiles stay selectable.
   int pick = 2;
-  if (d->force_tile >= 1 && d->force_tile <= 3) pick = d->force_tile - 1;
+  const int ft = d->force_tile % 10, fbk = d->force_tile / 10;   // force_tile = tile + 10 (BK 32) / + 20 (BK 64)
+  if (ft >= 1 && ft <= 3) pick = ft - 1;
+  const bool bk64_ok = !d->tap4 && d->Cin % 64 == 0 && d->Kpad % 64 == 0;
+  pl.bk = (fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32));
+  const int nchunks = d->Kpad / pl.bk;
+  (void)nchunks32;
+  pl.nchunks = nchunks;
   pl.tile = pick + 1;
   pl.bm = cfg[pick][0];
   pl.bn = cfg[pick][1];
@@ -352,13 +371,17 @@ int check_desc(const EodConvDesc* d) {
 }
 
 template <int BM, int BN>
-void launch_tile(const ConvArgs& a, bool tap4, dim3 grid, hipStream_t s) {
+void launch_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s) {
   if (tap4)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), 0, s, a);
+  else if (a.nlv > 0 && bk == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), 0, s, a);
   else if (a.nlv > 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), 0, s, a);
+  else if (bk == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -390,10 +413,10 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     a.lv_w[l] = d->level_w[l];
   }
   if (a.nlv) a.lv_off[a.nlv] = d->level_off[a.nlv];
-  a.nchunks = d->Kpad / 32;
   a.relu = d->relu; a.res_mode = d->res_mode; a.in_relu = d->in_relu; a.out_mode = d->out_mode;
   a.out_scale = d->out_scale;
-  const Plan pl = make_plan(d, a.M, a.nchunks);
+  const Plan pl = make_plan(d, a.M, d->Kpad / 32);
+  a.nchunks = pl.nchunks;
   a.splitk = pl.splitk; a.cps = pl.cps; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
@@ -401,9 +424,9 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
   switch (pl.tile) {
-    case 1: launch_tile<128, 128>(a, d->tap4 != 0, grid, s); break;
-    case 2: launch_tile<128, 64>(a, d->tap4 != 0, grid, s); break;
-    default: launch_tile<64, 64>(a, d->tap4 != 0, grid, s); break;
+    case 1: launch_tile<128, 128>(a, d->tap4 != 0, pl.bk, grid, s); break;
+    case 2: launch_tile<128, 64>(a, d->tap4 != 0, pl.bk, grid, s); break;
+    default: launch_tile<64, 64>(a, d->tap4 != 0, pl.bk, grid, s); break;
   }
   if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;

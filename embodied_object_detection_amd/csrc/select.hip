@@ -14,6 +14,7 @@
 // in registers of one wave and stops as soon as the requested number of boxes has been kept.
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
+#include <algorithm>
 
 namespace {
 
@@ -75,8 +76,7 @@ __device__ void block_sort_desc_reg(u64 (&v)[E], u64* xch) {
           }
           const bool desc = ((base_i + e) & k) == 0;
           const u64 a = v[e];
-          const u64 mx = a > b ? a : b, mn = a > b ? b : a;
-          v[e] = (lower == desc) ? mx : mn;
+          v[e] = ((a > b) == (lower == desc)) ? a : b;   // keep the max iff (lower == desc); equal keys: either
         }
         if (tj >= 64) __syncthreads();
       }
@@ -93,7 +93,8 @@ __device__ __forceinline__ int next_pow2(int n) {
 // ------------------------------------------------------------------------------------------------------
 // NMS on a score-sorted list
 // ------------------------------------------------------------------------------------------------------
-// mask[i*nb + bj] bit t: box (bj*64+t) is suppressed by box i (j > i, same label, IoU > thr)
+// Suppression matrix, stored TRANSPOSED: maskT[bj*(nb*64) + i] bit t: box (bj*64+t) is suppressed by box i (j > i, same
+// label, IoU > thr).  Word bj of 64 consecutive rows is then 512 contiguous bytes, which is what the scan reads.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ labels,
                                                        const int* __restrict__ n_ptr, int nb, float thr, u64* __restrict__ mask) {
   const int n = *n_ptr;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     const float iou = inter / (area_i + area_j - inter);
     if (iou > thr) bits |= (1ull << c);
   }
-  mask[(size_t)i * nb + bj] = bits;
+  mask[(size_t)bj * (nb * 64) + i] = bits;
 }
 
 struct ScanOut {
@@ -162,13 +163,18 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__
   __syncthreads();
   const int nchunk = (n + 63) >> 6;
   float kth = -1.0f;
+  // the diagonal block of chunk c+1 does not depend on the scan state: fetch it one chunk ahead
+  u64 diag_next = 0;
+  if (tid < 64 && tid < n) diag_next = mask[(size_t)tid];
   for (int c = 0; c < nchunk; ++c) {
     if (tid == c) sh_removed = removed;
     __syncthreads();
     if (tid < 64) {
-      const int row = c * 64 + tid;
-      u64 diag = 0;
-      if (row < n) diag = mask[(size_t)row * nb + c];
+      const u64 diag = diag_next;
+      {
+        const int nrow = (c + 1) * 64 + tid;
+        diag_next = (c + 1 < nchunk && nrow < n) ? mask[(size_t)(c + 1) * (nb * 64) + nrow] : 0ull;
+      }
       u64 cur = sh_removed;
       u64 kept = 0;
       const int lim = min(64, n - c * 64);
@@ -180,6 +186,20 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__
           cur |= ((u64)hi << 32) | lo;
         }
       }
+      const int total0 = sh_total;
+      const int nk = __popcll(kept);
+      if (total0 + nk < max_keep) {
+        // fast path (every chunk but the last one): all lanes append their kept index in parallel
+        if ((kept >> tid) & 1ull) {
+          const int pos = total0 + __popcll(kept & ((1ull << tid) - 1ull));
+          if (pos < o.cap) keep_idx[pos] = c * 64 + tid;
+        }
+        if (tid == 0) {
+          sh_total = total0 + nk;
+          sh_kept = kept;
+          sh_stop = 0;
+        }
+      } else
       if (tid == 0) {
         // append kept indices, honouring max_keep / ties
         int total = sh_total;
@@ -216,11 +236,16 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__
     if (sh_stop) break;
     const u64 kept = sh_kept;
     if (tid > c && tid < nb) {
-      u64 k = kept;
-      while (k) {
-        const int i = __ffsll((long long)k) - 1;
-        k &= k - 1;
-        removed |= mask[(size_t)(c * 64 + i) * nb + tid];
+      // word `tid` of the chunk's 64 rows: 512 contiguous bytes, loaded unconditionally as 32 independent 16-byte loads
+      // (all in flight together) and masked by the kept bits -- no dependent load chain.
+      const ulonglong2* col = reinterpret_cast<const ulonglong2*>(mask + (size_t)tid * (nb * 64) + c * 64);
+      ulonglong2 v[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = col[q];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        if ((kept >> (2 * q)) & 1ull) removed |= v[q].x;
+        if ((kept >> (2 * q + 1)) & 1ull) removed |= v[q].y;
       }
     }
     __syncthreads();
@@ -262,10 +287,10 @@ struct CnArgs {
 
 #define EOD_SORT_MAX 16384
 
-// one block per level: per-level top-k by score
+// one block per level: per-level top-k by score (E = 8: levels up to 8192 positions, E = 16: up to 16384)
+template <int E>
 __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
-  constexpr int E = EOD_SORT_MAX / 1024;
-  __shared__ u64 xch[EOD_SORT_MAX];
+  __shared__ u64 xch[1024 * E];
   __shared__ int sh_cnt;
   const int level = blockIdx.x;
   const int r0 = p.level_off[level];
@@ -308,9 +333,9 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
   if (threadIdx.x == 0) p.cand_cnt[level] = take;
 }
 
-// single block: merge the per-level lists, sort by sqrt-score, decode boxes
+// single block: merge the per-level lists, sort by sqrt-score, decode boxes (E*1024 >= levels*topk slots)
+template <int E>
 __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_sorted) {
-  constexpr int E = 8;
   __shared__ u64 xch[1024 * E];
   const int total_slots = p.levels * p.topk;
   u64 v[E];
@@ -366,6 +391,7 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
   constexpr int E = 8;
   __shared__ u64 xch[1024 * E];
   __shared__ int sh_cnt;
+  __shared__ unsigned char row_ok[1024];
   int R = R_cap;
   if (count) {
     const int c = *count;
@@ -374,6 +400,15 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
   const int C = C1 - 1;
   const int slots = R_cap * C;
   if (threadIdx.x == 0) sh_cnt = 0;
+  // a row takes part only if its box and ALL its scores are finite (d2 fast_rcnn_inference drops the others)
+  for (int r = threadIdx.x; r < R_cap; r += blockDim.x) {
+    bool fin = r < R;
+    if (fin) {
+      for (int q = 0; q < 4; ++q) fin = fin & (bool)isfinite(boxes[r * 4 + q]);
+      for (int q = 0; q < C1; ++q) fin = fin & (bool)isfinite(scores[r * C1 + q]);
+    }
+    row_ok[r] = fin ? 1 : 0;
+  }
   __syncthreads();
   u64 v[E];
   int local = 0;
@@ -383,12 +418,9 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
     u64 k = 0;
     if (i < slots) {
       const int r = i / C, c = i - r * C;
-      if (r < R) {
-        bool fin = true;
-        for (int q = 0; q < 4; ++q) fin = fin && isfinite(boxes[r * 4 + q]);
-        for (int q = 0; q < C1 && fin; ++q) fin = fin && isfinite(scores[r * C1 + q]);
+      if (row_ok[r]) {
         const float s = scores[r * C1 + c];
-        if (fin && s > thr) {
+        if (s > thr) {
           k = make_key(s, (unsigned)i);
           ++local;
         }
@@ -486,8 +518,17 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
     a.level_scale[l] = d->level_scale[l];
   }
   a.score_thresh = d->score_thresh; a.topk = d->pre_nms_topk; a.cand_keys = w.cand_keys; a.cand_cnt = w.cand_cnt;
-  hipLaunchKernelGGL(cn_level_topk_kernel, dim3(d->levels), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(cn_merge_decode_kernel, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
+  int max_level = 0;
+  for (int l = 0; l < d->levels; ++l) max_level = std::max(max_level, d->level_off[l + 1] - d->level_off[l]);
+  if (max_level <= 8192)
+    hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels), dim3(1024), 0, s, a);
+  // the per-level lists are packed level-major without holes only up to min(level size, topk) entries each
+  int packed = 0;
+  for (int l = 0; l < d->levels; ++l) packed += std::min(d->level_off[l + 1] - d->level_off[l], d->pre_nms_topk);
+  (void)packed;
+  hipLaunchKernelGGL(cn_merge_decode_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
   const int nb = (slots + 63) / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, s, w.sorted_boxes, (const int*)nullptr, w.n_sorted, nb, d->nms_thresh,
                      w.mask);
@@ -506,7 +547,7 @@ extern "C" int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream)
   if (!d || !d->boxes || !d->scores || !d->out_boxes || !d->out_scores || !d->out_classes || !d->out_rows || !d->out_count ||
       !d->workspace)
     return EOD_ERR_NULL;
-  if (d->R_cap <= 0 || d->C1 < 2 || d->topk <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->R_cap <= 0 || d->R_cap > 1024 || d->C1 < 2 || d->topk <= 0) return EOD_ERR_BAD_DIMS;
   const int slots = d->R_cap * (d->C1 - 1);
   if (slots > 8192) return EOD_ERR_CAPACITY;
   const SelWs w = carve(d->workspace, slots, slots, 0);

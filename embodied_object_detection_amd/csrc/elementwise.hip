@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restr
 // one wave per row: dot(x[row,:], w) + b -> sigmoid
 __global__ __launch_bounds__(256) void mask_predictor_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
                                                               float* __restrict__ prob, int rows, int C,
-                                                              const int* __restrict__ unit_count, int unit_rows) {
+                                                              const int* __restrict__ unit_count, int unit_rows,
+                                                              const int* __restrict__ out_units) {
   int R = rows;
   if (unit_count) {
     const int lim = *unit_count * unit_rows;
@@ -171,7 +172,14 @@ __global__ __launch_bounds__(256) void mask_predictor_kernel(const float* __rest
       s += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
     }
     s = wave_reduce_sum(s);
-    if (lane == 0) prob[row] = eod_sigmoid_precise(s + bias);
+    if (lane == 0) {
+      int orow = row;
+      if (out_units) {   // scatter: unit u of the compact input list is unit out_units[u] of the output
+        const int u = row / unit_rows;
+        orow = out_units[u] * unit_rows + (row - u * unit_rows);
+      }
+      prob[orow] = eod_sigmoid_precise(s + bias);
+    }
   }
 }
 
@@ -243,11 +251,11 @@ extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, 
 }
 
 extern "C" int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,
-                                          const int32_t* unit_count, int unit_rows, eod_stream_t stream) {
+                                          const int32_t* unit_count, int unit_rows, const int32_t* out_units, eod_stream_t stream) {
   if (!x || !w || !prob) return EOD_ERR_NULL;
-  if (rows <= 0 || C % 4 != 0) return EOD_ERR_BAD_DIMS;
+  if (rows <= 0 || C % 4 != 0 || (out_units && unit_rows <= 0)) return EOD_ERR_BAD_DIMS;
   hipLaunchKernelGGL(mask_predictor_kernel, dim3(grid_for((size_t)rows, 4, 8192)), dim3(256), 0, (hipStream_t)stream, x, w, bias, prob,
-                     rows, C, unit_count, unit_rows);
+                     rows, C, unit_count, unit_rows, out_units);
   return eod_launch_status();
 }
 

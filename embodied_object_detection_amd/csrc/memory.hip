@@ -593,6 +593,15 @@ extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, in
   return eod_launch_status();
 }
 
+extern "C" int eod_unique_rows(const int32_t* rows, const int32_t* count, int K_cap, int R_cap, int32_t* out_rows, int32_t* out_count,
+                               eod_stream_t stream) {
+  if (!rows || !count || !out_rows || !out_count) return EOD_ERR_NULL;
+  if (K_cap <= 0 || R_cap <= 0 || R_cap > 512) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, rows, count, K_cap, R_cap, out_rows, out_count,
+                     (int*)nullptr);
+  return eod_launch_status();
+}
+
 extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   if (!d || !d->featn || !d->prop_boxes || !d->prop_masks || !d->det_rows || !d->det_count || !d->proj || !d->mem || !d->obs ||
       !d->workspace)

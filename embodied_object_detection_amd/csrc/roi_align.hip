@@ -17,6 +17,7 @@ struct RoiArgs {
   float scale[3];
   int C;
   const float* boxes;
+  const int* box_rows;  // optional gather: ROI r pools box box_rows[r]
   const int* count;
   int R_cap;
   int S;
@@ -37,7 +38,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
     const int r = (int)(wid / bins);
     const int b = (int)(wid - (long)r * bins);
     const int ph = b / p.S, pw = b - ph * p.S;
-    const float bx1 = p.boxes[r * 4 + 0], by1 = p.boxes[r * 4 + 1], bx2 = p.boxes[r * 4 + 2], by2 = p.boxes[r * 4 + 3];
+    const int br = p.box_rows ? p.box_rows[r] : r;
+    const float bx1 = p.boxes[br * 4 + 0], by1 = p.boxes[br * 4 + 1], bx2 = p.boxes[br * 4 + 2], by2 = p.boxes[br * 4 + 3];
     // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [3,5]
     const float area = (bx2 - bx1) * (by2 - by1);
     float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
 }  // namespace
 
 extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C, const float* boxes,
-                             const int32_t* count, int R_cap, int out_size, float* out, eod_stream_t stream) {
+                             const int32_t* box_rows, const int32_t* count, int R_cap, int out_size, float* out,
+                             eod_stream_t stream) {
   if (!p3 || !p4 || !p5 || !boxes || !out) return EOD_ERR_NULL;
   if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(p3) || !eod_aligned16(p4) || !eod_aligned16(p5) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
@@ -124,7 +127,7 @@ extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, 
   a.feat[0] = p3; a.feat[1] = p4; a.feat[2] = p5;
   a.h[0] = h3; a.w[0] = w3; a.h[1] = h3 / 2; a.w[1] = w3 / 2; a.h[2] = h3 / 4; a.w[2] = w3 / 4;
   a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
-  a.C = C; a.boxes = boxes; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
+  a.C = C; a.boxes = boxes; a.box_rows = box_rows; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
   const long waves = (long)R_cap * out_size * out_size;
   long blocks = (waves + 3) / 4;
   if (blocks > 8192) blocks = 8192;

@@ -53,6 +53,9 @@ class CustomRCNNRecurrent:
         # the memory write-back and the 256-proposal mask pass run for every MEMORY_TYPE in the reference
         # (custom_rcnn.py:515,573); keep that for like-for-like timing
         self.always_update_memory = True
+        # Opt-in: compute the proposal masks only for the proposals the memory update reads (identical results, ~2 ms less
+        # at 640x640).  Off by default so the default frame does the same work as the reference (a 256-proposal mask pass).
+        self.lazy_proposal_masks = False
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         if state_dict is None:
@@ -79,6 +82,8 @@ class CustomRCNNRecurrent:
         R = self.proposal_generator.cap
         self.mem_scores = torch.zeros((R, self.C1), dtype=torch.float32, device=self.device)
         self.mem_selector = ops.DetectionSelector(R, self.C1, 100, self.device)
+        self._uniq_rows = torch.zeros((R,), dtype=torch.int32, device=self.device)
+        self._uniq_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
         # recurrent state
         self.implicit_memory: Optional[torch.Tensor] = None   # [N,512] f32  (== semmap_features)
         self.observations: Optional[torch.Tensor] = None      # [N] f32      (== observation_count)
@@ -188,7 +193,16 @@ class CustomRCNNRecurrent:
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
             views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
-        prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
+        mem_sel = None
+        if self.lazy_proposal_masks and (self.memory_type == "implicit_memory" or self.always_update_memory):
+            # select the memory instances first, then run the mask head only on those proposals (same results: the other
+            # proposals' masks are never read, custom_rcnn.py:875-880)
+            mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+            ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
+            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
+                                                            rows_count=self._uniq_count)
+        else:
+            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
 
         # detector_postprocess (custom_rcnn.py:579-580)
         out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
@@ -202,19 +216,24 @@ class CustomRCNNRecurrent:
 
         # memory update (custom_rcnn.py:515)
         if self.memory_type == "implicit_memory" or self.always_update_memory:
-            self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W))
+            self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
         self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
         if not materialize:
             return None
         return {"instances": self._materialize((out_h, out_w))}
 
-    def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw):
+    def select_memory_instances(self, prop_boxes, prop_scores, prop_count, image_hw):
+        """`inference_with_proposals` up to the NMS (custom_rcnn.py:825-875): CLIP re-score of the proposals, threshold
+        MEMORY_CLS_SCORE_THRESH, per-class NMS 0.5, top 100 -> (proposal row of every kept detection, count)."""
         H, W = image_hw
         R = self.proposal_generator.cap
-        featn = self.roi_heads.featn0
-        ops.memory_scores(featn, self.zs_weight, prop_scores, self.mem_scores, prop_count, R, self.C1)
+        ops.memory_scores(self.roi_heads.featn0, self.zs_weight, prop_scores, self.mem_scores, prop_count, R, self.C1)
         _, _, _, rows, cnt = self.mem_selector(prop_boxes, self.mem_scores, prop_count, float(W), float(H), self.cls_score_thresh, 0.5)
-        self._writer(featn, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations)
+        return rows, cnt
+
+    def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw, mem_sel=None):
+        rows, cnt = mem_sel if mem_sel is not None else self.select_memory_instances(prop_boxes, prop_scores, prop_count, image_hw)
+        self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations)
 
     def _materialize(self, out_hw) -> Instances:
         """Slice the fixed-capacity device buffers by the detection count (the frame's only host sync)."""

@@ -111,15 +111,18 @@ class DeticCascadeROIHeads:
         return self.selector(boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
 
     # ---- mask head ----------------------------------------------------------------------------------
-    def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor):
+    def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor,
+                     rows: torch.Tensor = None):
+        """Mask head on `count` ROIs.  With `rows` (a compact ascending list of box indices) ROI k pools `boxes[rows[k]]` and its
+        28x28 mask is written to `out[rows[k]]`: only the listed boxes are computed, the output layout stays per-box."""
         h3, w3 = shapes[0]
-        ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=self.mpool)
+        ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=self.mpool, box_rows=rows)
         src, dst = self.mpool, self.mbuf
         for conv in self.mask_convs:
             conv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=dst)
             src, dst = dst, src
         self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=self.mup)
-        ops.mask_predictor_sigmoid(self.mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out)
+        ops.mask_predictor_sigmoid(self.mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out, out_units=rows)
         return out
 
     def forward(self, views, shapes, prop_boxes, prop_scores, prop_count, image_hw):
@@ -129,6 +132,11 @@ class DeticCascadeROIHeads:
         self.forward_mask(views, shapes, det_boxes, det_count, self.topk, self.det_masks)      # forward_with_given_boxes
         return det
 
-    def forward_mask_memory(self, views, shapes, prop_boxes, prop_count):
-        """`forward_mask_memory` + `mask_rcnn_inference` on ALL proposals (custom_rcnn.py:573-574)."""
+    def forward_mask_memory(self, views, shapes, prop_boxes, prop_count, rows: torch.Tensor = None, rows_count: torch.Tensor = None):
+        """`forward_mask_memory` + `mask_rcnn_inference` on ALL proposals (custom_rcnn.py:573-574).
+
+        `rows` / `rows_count`: lazy variant -- only the proposals the memory update will read (custom_rcnn.py:875-880) get a
+        mask; every other proposal's mask is dead in the reference (never read after `inference_with_proposals`)."""
+        if rows is not None:
+            return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows)
         return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks)

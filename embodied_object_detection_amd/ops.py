@@ -188,21 +188,26 @@ def groupnorm_relu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, lev
 
 
 def mask_predictor_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: float, rows: int, Cc: int, count: Optional[torch.Tensor],
-                           unit_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           unit_rows: int, out: Optional[torch.Tensor] = None, out_units: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:
         out = torch.empty((rows,), dtype=torch.float32, device=x.device)
     check(_lib.load().eod_mask_predictor_sigmoid(x.data_ptr(), w.data_ptr(), bias, out.data_ptr(), rows, Cc, _ptr(count),
-                                                 unit_rows, _stream()), "eod_mask_predictor_sigmoid")
+                                                 unit_rows, _ptr(out_units), _stream()), "eod_mask_predictor_sigmoid")
     return out
 
 
 def roi_align(p3, p4, p5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count: Optional[torch.Tensor], R_cap: int, S: int,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, box_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:
         out = torch.empty((R_cap, S, S, Cc), dtype=torch.float32, device=p3.device)
-    check(_lib.load().eod_roi_align(p3.data_ptr(), p4.data_ptr(), p5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(count), R_cap, S,
-                                    out.data_ptr(), _stream()), "eod_roi_align")
+    check(_lib.load().eod_roi_align(p3.data_ptr(), p4.data_ptr(), p5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(box_rows),
+                                    _ptr(count), R_cap, S, out.data_ptr(), _stream()), "eod_roi_align")
     return out
+
+
+def unique_rows(rows: torch.Tensor, count: torch.Tensor, K_cap: int, R_cap: int, out_rows: torch.Tensor, out_count: torch.Tensor):
+    check(_lib.load().eod_unique_rows(rows.data_ptr(), count.data_ptr(), K_cap, R_cap, out_rows.data_ptr(), out_count.data_ptr(),
+                                      _stream()), "eod_unique_rows")
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -87,12 +87,13 @@ int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float
 /* mask predictor 1x1 conv -> 1 channel + sigmoid (d2 mask head predictor + mask_rcnn_inference,
  * custom_rcnn.py:574): x [R*784,C] -> prob [R*784] */
 int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,
-                               const int32_t* unit_count, int unit_rows, eod_stream_t stream);
+                               const int32_t* unit_count, int unit_rows, const int32_t* out_units /* optional scatter of units */,
+                               eod_stream_t stream);
 
 /* ---- ROIAlignV2 over p3..p5 (d2 ROIPooler, detic_roi_heads.py:332,265) -------------------------------- */
 int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C,
-                  const float* boxes /*[R,4]*/, const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/,
-                  eod_stream_t stream);
+                  const float* boxes /*[R,4]*/, const int32_t* box_rows /* optional gather: ROI r pools boxes[box_rows[r]] */,
+                  const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/, eod_stream_t stream);
 
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
@@ -172,6 +173,9 @@ int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, 
 /* a16 scoring of proposals in CLIP space (custom_rcnn.py:848-855): scores = sqrt(sigmoid(featn@zs)*ps) */
 int eod_memory_scores(const float* featn /*[R,512]*/, const float* zs, const float* prop_scores, float* scores /*[R,C1]*/,
                       const int32_t* count, int R_cap, int D, int C1, eod_stream_t stream);
+/* torch.unique of the kept proposal rows (custom_rcnn.py:875): ascending, duplicates removed. R_cap <= 512. */
+int eod_unique_rows(const int32_t* rows, const int32_t* count, int K_cap, int R_cap, int32_t* out_rows, int32_t* out_count,
+                    eod_stream_t stream);
 /* a16-a19 write path (custom_rcnn.py:681-760,875-936) */
 typedef struct EodMemWriteDesc {
   const float* featn;       /* [R,512] normalised x50 proposal features */

@@ -199,3 +199,20 @@ def test_product_path_refuses_cpu(synthetic_sd):
     from embodied_object_detection_amd import _lib, build_model
     with pytest.raises(_lib.EodError):
         build_model(_cfg(**{"MODEL.DEVICE": "cpu"}), synthetic_sd)
+
+
+def test_lazy_proposal_masks_give_identical_results(setup):
+    """Computing the proposal masks only for the proposals the memory update reads must not change anything."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    outs = []
+    for lazy in (False, True):
+        model = build_model(_cfg(), sd)
+        model.lazy_proposal_masks = lazy
+        res = [model([[f]])[0]["instances"] for f in frames[:3]]
+        outs.append((res, model.implicit_memory.cpu().clone(), model.observations.cpu().clone()))
+    (ra, ma, oa), (rb, mb, ob) = outs
+    assert torch.equal(oa, ob) and torch.equal(ma, mb), "memory state must be bitwise identical"
+    for a, b in zip(ra, rb):
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+        assert torch.equal(a.pred_masks, b.pred_masks)

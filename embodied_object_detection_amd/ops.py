@@ -33,12 +33,16 @@ class Workspace:
     """Grow-only scratch buffer per device (split-K slabs, selection scratch)."""
 
     def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
-            self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        return self.buf
+        # one buffer per (device, stream): kernels of different streams may run concurrently
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 _conv_ws = Workspace()

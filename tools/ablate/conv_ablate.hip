@@ -18,7 +18,7 @@
 // remap so that the workgroups sharing an L2 walk neighbouring tiles (same weight panel / same pixel rows).
 // Small problems are split along K (grid.y) into fp32 slabs reduced by a second kernel that also applies the
 // epilogue: deterministic, no atomics.
-#include "eod_common.h"
+#include "../../embodied_object_detection_amd/csrc/eod_common.h"
 #include "../../include/eod_hip.h"
 #include <cstdlib>
 
@@ -41,7 +41,6 @@ struct ConvArgs {
   // multi-level mode (shared-weight head over the FPN pyramid): rows [lv_off[l], lv_off[l+1]) form an lv_h[l] x lv_w[l] image
   int nlv;
   int lv_off[6], lv_h[5], lv_w[5];
-  unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
@@ -114,70 +113,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   if (c_end > p.nchunks) c_end = p.nchunks;
 
   const int lr = tid / QPR, lq = tid % QPR;
-  // Operand addressing.  Both tiles are fetched with SRSRC buffer loads (32-bit byte offsets + hardware range check):
-  //  * every tile row gets ONE byte offset (its (ky,kx)=(0,0) tap position) and a bit mask of the taps that fall inside
-  //    the image, both computed once per workgroup; per chunk a load costs an add, a bit test and a select -- no
-  //    64-bit address arithmetic, no exec-mask branches; a masked-off / out-of-tile lane gets offset 0xFFFFFFFF, which
-  //    the range check turns into zeros (the conv's zero padding);
-  //  * a weight row's offset never changes: the K position goes into the scalar offset of the instruction.
-  int a_off[AR], a_iy[AR], a_ix[AR];        // TAP4 (stem) path only
-  unsigned a_voff[AR];
-  unsigned long long a_mask[AR];
-  unsigned a_pitch[MULTI ? AR : 1];
-  const int ntaps = p.KH * p.KW;
+  int a_off[AR], a_iy[AR], a_ix[AR];
+  int a_h[MULTI ? AR : 1], a_w[MULTI ? AR : 1];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + lr + RPP * i;
-    int iy0 = 0, ix0 = 0, off = 0, hh = 1, ww = 1;
-    const bool rowok = m < M;
-    if (rowok) {
+    if (m < M) {
       if (MULTI) {
         int l = 0;
         while (l + 1 < p.nlv && m >= p.lv_off[l + 1]) ++l;
         const int local = m - p.lv_off[l];
-        ww = p.lv_w[l];
-        hh = p.lv_h[l];
-        const int oy = local / ww;
-        iy0 = oy - p.pad;
-        ix0 = (local - oy * ww) - p.pad;
-        off = p.lv_off[l];
+        const int w = p.lv_w[l];
+        const int oy = local / w;
+        a_iy[i] = oy - p.pad;
+        a_ix[i] = (local - oy * w) - p.pad;
+        a_off[i] = p.lv_off[l];
+        a_h[i] = p.lv_h[l];
+        a_w[i] = w;
       } else {
         const int ox = m % p.OW;
         const int t2 = m / p.OW;
         const int oy = t2 % p.OH;
         const int img = t2 / p.OH;
-        iy0 = oy * p.stride - p.pad;
-        ix0 = ox * p.stride - p.pad;
-        off = img * p.H * p.W;
-        hh = p.H;
-        ww = p.W;
+        a_iy[i] = oy * p.stride - p.pad;
+        a_ix[i] = ox * p.stride - p.pad;
+        a_off[i] = img * p.H * p.W;
       }
-    }
-    a_iy[i] = rowok ? iy0 : -(1 << 28);
-    a_ix[i] = ix0;
-    a_off[i] = off;
-    if (!TAP4) {
-      unsigned long long mask = 0;
-      if (rowok) {
-        for (int tp = 0; tp < ntaps; ++tp) {
-          const int ky = tp / p.KW, kx = tp - ky * p.KW;
-          const bool ok = ((unsigned)(iy0 + ky) < (unsigned)hh) && ((unsigned)(ix0 + kx) < (unsigned)ww);
-          mask |= (unsigned long long)ok << tp;
-        }
+    } else {
+      a_iy[i] = -(1 << 28);
+      a_ix[i] = 0;
+      a_off[i] = 0;
+      if (MULTI) {
+        a_h[i] = 1;
+        a_w[i] = 1;
       }
-      a_mask[i] = mask;
-      a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);   // may wrap for padded taps: only used when the tap bit is set
-      if (MULTI) a_pitch[i] = (unsigned)(ww * p.Cin * 4);
     }
   }
-  unsigned w_voff[BR];
+  const float* wrow[BR];
+  bool wvalid[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
     const int n = n0 + lr + RPP * j;
-    w_voff[j] = n < p.Cout ? (unsigned)((n * p.Kpad + 4 * lq) * 4) : 0xFFFFFFFFu;
+    wvalid[j] = n < p.Cout;
+    wrow[j] = p.w + (size_t)(wvalid[j] ? n : 0) * p.Kpad + 4 * lq;
   }
-  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
   f32x4 ar[AR], br[BR];
   auto load_chunk = [&](int chunk) {
@@ -187,14 +166,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       const int c0 = k0 - tap * p.Cin;
       const int ky = tap / p.KW;
       const int kx = tap - ky * p.KW;
-      const unsigned tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ky * p.W + kx) * p.Cin + c0) * 4);
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        const bool ok = (a_mask[i] >> tap) & 1ull;
-        unsigned vo = a_voff[i] + tap_off;
-        if (MULTI) vo += (unsigned)ky * a_pitch[i];
-        vo = ok ? vo : 0xFFFFFFFFu;
-        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0));
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const int hh = MULTI ? a_h[i] : p.H, ww = MULTI ? a_w[i] : p.W;
+        const bool ok = ((unsigned)iy < (unsigned)hh) && ((unsigned)ix < (unsigned)ww);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * ww + ix) * p.Cin + c0 + 4 * lq);
+        ar[i] = v;
       }
     } else {
       const int tap = chunk * 8 + lq;
@@ -220,8 +199,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < BR; ++j)
-      br[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], k0 * 4, 0));
+    for (int j = 0; j < BR; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wvalid[j]) v = *reinterpret_cast<const f32x4*>(wrow[j] + k0);
+      br[j] = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -239,12 +221,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   load_chunk(c_begin);
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#ifdef ABL_NOLDSW
+    if (chunk == c_begin)
+#endif
 #pragma unroll
     for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + RPP * i) * LS + 4 * lq) = ar[i];
+#ifdef ABL_NOLDSW
+    if (chunk == c_begin)
+#endif
 #pragma unroll
     for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + RPP * j) * LS + 4 * lq) = br[j];
     __syncthreads();
+#ifndef ABL_NOGLOBAL
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];
@@ -260,7 +250,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
     }
+#ifndef ABL_NOBARRIER
     __syncthreads();
+#endif
   }
 
   const int half = lane >> 5;
@@ -378,10 +370,7 @@ int check_desc(const EodConvDesc* d) {
     if (d->OH != (d->H + 2 * d->pad - d->KH) / d->stride + 1) return EOD_ERR_BAD_DIMS;
     if (d->OW != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return EOD_ERR_BAD_DIMS;
   }
-  // operand buffers are addressed with 32-bit byte offsets (buffer descriptors): < 2 GiB each
-  if (d->levels <= 0 && (long)d->N * d->H * d->W * d->Cin >= (1L << 29)) return EOD_ERR_BAD_DIMS;
-  if ((long)d->Cout * d->Kpad >= (1L << 29)) return EOD_ERR_BAD_DIMS;
-  if (d->KH * d->KW > 64) return EOD_ERR_BAD_DIMS;
+  if (d->levels <= 0 && (long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return EOD_ERR_BAD_DIMS;
   if ((long)total_rows(d) * (d->Cout > d->Cin ? d->Cout : d->Cin) >= (1L << 31)) return EOD_ERR_BAD_DIMS;
   if (d->out_mode == 1 && (d->Cout % 4 != 0)) return EOD_ERR_BAD_DIMS;
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
@@ -427,11 +416,6 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
   a.M = total_rows(d);
-  {
-    const size_t xe = d->levels > 0 ? (size_t)d->level_off[d->levels] * d->Cin : (size_t)d->N * d->H * d->W * d->Cin;
-    a.x_bytes = (unsigned)(xe * sizeof(float));
-    a.w_bytes = (unsigned)((size_t)d->Cout * d->Kpad * sizeof(float));
-  }
   a.nlv = d->levels > 0 ? d->levels : 0;
   for (int l = 0; l < a.nlv; ++l) {
     a.lv_off[l] = d->level_off[l];

@@ -24,6 +24,15 @@
 
 namespace {
 
+// Division by a launch-invariant integer with one mul_hi + shifts (Granlund-Montgomery, exact for every 32-bit n).
+struct FastDiv {
+  unsigned mp, sh1, sh2, d;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.mp, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct ConvArgs {
   const float* x;
   const float* w;
@@ -42,6 +51,7 @@ struct ConvArgs {
   int nlv;
   int lv_off[6], lv_h[5], lv_w[5];
   unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
+  FastDiv div_ow, div_oh, div_cd;
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
@@ -49,13 +59,13 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
   size_t oidx;
   if (p.out_mode == 1) {
     const int Cd = p.Cout >> 2;
-    const int quad = n / Cd;
+    const int quad = (int)fdiv((unsigned)n, p.div_cd);
     co = n - quad * Cd;
     const int dy = quad >> 1, dx = quad & 1;
-    const int ox = m % p.OW;
-    const int t = m / p.OW;
-    const int oy = t % p.OH;
-    const int img = t / p.OH;
+    const int t = (int)fdiv((unsigned)m, p.div_ow);
+    const int ox = m - t * p.OW;
+    const int img = (int)fdiv((unsigned)t, p.div_oh);
+    const int oy = t - img * p.OH;
     oidx = ((size_t)(img * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + (2 * ox + dx)) * Cd + co;
   } else {
     oidx = (size_t)m * p.Cout + n;
@@ -65,10 +75,10 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
   if (p.res_mode == 1) {
     v += p.res[(size_t)m * p.Cout + n];
   } else if (p.res_mode == 2) {
-    const int ox = m % p.OW;
-    const int t = m / p.OW;
-    const int oy = t % p.OH;
-    const int img = t / p.OH;
+    const int t = (int)fdiv((unsigned)m, p.div_ow);
+    const int ox = m - t * p.OW;
+    const int img = (int)fdiv((unsigned)t, p.div_oh);
+    const int oy = t - img * p.OH;
     const int rh = p.OH >> 1, rw = p.OW >> 1;
     v += p.res[((size_t)(img * rh + (oy >> 1)) * rw + (ox >> 1)) * p.Cout + n];
   }
@@ -304,6 +314,18 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
+FastDiv make_fastdiv(unsigned d) {
+  FastDiv f{};
+  if (d == 0) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mp = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.sh1 = l < 1 ? l : 1;
+  f.sh2 = l > 0 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}
+
 inline int default_bk() {
   static const int v = [] {
     const char* e = getenv("EOD_CONV_BK");
@@ -427,6 +449,9 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
   a.M = total_rows(d);
+  a.div_ow = make_fastdiv((unsigned)(d->OW > 0 ? d->OW : 1));
+  a.div_oh = make_fastdiv((unsigned)(d->OH > 0 ? d->OH : 1));
+  a.div_cd = make_fastdiv((unsigned)((d->Cout >> 2) > 0 ? (d->Cout >> 2) : 1));
   {
     const size_t xe = d->levels > 0 ? (size_t)d->level_off[d->levels] * d->Cin : (size_t)d->N * d->H * d->W * d->Cin;
     a.x_bytes = (unsigned)(xe * sizeof(float));

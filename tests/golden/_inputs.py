@@ -118,3 +118,13 @@ def zs_case(seed: int = 8, R: int = 17):
     w = torch.randn((512, 1024), generator=g) * (1.0 / 1024) ** 0.5
     b = torch.randn((512,), generator=g) * 0.1
     return x, w, b
+
+
+def robot_case(seed: int = 21, H: int = 120, W: int = 160):
+    """Depth in millimetres (uint16-like), planar robot pose (x, y, theta)."""
+    rng = np.random.RandomState(seed)
+    base = 2500 + 1500 * np.sin(np.linspace(0, 4, W))[None, :] * np.cos(np.linspace(0, 3, H))[:, None]
+    depth_mm = np.clip(base + 200 * rng.randn(H, W), 0, 9000).astype(np.uint16)   # cv2.IMREAD_ANYDEPTH gives uint16 mm
+    depth_mm[:3] = 0                         # no-return pixels
+    pose = np.array([1.75, -2.5, 0.6], dtype=np.float32)
+    return dict(depth_mm=depth_mm, pose=pose)

@@ -100,3 +100,26 @@ def test_zero_shot_classifier(golden_dir):
     np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=1e-5)
     # and through the oracle's stage function (fc layers set to identity-free path is covered elsewhere)
     assert g["logits"].shape == (17, 21)
+
+
+def test_robot_front_end_against_robot_demo(golden_dir):
+    """Second caller of the boundary: fixed-K projector, axis-swapped transform, x*map_h+y ordering (robot_demo.py:489-534)."""
+    from embodied_object_detection_amd.data import robot as R
+    g = _load(golden_dir, "robot.npz")
+    c = I.robot_case()
+    T = R.robot_transform(c["pose"])
+    np.testing.assert_allclose(T, g["T"], rtol=0, atol=1e-7)
+    depth_m = (np.asarray(c["depth_mm"], dtype=np.float64) / 1000).astype(np.float32)
+    xyz = OP.unproject_world(depth_m, g["T"], *R.ROBOT_INTRINSICS, proj_shift=(0, 0, 0))
+    np.testing.assert_allclose(xyz, g["xyz"], rtol=0, atol=3e-6)
+    fe = R.RobotFrontEnd(projector=lambda d, T_, intr, ps, ms, cell, mw, mh, order=0: OP.depth_to_proj_indices(d, T_, intr, ps, ms, cell, mw, mh, order))
+    f = fe.frame(np.zeros(c["depth_mm"].shape + (3,), np.uint8), c["depth_mm"], c["pose"])
+    assert f["memory_reset"] is True and f["proj_indices"].shape == c["depth_mm"].shape + (1,) and f["memory"].shape[0] == 40000
+    got = f["proj_indices"][..., 0]
+    agree = (got == g["proj"]).mean()
+    # the reference transform comes out of a torch matmul (T @ R) whose last-ulp rounding is not specified: allow a handful of
+    # boundary pixels, require the rest bit-exact
+    assert agree > 0.999, agree
+    assert fe.frame(np.zeros(c["depth_mm"].shape + (3,), np.uint8), c["depth_mm"], c["pose"])["memory_reset"] is False
+    assert R.nearest_by_timestamp(1005, ["0990.png", "1010.png", "1000.png"]) == "1010.png"   # first minimum wins
+    assert R.nearest_by_timestamp(1000, ["0990.png", "1010.png"]) == "0990.png"

@@ -70,6 +70,16 @@ def available_cores() -> int:
     return max(1, min(n, 32))
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, separate passes: profiles/r01_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")) as fh:
+            return round(float(json.load(fh)["traffic_bytes_per_launch"]), 1)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -286,7 +296,7 @@ def main():
         tot_ms = sum(durs)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<64,64,BK=64> (mask_fcn 3x3 implicit GEMM, M=rois*196, N=256, K=2304)",
                     "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                     "launches": len(durs), "avg_launch_ms": round(tot_ms / len(durs), 4),
                     "algorithmic_flop_per_launch": round(sum(flops) / len(flops), 1)}
 

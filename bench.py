@@ -323,7 +323,7 @@ def main():
             "eval_allreduce_ms": round(t_ar * 1e3, 3),
             "ap50_synthetic": None if ap is None else round(ap["AP50"], 3),
         }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bench contract)
         result["cpu_baseline"] = cpu_baseline(sd, host_frames[:8], args, args.cpu_budget_s)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -216,3 +216,53 @@ def test_lazy_proposal_masks_give_identical_results(setup):
     for a, b in zip(ra, rb):
         assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
         assert torch.equal(a.pred_masks, b.pred_masks)
+
+
+def test_native_480x640_frame_and_empty_edge_cases(synthetic_sd):
+    """Config A geometry (480x640, the native mp3d frame: p6 8x10, p7 4x5) against the oracle, then the empty cases:
+    no detection passes the threshold (D = 0) and no memory instance passes (K = 0: state must not change,
+    custom_rcnn.py:686,872-873)."""
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    seq = SyntheticSequence(5, H=480, W=640, n_frames=2, map_w=60, map_h=60, cell=0.5)
+    frames = [seq.frame(0), seq.frame(1)]
+    model = build_model(_cfg(), synthetic_sd)
+    oracle = OM.RecurrentOracle(synthetic_sd, M.OracleCfg(map_feature_weight=5.0))
+    ref = oracle.step(frames[0], 0, frames)["instances"]
+    out = model([[frames[0]]])[0]["instances"]
+    idx, iou = _match(ref["pred_boxes"], out.pred_boxes.tensor.cpu(), ref["pred_classes"], out.pred_classes.cpu())
+    ok = (iou > 0.99) & ((out.scores.cpu()[idx] - ref["scores"]).abs() < 1e-3)
+    assert ok.float().mean().item() >= 0.98
+    assert tuple(out.pred_masks.shape[1:]) == (480, 640) and out.pred_masks.dtype == torch.bool
+    assert torch.equal(model.observations.cpu(), oracle.observations)
+    # D = 0 and K = 0
+    empty = build_model(_cfg(**{"MODEL.ROI_HEADS.SCORE_THRESH_TEST": 1.0, "MODEL.MEMORY_CLS_SCORE_THRESH": 1.0}), synthetic_sd)
+    res = empty([[frames[0], frames[1]]])
+    assert len(res) == 2 and all(len(r["instances"]) == 0 for r in res)
+    assert tuple(res[0]["instances"].pred_masks.shape) == (0, 480, 640)
+    assert int(empty.last_stats["mem_k"].item()) == 0
+    assert float(empty.implicit_memory.abs().sum()) == 0.0 and float(empty.observations.sum()) == 0.0
+
+
+def test_test_type_longterm_and_episodic_snapshots(setup):
+    """TEST_TYPE longterm reads the memory snapshot taken at the first frame of the episode (custom_rcnn.py:482-491); default /
+    episodic refresh it every frame."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    for tt in ("longterm", "episodic"):
+        model = build_model(_cfg(**{"MODEL.TEST_TYPE": tt}), sd)
+        ocfg = M.OracleCfg(memory_cls_score_thresh=0.3, map_feature_weight=5.0, test_type=tt)
+        oracle = OM.RecurrentOracle(sd, ocfg)
+        outs = model([frames])                                   # one episode of 4 frames in ONE call
+        refs = oracle([frames])
+        assert len(outs) == len(refs) == 4
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            inst, ri = o["instances"], r["instances"]
+            idx, iou = _match(ri["pred_boxes"], inst.pred_boxes.tensor.cpu(), ri["pred_classes"], inst.pred_classes.cpu())
+            ok = (iou > 0.99) & ((inst.scores.cpu()[idx] - ri["scores"]).abs() < 1e-3)
+            assert ok.float().mean().item() >= 0.97, (tt, i)
+        assert torch.equal(model.observations.cpu(), oracle.observations)
+    # and the two policies really differ on this episode (frames 1..3 see an empty snapshot under longterm)
+    a = build_model(_cfg(**{"MODEL.TEST_TYPE": "longterm"}), sd)([frames])[2]["instances"].scores.cpu()
+    b = build_model(_cfg(**{"MODEL.TEST_TYPE": "default"}), sd)([frames])[2]["instances"].scores.cpu()
+    assert a.shape != b.shape or not torch.allclose(a, b, atol=1e-6)

@@ -60,7 +60,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2), (13, 1), (22, 2), (41, 1), (42, 1), (43, 1), (43, 3)])
 def test_conv_matches_f_conv2d(dev, case, tile, splitk):
     from embodied_object_detection_amd import ops
     N, H, W, Cin, Cout, k, stride, pad = case
@@ -462,8 +462,8 @@ def test_semmap_labels_match_oracle(dev):
     assert (got == -1).sum().item() > 0 and (got >= 0).sum().item() > 0
 
 
-@pytest.mark.parametrize("cout,splitk", [(256, 0), (5, 0), (64, 3)])
-def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk):
+@pytest.mark.parametrize("cout,splitk,tile", [(256, 0, 0), (5, 0, 0), (64, 3, 0), (256, 1, 43), (64, 2, 42)])
+def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk, tile):
     """One launch over the 5 FPN levels with shared weights == five per-level 'same' convolutions."""
     from embodied_object_detection_amd import ops
     hw = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]
@@ -476,7 +476,7 @@ def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk):
         off.append(off[-1] + h * ww)
     flat = torch.cat([nhwc(x).reshape(-1, Cin) for x in xs]).contiguous().to(dev)
     conv = ops.Conv(w, b, pad=1, device=dev)
-    y = conv(flat, 1, 0, 0, relu=True, levels=(off, hw), force_splitk=splitk).cpu()
+    y = conv(flat, 1, 0, 0, relu=True, levels=(off, hw), force_splitk=splitk, force_tile=tile).cpu()
     for i, x in enumerate(xs):
         ref = F.relu(F.conv2d(x, w, b, padding=1))
         close(y[off[i]:off[i + 1]], nhwc(ref).reshape(-1, cout))

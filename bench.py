@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 dense (v_mfma_f32_32x32x16_bf16, 32 cycles per SIMD)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -146,6 +147,7 @@ def main():
     model = build_model(cfg, sd)
     log('model built')
 
+    headline_math = ops.get_conv_math()          # "fp32" unless EOD_CONV_MATH=bf16x3 is exported
     n_frames = args.steps + args.warmup
     seq = SyntheticSequence(rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell,
                             projector=None)
@@ -227,6 +229,47 @@ def main():
                                                    "update reads instead of all 256 (the reference computes and discards the rest)"}
         model.lazy_proposal_masks = False
 
+        # fp32 emulated on the bf16 matrix cores (three-way operand split, six MFMAs per term set, fp32 accumulate): same
+        # parity tests, 16/6 of the fp32-MFMA arithmetic ceiling.  Opt-in (EOD_CONV_MATH=bf16x3 / ops.set_conv_math).
+        if ops.get_conv_math() == "fp32":
+            prev_math = ops.set_conv_math("bf16x3")
+            ev2 = []
+            if not args.no_kernel_events:
+                for conv in model.roi_heads.mask_convs:
+                    conv.event_log = ev2
+            for i in range(args.warmup):
+                step(i, False)
+            torch.cuda.synchronize()
+            ev2.clear()
+            barrier()
+            tv = time.perf_counter()
+            for i in range(args.warmup, n_frames):
+                step(i, False)
+            torch.cuda.synchronize()
+            barrier()
+            tv = time.perf_counter() - tv
+            for conv in model.roi_heads.mask_convs:
+                conv.event_log = None
+            ops.set_conv_math(prev_math)
+            if distributed:
+                t = torch.tensor([tv], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tv = float(t.item())
+            v = {"value": round(args.steps * world / tv, 3), "unit": "frames/s", "ms_per_step": round(tv / args.steps * 1e3, 3),
+                 "note": "every eligible conv/linear on the bf16 MFMA pipe with fp32 operands split into three bf16 pieces "
+                         "(6 MFMAs per K=16 step, fp32 accumulate); passes the same 1e-3 parity tests; error vs an fp64 conv "
+                         "within 2x of the fp32-MFMA kernel's (tests/test_kernels_gpu.py::test_conv_bf16x3_accuracy)"}
+            if ev2:
+                durs = [s_.elapsed_time(e_) for (s_, e_, _c) in ev2]
+                fl = [2.0 * (int(c.item()) if c is not None else 0) * 196 * 256 * 2304 for (_s, _e, c) in ev2]
+                ach = sum(fl) / (sum(durs) * 1e-3) / 1e12
+                v["mask_conv"] = {"kernel": "conv_bf16x3_kernel<128,128>", "achieved_fp32_equivalent_tflops": round(ach, 3),
+                                  "avg_launch_ms": round(sum(durs) / len(durs), 4),
+                                  "frac_of_bf16_dense_peak_algorithmic": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  "frac_of_bf16_dense_peak_issued": round(6.0 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+            variants["bf16x3_split_mfma"] = v
+
         # independent scenes interleaved on separate HIP streams of the same GPU (config 5 batches 4 sequences per GPU):
         # each scene keeps its own model state; small kernels of one scene overlap the mask-head GEMMs of another
         if args.streams > 1:
@@ -294,9 +337,13 @@ def main():
         rows = [int(c.item()) if c is not None else 0 for (_s, _e, c) in ev]
         flops = [2.0 * r * 196 * 256 * 2304 for r in rows]
         tot_ms = sum(durs)
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<64,64,BK=64> (mask_fcn 3x3 implicit GEMM, M=rois*196, N=256, K=2304)",
-                    "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+        b3 = headline_math == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
+        kname = ("conv_bf16x3_kernel<128,128> (bf16 MFMA, 3-way operand split: 6 issued MFMA flops per algorithmic flop)" if b3
+                 else "conv_igemm_kernel<64,64,BK=64>") + " (mask_fcn 3x3 implicit GEMM, M=rois*196, N=256, K=2304)"
+        roofline = {"bound": "mfma", "kernel": kname,
+                    "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / peak, 4), "traffic": None if b3 else pmc_traffic(),
                     "launches": len(durs), "avg_launch_ms": round(tot_ms / len(durs), 4),
                     "algorithmic_flop_per_launch": round(sum(flops) / len(flops), 1)}
 
@@ -310,7 +357,8 @@ def main():
             "metric": "frames/sec (640x640, implicit_memory); frames/sec/GPU = value / n_gpus",
             "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if headline_math == "fp32" else "f32 emulated as 3 x bf16 on the bf16 MFMA pipe, fp32 accumulate", "data": "synthetic",
             "config": {"workload": f"recurrent per-frame inference, MEMORY_TYPE implicit_memory, MAP_FEAT_FUSION sum, "
                                    f"{H}x{W} synthetic sequence, memory grid {map_w}x{map_h} @ {args.cell} m, one scene per GPU "
                                    f"(BASELINE.json configs[2]/[3])",

@@ -70,6 +70,8 @@ SIGNATURES = {
     "eod_abi_version": (C.c_int, []),
     "eod_conv2d": (C.c_int, [C.POINTER(EodConvDesc), C.c_void_p]),
     "eod_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(EodConvDesc)]),
+    "eod_set_conv_math": (C.c_int, [C.c_int]),
+    "eod_get_conv_math": (C.c_int, []),
     "eod_preprocess_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     "eod_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),

@@ -51,6 +51,23 @@ _conv_ws = Workspace()
 # ----------------------------------------------------------------------------------------------------
 # weight preparation (host, once per model build)
 # ----------------------------------------------------------------------------------------------------
+_CONV_MATH = {"fp32": 0, "bf16x3": 1}
+
+
+def set_conv_math(mode: str) -> str:
+    """Arithmetic of every conv / linear launch from now on (process-wide): "fp32" (fp32 MFMA, default) or "bf16x3" (three-way
+    bf16 operand split on the bf16 MFMA pipe, fp32 accumulate; include/eod_hip.h eod_set_conv_math).  Returns the previous mode."""
+    if mode not in _CONV_MATH:
+        raise ValueError(f"conv math must be one of {sorted(_CONV_MATH)}, got {mode!r}")
+    prev = _lib.load().eod_set_conv_math(_CONV_MATH[mode])
+    check(min(prev, 0), "eod_set_conv_math")
+    return {v: k for k, v in _CONV_MATH.items()}[prev]
+
+
+def get_conv_math() -> str:
+    return {v: k for k, v in _CONV_MATH.items()}[_lib.load().eod_get_conv_math()]
+
+
 def fold_bn(w: torch.Tensor, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5):
     """FrozenBatchNorm2d folded into the preceding bias-free conv."""
     scale = bn_w / torch.sqrt(bn_var + eps)

@@ -58,7 +58,8 @@ typedef struct EodConvDesc {
   int32_t in_relu;   /* ReLU applied to x on load (p7 = conv(relu(p6)), timm.py:362) */
   int32_t out_mode;  /* 0 NHWC, 1 ConvTranspose2d(k2,s2) scatter: n = (dy*2+dx)*Cout/4 + co */
   int32_t tap4;      /* 1: Cin == 4 (stem, RGB padded to 4): one float4 per tap */
-  int32_t force_tile; /* 0 auto, else 1=128x128 2=128x64 3=64x64 (benchmarks/tests) */
+  int32_t force_tile; /* 0 auto, else tile + 10 * variant: tile 1=128x128 2=128x64 3=64x64; variant 0 default, 1 BK=32, 2 BK=64,
+                         4 LDS-DMA staging (experimental), 5 bf16x3 split math (benchmarks/tests) */
   int32_t force_splitk; /* 0 auto */
   float out_scale;
   /* pyramid mode (levels > 0): x / y are [level_off[levels], C] row lists, level l is a level_h[l] x level_w[l] image;
@@ -70,6 +71,17 @@ typedef struct EodConvDesc {
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
+/* Arithmetic of eod_conv2d when force_tile == 0 (process-wide, read at every call; initial value from the environment variable
+ * EOD_CONV_MATH = fp32 | bf16x3):
+ *   EOD_MATH_FP32   (0, default) fp32 matrix-core FMAs (v_mfma_f32_32x32x2_f32): the reference's arithmetic class;
+ *   EOD_MATH_BF16X3 (1) every fp32 operand split into three bf16 pieces, six bf16 MFMAs per product term set, fp32 accumulate:
+ *                   fp32-class accuracy (error vs an fp64 convolution within 2x of the fp32 path's, tests/test_kernels_gpu.py)
+ *                   at 16/6 of the fp32-MFMA ceiling.  The 7x7 stem and in_relu convs stay on the fp32 kernel.
+ * Returns the previous mode, or EOD_ERR_BAD_DIMS for an unknown one.  Nothing in the reference to mirror (build-defined). */
+#define EOD_MATH_FP32 0
+#define EOD_MATH_BF16X3 1
+int eod_set_conv_math(int mode);
+int eod_get_conv_math(void);
 
 /* ---- small dense / elementwise ops -------------------------------------------------------------------- */
 /* d2 GeneralizedRCNN.preprocess_image (custom_rcnn.py:557): u8 CHW RGB -> (x-mean)/std, NHWC4 (4th channel

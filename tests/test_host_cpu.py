@@ -45,6 +45,11 @@ def test_conv_descriptor_validation_without_gpu():
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Kpad = 1, 4, 4, 48, 4, 4, 8, 1, 1, 1, 0, 64
     assert lib.eod_conv2d(C.byref(d), None) == -1             # Cin % 32 != 0 -> EOD_ERR_BAD_DIMS
     assert lib.eod_conv2d_workspace_bytes(C.byref(d)) == 0
+    # arithmetic-mode switch is host state: round trip + refusal of unknown modes
+    prev = lib.eod_get_conv_math()
+    assert lib.eod_set_conv_math(1) == prev and lib.eod_get_conv_math() == 1
+    assert lib.eod_set_conv_math(7) == -1 and lib.eod_get_conv_math() == 1
+    assert lib.eod_set_conv_math(prev) == 1
 
 
 def test_product_fails_loudly_without_gpu_or_library(monkeypatch):

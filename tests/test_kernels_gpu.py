@@ -60,7 +60,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2), (13, 1), (22, 2), (41, 1), (42, 1), (43, 1), (43, 3)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2), (13, 1), (22, 2), (41, 1), (42, 1), (43, 1), (43, 3), (51, 1), (52, 1), (53, 1), (53, 3)])
 def test_conv_matches_f_conv2d(dev, case, tile, splitk):
     from embodied_object_detection_amd import ops
     N, H, W, Cin, Cout, k, stride, pad = case
@@ -71,6 +71,57 @@ def test_conv_matches_f_conv2d(dev, case, tile, splitk):
     conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
     y = conv(nhwc(x).to(dev), N, H, W, force_tile=tile, force_splitk=splitk)
     close(nchw(y), ref)
+
+
+@pytest.mark.parametrize("case", [(8, 14, 14, 256, 256, 3, 1), (1, 20, 20, 2048, 256, 1, 0), (64, 1, 1, 12544, 128, 1, 0)])
+@pytest.mark.parametrize("spread", [False, True])
+def test_conv_bf16x3_accuracy(dev, case, spread):
+    """The three-way bf16 split is an fp32-class computation: its error against an fp64 convolution stays within 2.5x of the
+    fp32-MFMA kernel's (and of torch's CPU fp32 conv), also when the input channels span six decades."""
+    from embodied_object_detection_amd import ops
+    N, H, W, Cin, Cout, k, pad = case
+    x = rnd(N, Cin, H, W, seed=11)
+    if spread:
+        x = x * torch.logspace(-3, 3, Cin).view(1, Cin, 1, 1)
+    w = rnd(Cout, Cin, k, k, seed=12, scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=13)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad)
+    scale = ref.abs().mean().item()
+    conv = ops.Conv(w, b, stride=1, pad=pad, device=dev)
+    xd = nhwc(x).to(dev)
+    err = {}
+    for name, tile in (("fp32", 23), ("b3_128", 51), ("b3_64", 53)):
+        y = nchw(conv(xd, N, H, W, force_tile=tile, force_splitk=1)).double().cpu()
+        e = (y - ref).abs()
+        err[name] = (e.max().item() / scale, e.mean().item() / scale)
+    e = (F.conv2d(x, w, b, padding=pad).double() - ref).abs()
+    err["cpu"] = (e.max().item() / scale, e.mean().item() / scale)
+    for name in ("b3_128", "b3_64"):
+        assert err[name][1] <= 2.5 * max(err["fp32"][1], err["cpu"][1]), err
+        assert err[name][0] <= 4.0 * max(err["fp32"][0], err["cpu"][0]), err
+        assert err[name][1] < 3e-6, err
+
+
+def test_conv_math_mode_switch(dev):
+    """eod_set_conv_math routes force_tile == 0 launches; both modes agree to fp32 noise; unknown modes are refused."""
+    from embodied_object_detection_amd import ops
+    x = rnd(2, 64, 16, 16, seed=21)
+    w = rnd(96, 64, 3, 3, seed=22, scale=0.05)
+    conv = ops.Conv(w, None, stride=1, pad=1, device=dev)
+    xd = nhwc(x).to(dev)
+    assert ops.get_conv_math() == "fp32"
+    y0 = conv(xd, 2, 16, 16).clone()
+    assert ops.set_conv_math("bf16x3") == "fp32"
+    try:
+        y1 = conv(xd, 2, 16, 16).clone()
+        y_in = conv(xd, 2, 16, 16, in_relu=True).clone()     # in_relu stays on the fp32 kernel
+    finally:
+        assert ops.set_conv_math("fp32") == "bf16x3"
+    assert not torch.equal(y0, y1)                             # a different kernel ran
+    close(y1, y0, rtol=1e-5, atol=1e-5)
+    close(nchw(y_in), F.conv2d(F.relu(x), w, None, padding=1))
+    with pytest.raises(ValueError):
+        ops.set_conv_math("fp16")
 
 
 def test_conv_epilogues(dev):
@@ -462,7 +513,7 @@ def test_semmap_labels_match_oracle(dev):
     assert (got == -1).sum().item() > 0 and (got >= 0).sum().item() > 0
 
 
-@pytest.mark.parametrize("cout,splitk,tile", [(256, 0, 0), (5, 0, 0), (64, 3, 0), (256, 1, 43), (64, 2, 42)])
+@pytest.mark.parametrize("cout,splitk,tile", [(256, 0, 0), (5, 0, 0), (64, 3, 0), (256, 1, 43), (64, 2, 42), (256, 1, 53), (64, 2, 52)])
 def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk, tile):
     """One launch over the 5 FPN levels with shared weights == five per-level 'same' convolutions."""
     from embodied_object_detection_amd import ops

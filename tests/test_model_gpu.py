@@ -123,7 +123,20 @@ def test_backbone_and_heads_stagewise(setup):
     assert close(pm[:k], ref_pm[:, 0], 1e-3)
 
 
-def test_recurrent_frames_match_oracle(setup):
+@pytest.fixture
+def conv_math(request):
+    """Runs the test under the requested eod_conv2d arithmetic and restores the previous mode."""
+    from embodied_object_detection_amd import ops
+    prev = ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(prev)
+
+
+@pytest.mark.parametrize("conv_math", ["fp32", "bf16x3"], indirect=True)
+def test_recurrent_frames_match_oracle(setup, conv_math):
+    """Same tolerances for both arithmetic modes: fp32 MFMA (default) and the three-way bf16 split on the bf16 MFMA pipe."""
+    from embodied_object_detection_amd import ops
+    assert ops.get_conv_math() == conv_math
     model, frames, sd, ocfg = setup["model"], setup["frames"], setup["sd"], setup["ocfg"]
     oracle = OM.RecurrentOracle(sd, ocfg)
     H, W = setup["H"], setup["W"]

@@ -801,6 +801,253 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs p) {
 #endif
 }
 
+// 256 x 128 tile, 512 threads (8 waves as 4 x 2, 64 x 64 per wave), one workgroup per CU.
+//   * two LDS stages of 384 rows x 208 B (159 744 B of the 160 KiB): the pieces of chunk c+1 are written into the other stage
+//     WHILE chunk c is multiplied, so there is one barrier per chunk and no staging registers between iterations;
+//   * every group of six MFMAs (one 32x32 tile, one K=16 step) carries one staging unit of this thread: split one float4
+//     (22 VALU), three ds_write_b64, one buffer load that refills the raw register with chunk c+2;
+//   * the fragments of the second K=16 step are read while the first one is multiplied.
+template <bool MULTI>
+__global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 128, BK = 32;
+  constexpr int ROWB = 3 * 2 * BK + 16;     // 208
+  constexpr int STAGE = (BM + BN) * ROWB;   // 79 872
+  constexpr int AR = 4, BR = 2, UNITS = AR + BR;
+  extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+  char* lds = lds_dyn;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int M = p.M;
+  if (p.m_count) {
+    const int c = *p.m_count;
+    const int lim = c * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.y;
+  const int c_begin = z * p.cps;
+  int c_end = c_begin + p.cps;
+  if (c_end > p.nchunks) c_end = p.nchunks;
+
+  const int lr = tid >> 3, lq = tid & 7;      // 64 rows per pass, 8 float4 per row
+  unsigned a_voff[AR];
+  unsigned long long a_mask[AR];
+  unsigned a_pitch[MULTI ? AR : 1];
+  const int ntaps = p.KH * p.KW;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lr + 64 * i;
+    int iy0 = 0, ix0 = 0, off = 0, hh = 1, ww = 1;
+    const bool rowok = m < M;
+    if (rowok) {
+      if (MULTI) {
+        int l = 0;
+        while (l + 1 < p.nlv && m >= p.lv_off[l + 1]) ++l;
+        const int local = m - p.lv_off[l];
+        ww = p.lv_w[l];
+        hh = p.lv_h[l];
+        const int oy = local / ww;
+        iy0 = oy - p.pad;
+        ix0 = (local - oy * ww) - p.pad;
+        off = p.lv_off[l];
+      } else {
+        const int tq = (int)fdiv((unsigned)m, p.div_ow);
+        const int ox = m - tq * p.OW;
+        const int img = (int)fdiv((unsigned)tq, p.div_oh);
+        const int oy = tq - img * p.OH;
+        iy0 = oy * p.stride - p.pad;
+        ix0 = ox * p.stride - p.pad;
+        off = img * p.H * p.W;
+        hh = p.H;
+        ww = p.W;
+      }
+    }
+    unsigned long long mask = 0;
+    if (rowok) {
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int ky = tp / p.KW, kx = tp - ky * p.KW;
+        const bool ok = ((unsigned)(iy0 + ky) < (unsigned)hh) && ((unsigned)(ix0 + kx) < (unsigned)ww);
+        mask |= (unsigned long long)ok << tp;
+      }
+    }
+    a_mask[i] = mask;
+    a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);
+    if (MULTI) a_pitch[i] = (unsigned)(ww * p.Cin * 4);
+  }
+  unsigned w_voff[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lr + 64 * j;
+    w_voff[j] = n < p.Cout ? (unsigned)((n * p.Kpad + 4 * lq) * 4) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  f32x4 raw[UNITS];
+  bool in_loop = false;     // diagnostic builds (tools/ablate/run_bf16x3.py) drop parts of the loop body
+  (void)in_loop;
+  struct TapInfo { int tap, ky; unsigned tap_off, k0b; };
+  auto tap_info = [&](int chunk) {
+    if (chunk > c_end - 1) chunk = c_end - 1;          // past-the-end prefetches re-read the last chunk (never used)
+    const int k0 = chunk * BK;
+    TapInfo ti;
+    ti.tap = k0 / p.Cin;
+    const int c0 = k0 - ti.tap * p.Cin;
+    ti.ky = ti.tap / p.KW;
+    const int kx = ti.tap - ti.ky * p.KW;
+    ti.tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ti.ky * p.W + kx) * p.Cin + c0) * 4);
+    ti.k0b = (unsigned)(k0 * 4);
+    return ti;
+  };
+  auto load_unit = [&](const TapInfo& ti, int u) {
+#ifdef ABL_NOGLOBAL
+    if (in_loop) return;
+#endif
+    if (u < AR) {
+      const bool ok = (a_mask[u] >> ti.tap) & 1ull;
+      unsigned vo = a_voff[u] + ti.tap_off;
+      if (MULTI) vo += (unsigned)ti.ky * a_pitch[u];
+      vo = ok ? vo : 0xFFFFFFFFu;
+      raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0));
+    } else {
+      raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[u - AR], ti.k0b, 0));
+    }
+  };
+  // staging unit u of this thread lands at st_off[u] inside a stage
+  auto st_off = [&](int u) { return u < AR ? (lr + 64 * u) * ROWB + lq * 8 : (BM + lr + 64 * (u - AR)) * ROWB + lq * 8; };
+  auto stage_unit = [&](char* stage, int u) {
+#ifdef ABL_NOSPLIT
+    Split3 s3;
+    s3.h.x = __builtin_bit_cast(unsigned, raw[u].x); s3.h.y = __builtin_bit_cast(unsigned, raw[u].y);
+    s3.m.x = __builtin_bit_cast(unsigned, raw[u].z); s3.m.y = __builtin_bit_cast(unsigned, raw[u].w);
+    s3.l = s3.h;
+    if (!in_loop) s3 = split3(raw[u]);
+#else
+    const Split3 s3 = split3(raw[u]);
+#endif
+#ifdef ABL_NOLDSW
+    if (in_loop) {
+      asm volatile("" ::"v"(s3.h.x), "v"(s3.h.y), "v"(s3.m.x), "v"(s3.m.y), "v"(s3.l.x), "v"(s3.l.y));
+      return;
+    }
+#endif
+    char* dst = stage + st_off(u);
+    *reinterpret_cast<uint2*>(dst) = s3.h;
+    *reinterpret_cast<uint2*>(dst + 64) = s3.m;
+    *reinterpret_cast<uint2*>(dst + 128) = s3.l;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int a_fo = (wm * 64 + frow) * ROWB + fh * 16;
+  const int b_fo = (BM + wn * 64 + frow) * ROWB + fh * 16;
+
+  {
+    const TapInfo t0 = tap_info(c_begin);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) load_unit(t0, u);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) stage_unit(lds, u);
+    const TapInfo t1 = tap_info(c_begin + 1);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) load_unit(t1, u);
+  }
+  in_loop = true;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int st = (chunk - c_begin) & 1;
+    char* cur = lds + st * STAGE;
+    char* nxt = lds + (st ^ 1) * STAGE;
+    __syncthreads();      // stage `cur` fully written (previous iteration), stage `nxt` no longer read
+    const TapInfo tn = tap_info(chunk + 2);
+    bf16x8_t af[2][2][3], bfr[2][2][3];    // [K=16 step][tile][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        af[0][i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(cur + a_fo + i * 32 * ROWB + q * 64));
+        bfr[0][i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(cur + b_fo + i * 32 * ROWB + q * 64));
+      }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int g = (s * 2 + i) * 2 + j;
+          if (s == 0) {     // prefetch a quarter of the second step's fragments per group
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              if (j == 0)
+                af[1][i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(cur + a_fo + i * 32 * ROWB + q * 64 + 32));
+              else
+                bfr[1][i][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(cur + b_fo + i * 32 * ROWB + q * 64 + 32));
+            }
+          }
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][2], bfr[s][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][0], bfr[s][j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][1], bfr[s][j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][1], bfr[s][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][0], bfr[s][j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][0], bfr[s][j][0], acc[i][j], 0, 0, 0);
+          if (g < UNITS) {
+            stage_unit(nxt, g);
+            load_unit(tn, g);
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + (wn * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + (wm * 2 + i) * 32 + row;
+        if (m < M && n < p.Cout) {
+          const float v = acc[i][j][r];
+          if (p.splitk > 1) {
+            p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
+          } else {
+            epilogue_store(p, v, m, n);
+          }
+        }
+      }
+    }
+  }
+#endif
+}
+
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   int M = p.M;
   if (p.m_count) {
@@ -864,7 +1111,7 @@ struct Plan {
 };
 
 Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
-  static const int cfg[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  static const int cfg[4][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}};   // the last one: bf16x3 8-wave kernel only
   Plan pl{};
   // Measured on MI355X (tools/conv_bench.py, profiles/r01_conv_bench.log): the 64x64 tile (7 waves/SIMD, finest
   // tile quantisation over 256 CUs) is the fastest or ties on every shape of this path, including the
@@ -872,13 +1119,17 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   int pick = 2;
   const int ft = d->force_tile % 10, fbk = d->force_tile / 10;   // force_tile = tile + 10 (BK 32) / + 20 (BK 64)
   if (ft >= 1 && ft <= 3) pick = ft - 1;
+  else if (ft == 4 && fbk == 5 && !d->tap4 && !d->in_relu) pick = 3;
   else if (M >= 32768 && big_tile_env() >= 1 && big_tile_env() <= 3) pick = big_tile_env() - 1;   // experiment knob
   const bool bk64_ok = !d->tap4 && d->Cin % 64 == 0 && d->Kpad % 64 == 0;
   pl.glds = (fbk == 4 && !d->tap4) ? 1 : ((fbk == 5 && !d->tap4 && !d->in_relu) ? 2 : 0);
   if (d->force_tile == 0 && math_mode().load(std::memory_order_relaxed) == EOD_MATH_BF16X3 && !d->tap4 && !d->in_relu) {
     pl.glds = 2;
     const long t128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
-    pick = t128 >= 512 ? 0 : 2;     // 128x128 once it fills two workgroups per CU, else the finest tile
+    const long t256 = (long)((M + 255) / 256) * ((d->Cout + 127) / 128);
+    // measured (profiles/r01_bf16x3_accuracy_speed.log): 256x128 (8 waves, one workgroup per CU) once it fills the chip,
+    // 128x128 once it fills two workgroups per CU, else the finest tile
+    pick = t256 >= 256 ? 3 : (t128 >= 512 ? 0 : 2);
   }
   pl.bk = pl.glds ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
   const int nchunks = d->Kpad / pl.bk;
@@ -1020,6 +1271,18 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
   switch (pl.tile) {
+    case 4: {
+      constexpr int kLds = 2 * (256 + 128) * 208;
+      static const bool attr = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        return true;
+      }();
+      (void)attr;
+      if (a.nlv > 0) hipLaunchKernelGGL((conv_bf16x3_w8_kernel<true>), grid, dim3(512), kLds, s, a);
+      else hipLaunchKernelGGL((conv_bf16x3_w8_kernel<false>), grid, dim3(512), kLds, s, a);
+      break;
+    }
     case 1: launch_tile<128, 128>(a, d->tap4 != 0, pl.bk, pl.glds, grid, s); break;
     case 2: launch_tile<128, 64>(a, d->tap4 != 0, pl.bk, pl.glds, grid, s); break;
     default: launch_tile<64, 64>(a, d->tap4 != 0, pl.bk, pl.glds, grid, s); break;

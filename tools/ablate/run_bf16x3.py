@@ -23,7 +23,7 @@ for rep in range(2):
   for name in variants:
     so = os.path.join(HERE, f"b3_{name}.so")
     lib = C.CDLL(so); lib.eod_conv2d.restype = C.c_int; lib.eod_conv2d.argtypes = [C.POINTER(_lib.EodConvDesc), C.c_void_p]
-    for tile in (51, 53):
+    for tile in (51, 54):
         d = _lib.EodConvDesc(); d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
         d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Kpad = R, 14, 14, 256, 14, 14, 256, 3, 3, 1, 1, kpad
         d.relu, d.out_scale, d.force_tile = 1, 1.0, tile

@@ -59,9 +59,9 @@ for label, args in (("3x3 256->256 K=2304", (8, 14, 14, 256, 256, 3, 1)), ("1x1 
         r = accuracy(*args, tiles=(23, 51, 52, 53), scale_spread=spread)
         print(label, "spread" if spread else "unit", {k: (f"{v[0]:.2e}", f"{v[1]:.2e}") for k, v in r.items()}, flush=True)
 
-speed("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 51, 52, 53, 23, 51, 52, 53))
-speed("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 51, 52, 53))
-speed("tower 3x3 256 80x80", 1, 80, 80, 256, 256, 3, 1, 1, tiles=(0, 51, 52, 53))
+speed("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 51, 53, 54, 23, 51, 53, 54))
+speed("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 51, 53, 54))
+speed("tower 3x3 256 80x80", 1, 80, 80, 256, 256, 3, 1, 1, tiles=(0, 51, 52, 53, 54))
 speed("l3 conv2 3x3 256 40x40", 1, 40, 40, 256, 256, 3, 1, 1, tiles=(0, 53))
 speed("l4 conv3 1x1 512->2048", 1, 20, 20, 512, 2048, 1, 1, 0, tiles=(0, 53))
 speed("fc1 256x12544->1024", 256, 1, 1, 12544, 1024, 1, 1, 0, tiles=(0, 53, 52))

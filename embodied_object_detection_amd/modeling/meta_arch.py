@@ -148,6 +148,8 @@ class CustomRCNNRecurrent:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
                 out = self.inference_frame(frame, refresh_memory_snapshot=refresh)
+                if self.save_semmap and i == 0:
+                    self.save_memory_snapshot(frame["sequence_name"])          # custom_rcnn.py:518-530
                 batch_output.append(out)
         return batch_output
 
@@ -234,6 +236,13 @@ class CustomRCNNRecurrent:
     def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw, mem_sel=None):
         rows, cnt = mem_sel if mem_sel is not None else self.select_memory_instances(prop_boxes, prop_scores, prop_count, image_hw)
         self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations)
+
+    def save_memory_snapshot(self, sequence_name: str) -> str:
+        """`MODEL.TEST_SAVE_SEMMAP` dump (custom_rcnn.py:518-530): semmap, impicit_memory [sic], observations -> OUTPUT_DIR/memory/."""
+        from ..data.snapshot import write_snapshot
+        semmap = self.semantic_map()
+        return write_snapshot(self.output_dir, sequence_name, semmap.cpu().numpy(), self.implicit_memory.cpu().numpy(),
+                              self.observations.cpu().numpy())
 
     def _materialize(self, out_hw) -> Instances:
         """Slice the fixed-capacity device buffers by the detection count (the frame's only host sync)."""

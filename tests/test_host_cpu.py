@@ -299,3 +299,22 @@ def test_oracle_nms_and_roi_align_properties():
     assert torch.allclose(out[0, 0], expect, atol=1e-5)
     lv = OO.assign_boxes_to_levels(torch.tensor([[0, 0, 10, 10], [0, 0, 224, 224], [0, 0, 600, 600.0]]))
     assert lv.tolist() == [0, 1, 2]
+
+
+def test_memory_snapshot_roundtrip(tmp_path):
+    """Dump / load of the memory snapshot keeps the reference's dataset names (incl. its spelling), dtypes and the +1 label shift."""
+    from embodied_object_detection_amd.data import snapshot as S
+    rng = np.random.RandomState(0)
+    sem = rng.randint(-1, 20, size=300).astype(np.int64)
+    mem = rng.randn(300, 512)
+    obs = rng.randint(0, 5, size=300).astype(np.float64)
+    path = S.write_snapshot(str(tmp_path), "scene0_ep1.h5", sem, mem, obs)
+    assert path.endswith(os.path.join("memory", "scene0_ep1.h5.npz"))
+    with np.load(path) as z:
+        assert sorted(z.files) == ["impicit_memory", "observations", "semmap"]
+        assert z["semmap"].dtype == np.int32 and z["impicit_memory"].dtype == np.float32 and z["observations"].dtype == np.float32
+    got = S.read_snapshot(os.path.join(str(tmp_path), "memory"), "scene0_ep1.h5")
+    assert np.array_equal(got["semmap_real"], sem + 1)                 # loader.py:221
+    assert np.array_equal(got["implicit_memory"], mem.astype(np.float32)) and np.array_equal(got["observations"], obs)
+    miss = S.read_snapshot(os.path.join(str(tmp_path), "nope"), "x", fallback_memory=mem)
+    assert miss["semmap_real"] is None and miss["observations"] is None and miss["implicit_memory"] is mem

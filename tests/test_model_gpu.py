@@ -3,6 +3,7 @@ oracle on identical seeded frames.  Tolerance from BASELINE.json north_star: 1e-
 bit-exact integer indexing.  Data-dependent selections (top-k / NMS) can legitimately differ on near-ties between two
 fp32 implementations, so list comparisons match entries by IoU and require >= 98 % of the entries to agree."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -279,3 +280,21 @@ def test_test_type_longterm_and_episodic_snapshots(setup):
     a = build_model(_cfg(**{"MODEL.TEST_TYPE": "longterm"}), sd)([frames])[2]["instances"].scores.cpu()
     b = build_model(_cfg(**{"MODEL.TEST_TYPE": "default"}), sd)([frames])[2]["instances"].scores.cpu()
     assert a.shape != b.shape or not torch.allclose(a, b, atol=1e-6)
+
+
+def test_save_semmap_dumps_snapshot_after_first_frame(setup, tmp_path):
+    """MODEL.TEST_SAVE_SEMMAP (custom_rcnn.py:518-530): after frame 0 of every inner sequence the module writes semmap,
+    impicit_memory [sic] and observations; the dump equals the device state after that frame and the oracle's labels."""
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.snapshot import read_snapshot
+    frames, sd = setup["frames"], setup["sd"]
+    model = build_model(_cfg(**{"MODEL.TEST_SAVE_SEMMAP": True, "OUTPUT_DIR": str(tmp_path)}), sd)
+    model([frames[:1]])
+    mem_after_0 = model.implicit_memory.cpu().numpy().copy()
+    obs_after_0 = model.observations.cpu().numpy().copy()
+    snap = read_snapshot(os.path.join(str(tmp_path), "memory"), frames[0]["sequence_name"])
+    assert np.array_equal(snap["implicit_memory"], mem_after_0) and np.array_equal(snap["observations"], obs_after_0)
+    ref = OM.semmap_labels(torch.from_numpy(mem_after_0), torch.from_numpy(obs_after_0), model.zs_weight.cpu(), model.obs_score_thresh)
+    agree = (torch.from_numpy(snap["semmap_real"] - 1) == ref).float().mean().item()
+    assert agree >= 0.999, agree
+    assert snap["semmap_real"].dtype == np.int32 and snap["semmap_real"].min() >= 0

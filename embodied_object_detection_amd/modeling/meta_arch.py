@@ -56,6 +56,13 @@ class CustomRCNNRecurrent:
         # Opt-in: compute the proposal masks only for the proposals the memory update reads (identical results, ~2 ms less
         # at 640x640).  Off by default so the default frame does the same work as the reference (a 256-proposal mask pass).
         self.lazy_proposal_masks = False
+        # The proposal mask pass (custom_rcnn.py:573) needs only the proposals and the FPN features, not the box cascade: the
+        # cascade's small latency-bound launches (15 FC GEMMs, 3 ROIAligns, the selection sorts) are enqueued on a second,
+        # high-priority HIP stream and run beside the proposal pass's large GEMMs.  The detection mask pass follows on the main
+        # stream after both (the two large passes never share the chip).  Same kernels, same inputs, same results; `overlap_branches = False` restores one stream.
+        self.overlap_branches = True
+        self._side_stream = None
+        self._ev_props = self._ev_pm = None
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         if state_dict is None:
@@ -193,18 +200,35 @@ class CustomRCNNRecurrent:
         x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
         feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj)
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
-        det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
-            views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+        update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
-        if self.lazy_proposal_masks and (self.memory_type == "implicit_memory" or self.always_update_memory):
-            # select the memory instances first, then run the mask head only on those proposals (same results: the other
-            # proposals' masks are never read, custom_rcnn.py:875-880)
-            mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-            ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
-            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
-                                                            rows_count=self._uniq_count)
+        if self.overlap_branches and not self.lazy_proposal_masks:
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)     # the small launches go first
+                self._ev_props, self._ev_pm = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_props.record(main)
+            self._side_stream.wait_event(self._ev_props)
+            with torch.cuda.stream(self._side_stream):
+                det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(
+                    views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+                self._ev_pm.record(self._side_stream)
+            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
+                                                            bufs=self.roi_heads.proposal_pass_buffers())
+            main.wait_event(self._ev_pm)
+            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
         else:
-            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
+            det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
+                views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+            if self.lazy_proposal_masks and update_mem:
+                # select the memory instances first, then run the mask head only on those proposals (same results: the other
+                # proposals' masks are never read, custom_rcnn.py:875-880)
+                mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
+                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
+                                                                rows_count=self._uniq_count)
+            else:
+                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
 
         # detector_postprocess (custom_rcnn.py:579-580)
         out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))

@@ -84,6 +84,7 @@ class DeticCascadeROIHeads:
         self.mup = torch.empty((M, 28, 28, 256), **f32)
         self.det_masks = torch.zeros((D, 28, 28), **f32)
         self.prop_masks = torch.zeros((R, 28, 28), **f32)
+        self._prop_bufs = None      # second activation set, allocated when the proposal pass runs on its own stream
         self.selector = ops.DetectionSelector(R, self.C1, self.topk, device)
 
     # ---- cascade box heads ------------------------------------------------------------------------
@@ -112,17 +113,18 @@ class DeticCascadeROIHeads:
 
     # ---- mask head ----------------------------------------------------------------------------------
     def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor,
-                     rows: torch.Tensor = None):
+                     rows: torch.Tensor = None, bufs=None):
         """Mask head on `count` ROIs.  With `rows` (a compact ascending list of box indices) ROI k pools `boxes[rows[k]]` and its
         28x28 mask is written to `out[rows[k]]`: only the listed boxes are computed, the output layout stays per-box."""
         h3, w3 = shapes[0]
-        ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=self.mpool, box_rows=rows)
-        src, dst = self.mpool, self.mbuf
+        mpool, mbuf, mup = bufs if bufs is not None else (self.mpool, self.mbuf, self.mup)
+        ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=mpool, box_rows=rows)
+        src, dst = mpool, mbuf
         for conv in self.mask_convs:
             conv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=dst)
             src, dst = dst, src
-        self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=self.mup)
-        ops.mask_predictor_sigmoid(self.mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out, out_units=rows)
+        self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=mup)
+        ops.mask_predictor_sigmoid(mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out, out_units=rows)
         return out
 
     def forward(self, views, shapes, prop_boxes, prop_scores, prop_count, image_hw):
@@ -132,11 +134,21 @@ class DeticCascadeROIHeads:
         self.forward_mask(views, shapes, det_boxes, det_count, self.topk, self.det_masks)      # forward_with_given_boxes
         return det
 
-    def forward_mask_memory(self, views, shapes, prop_boxes, prop_count, rows: torch.Tensor = None, rows_count: torch.Tensor = None):
+    def proposal_pass_buffers(self):
+        """Own activation buffers for the proposal mask pass, so that it can run concurrently with the box cascade."""
+        if self._prop_bufs is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            R = self.R
+            self._prop_bufs = (torch.empty((R, 14, 14, 256), **f32), torch.empty((R, 14, 14, 256), **f32),
+                               torch.empty((R, 28, 28, 256), **f32))
+        return self._prop_bufs
+
+    def forward_mask_memory(self, views, shapes, prop_boxes, prop_count, rows: torch.Tensor = None, rows_count: torch.Tensor = None,
+                            bufs=None):
         """`forward_mask_memory` + `mask_rcnn_inference` on ALL proposals (custom_rcnn.py:573-574).
 
         `rows` / `rows_count`: lazy variant -- only the proposals the memory update will read (custom_rcnn.py:875-880) get a
         mask; every other proposal's mask is dead in the reference (never read after `inference_with_proposals`)."""
         if rows is not None:
             return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows)
-        return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks)
+        return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks, bufs=bufs)

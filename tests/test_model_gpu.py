@@ -298,3 +298,22 @@ def test_save_semmap_dumps_snapshot_after_first_frame(setup, tmp_path):
     agree = (torch.from_numpy(snap["semmap_real"] - 1) == ref).float().mean().item()
     assert agree >= 0.999, agree
     assert snap["semmap_real"].dtype == np.int32 and snap["semmap_real"].min() >= 0
+
+
+def test_branch_overlap_on_two_streams_gives_identical_results(setup):
+    """Running the box cascade on a second stream beside the proposal mask pass is a scheduling change only: detections,
+    masks and the memory state are bitwise identical to the single-stream order, frame after frame."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    outs = []
+    for overlap in (False, True):
+        model = build_model(_cfg(), sd)
+        model.overlap_branches = overlap
+        res = [model([[f]])[0]["instances"] for f in frames]
+        outs.append((res, model.implicit_memory.cpu().clone(), model.observations.cpu().clone(),
+                     model.roi_heads.prop_masks.cpu().clone()))
+    (ra, ma, oa, pa), (rb, mb, ob, pb) = outs
+    assert torch.equal(oa, ob) and torch.equal(ma, mb) and torch.equal(pa, pb)
+    for a, b in zip(ra, rb):
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+        assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_masks, b.pred_masks)

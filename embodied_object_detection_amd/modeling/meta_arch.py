@@ -62,7 +62,8 @@ class CustomRCNNRecurrent:
         # stream after both (the two large passes never share the chip).  Same kernels, same inputs, same results; `overlap_branches = False` restores one stream.
         self.overlap_branches = True
         self._side_stream = None
-        self._ev_props = self._ev_pm = None
+        self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = None
+        self.overlap_memory_write = True    # also the memory selection + write-back, beside the detection mask pass
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         if state_dict is None:
@@ -202,20 +203,32 @@ class CustomRCNNRecurrent:
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
+        mem_done = False
         if self.overlap_branches and not self.lazy_proposal_masks:
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)     # the small launches go first
-                self._ev_props, self._ev_pm = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_props, self._ev_pm, self._ev_box, self._ev_mem = (torch.cuda.Event() for _ in range(4))
             self._ev_props.record(main)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
                 det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(
                     views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
-                self._ev_pm.record(self._side_stream)
+                self._ev_box.record(self._side_stream)
+                if update_mem and self.overlap_memory_write:
+                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
             prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
                                                             bufs=self.roi_heads.proposal_pass_buffers())
-            main.wait_event(self._ev_pm)
+            if update_mem and self.overlap_memory_write:
+                # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
+                # stream beside the detection mask pass; the main stream joins at the end of the frame
+                self._ev_pm.record(main)
+                self._side_stream.wait_event(self._ev_pm)
+                with torch.cuda.stream(self._side_stream):
+                    self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
+                    self._ev_mem.record(self._side_stream)
+                mem_done = True
+            main.wait_event(self._ev_box)
             self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
         else:
             det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
@@ -241,7 +254,9 @@ class CustomRCNNRecurrent:
                         self.mask_threshold, P["masks"])
 
         # memory update (custom_rcnn.py:515)
-        if self.memory_type == "implicit_memory" or self.always_update_memory:
+        if mem_done:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_mem)
+        elif update_mem:
             self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
         self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
         if not materialize:

@@ -1,0 +1,105 @@
+// Shared by the convolution translation units: launch arguments, the fused epilogue and the launch entry points of the
+// kernel families (fp32 MFMA: conv_fp32.hip, LDS-DMA experiment: conv_glds.hip, bf16x3 split: conv_bf16x3.hip).  Planning,
+// argument checks and the C ABI live in conv_igemm.hip.
+#pragma once
+#include "eod_common.h"
+
+namespace eodconv {
+
+
+// Division by a launch-invariant integer with one mul_hi + shifts (Granlund-Montgomery, exact for every 32-bit n).
+struct FastDiv {
+  unsigned mp, sh1, sh2, d;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.mp, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  float* partial;
+  const int* m_count;
+  int m_unit;
+  int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad;
+  int M, nchunks, splitk, cps;
+  int relu, res_mode, in_relu, out_mode;
+  int tiles_m, tiles_n;
+  float out_scale;
+  // multi-level mode (shared-weight head over the FPN pyramid): rows [lv_off[l], lv_off[l+1]) form an lv_h[l] x lv_w[l] image
+  int nlv;
+  int lv_off[6], lv_h[5], lv_w[5];
+  unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
+  FastDiv div_ow, div_oh, div_cd;
+};
+
+__device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
+  int co = n;
+  size_t oidx;
+  if (p.out_mode == 1) {
+    const int Cd = p.Cout >> 2;
+    const int quad = (int)fdiv((unsigned)n, p.div_cd);
+    co = n - quad * Cd;
+    const int dy = quad >> 1, dx = quad & 1;
+    const int t = (int)fdiv((unsigned)m, p.div_ow);
+    const int ox = m - t * p.OW;
+    const int img = (int)fdiv((unsigned)t, p.div_oh);
+    const int oy = t - img * p.OH;
+    oidx = ((size_t)(img * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + (2 * ox + dx)) * Cd + co;
+  } else {
+    oidx = (size_t)m * p.Cout + n;
+  }
+  if (p.bias) v += p.bias[co];
+  v *= p.out_scale;
+  if (p.res_mode == 1) {
+    v += p.res[(size_t)m * p.Cout + n];
+  } else if (p.res_mode == 2) {
+    const int t = (int)fdiv((unsigned)m, p.div_ow);
+    const int ox = m - t * p.OW;
+    const int img = (int)fdiv((unsigned)t, p.div_oh);
+    const int oy = t - img * p.OH;
+    const int rh = p.OH >> 1, rw = p.OW >> 1;
+    v += p.res[((size_t)(img * rh + (oy >> 1)) * rw + (ox >> 1)) * p.Cout + n];
+  }
+  if (p.relu) v = fmaxf(v, 0.0f);
+  p.y[oidx] = v;
+}
+
+// Stores one wave's accumulators (TM x TN tiles of 32x32, MFMA C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+// through the fused epilogue, or as a split-K slab.
+template <int TM, int TN>
+__device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16 (&acc)[TM][TN], int m_base, int n_base, int M, int z,
+                                                 int lane) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_base + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m_base + i * 32 + row;
+        if (m < M && n < p.Cout) {
+          const float v = acc[i][j][r];
+          if (p.splitk > 1) {
+            p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
+          } else {
+            epilogue_store(p, v, m, n);
+          }
+        }
+      }
+    }
+  }
+}
+
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (4 waves); bf16x3 also 4 = 256x128 (8 waves, dynamic LDS)
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s);
+void launch_conv_glds(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
+void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
+
+}  // namespace eodconv

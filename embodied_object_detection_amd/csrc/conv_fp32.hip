@@ -1,0 +1,252 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   y[m][n] = act( (sum_k A[m][k] * Wt[n][k] + bias[n]) * out_scale + res[m][n] )
+//
+// A[m][k] is the im2col view of the NHWC input: m = (img, oy, ox), k = (ky, kx, c) with c fastest, so a
+// 32-wide K chunk is 128 contiguous bytes of one input pixel.  Wt is [Cout][Kpad] (K fastest), which makes
+// both operand tiles "row = m or n, 32 contiguous k": they are staged through LDS as [rows][36] floats (the +4
+// pad makes the 16-lane groups of ds_read_b128 conflict free) and each lane fetches 4 consecutive k of its
+// row with ONE ds_read_b128.  The MFMA k-slot <-> k mapping is a free permutation as long as A and B agree:
+// lane half h supplies k = kk*8 + 4h + t to instruction t (t = 0..3), for both operands.
+//
+// fp32 in / fp32 accumulate: the result is an exact fp32 fma chain (same numerics class as the CPU
+// reference path), the peak is the fp32 MFMA rate 157 TFLOP/s.
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile BM x BN in {128x128, 128x64, 64x64}, each wave owns
+// (BM/2) x (BN/2) as 32x32 MFMA tiles.  Global -> register prefetch of chunk c+1 overlaps the MFMAs of chunk
+// c; one LDS buffer, two barriers per chunk.  Tiles are dealt to workgroups through an XCD-aware bijective
+// remap so that the workgroups sharing an L2 walk neighbouring tiles (same weight panel / same pixel rows).
+// Small problems are split along K (grid.y) into fp32 slabs reduced by a second kernel that also applies the
+// epilogue: deterministic, no atomics.
+#include "conv_common.h"
+
+namespace eodconv {
+namespace {
+
+template <int BM, int BN, int BK, bool TAP4, bool MULTI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int LS = BK + 4;  // LDS row stride in floats (+4: conflict-free 16-lane groups of ds_read_b128)
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int QPR = BK / 4;        // float4 per tile row
+  constexpr int RPP = 256 / QPR;     // tile rows staged per pass of the 256 threads
+  constexpr int AR = BM / RPP, BR = BN / RPP;
+  static_assert(!TAP4 || BK == 32, "the stem path stages one 7x7 tap per float4: BK must be 32");
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LS];
+  float* As = lds;
+  float* Bs = lds + BM * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int M = p.M;
+  if (p.m_count) {
+    const int c = *p.m_count;
+    const int lim = c * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  // Only the tiles that hold valid rows do work; the XCD remap is taken over THAT count so that a short dynamic
+  // row count (e.g. 256 of 320 ROI slots) still spreads evenly over the 8 XCDs instead of idling the last ones.
+  const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.y;
+  const int c_begin = z * p.cps;
+  int c_end = c_begin + p.cps;
+  if (c_end > p.nchunks) c_end = p.nchunks;
+
+  const int lr = tid / QPR, lq = tid % QPR;
+  // Operand addressing.  Both tiles are fetched with SRSRC buffer loads (32-bit byte offsets + hardware range check):
+  //  * every tile row gets ONE byte offset (its (ky,kx)=(0,0) tap position) and a bit mask of the taps that fall inside
+  //    the image, both computed once per workgroup; per chunk a load costs an add, a bit test and a select -- no
+  //    64-bit address arithmetic, no exec-mask branches; a masked-off / out-of-tile lane gets offset 0xFFFFFFFF, which
+  //    the range check turns into zeros (the conv's zero padding);
+  //  * a weight row's offset never changes: the K position goes into the scalar offset of the instruction.
+  int a_off[AR], a_iy[AR], a_ix[AR];        // TAP4 (stem) path only
+  unsigned a_voff[AR];
+  unsigned long long a_mask[AR];
+  unsigned a_pitch[MULTI ? AR : 1];
+  const int ntaps = p.KH * p.KW;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lr + RPP * i;
+    int iy0 = 0, ix0 = 0, off = 0, hh = 1, ww = 1;
+    const bool rowok = m < M;
+    if (rowok) {
+      if (MULTI) {
+        int l = 0;
+        while (l + 1 < p.nlv && m >= p.lv_off[l + 1]) ++l;
+        const int local = m - p.lv_off[l];
+        ww = p.lv_w[l];
+        hh = p.lv_h[l];
+        const int oy = local / ww;
+        iy0 = oy - p.pad;
+        ix0 = (local - oy * ww) - p.pad;
+        off = p.lv_off[l];
+      } else {
+        const int ox = m % p.OW;
+        const int t2 = m / p.OW;
+        const int oy = t2 % p.OH;
+        const int img = t2 / p.OH;
+        iy0 = oy * p.stride - p.pad;
+        ix0 = ox * p.stride - p.pad;
+        off = img * p.H * p.W;
+        hh = p.H;
+        ww = p.W;
+      }
+    }
+    a_iy[i] = rowok ? iy0 : -(1 << 28);
+    a_ix[i] = ix0;
+    a_off[i] = off;
+    if (!TAP4) {
+      unsigned long long mask = 0;
+      if (rowok) {
+        for (int tp = 0; tp < ntaps; ++tp) {
+          const int ky = tp / p.KW, kx = tp - ky * p.KW;
+          const bool ok = ((unsigned)(iy0 + ky) < (unsigned)hh) && ((unsigned)(ix0 + kx) < (unsigned)ww);
+          mask |= (unsigned long long)ok << tp;
+        }
+      }
+      a_mask[i] = mask;
+      a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);   // may wrap for padded taps: only used when the tap bit is set
+      if (MULTI) a_pitch[i] = (unsigned)(ww * p.Cin * 4);
+    }
+  }
+  unsigned w_voff[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lr + RPP * j;
+    w_voff[j] = n < p.Cout ? (unsigned)((n * p.Kpad + 4 * lq) * 4) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  f32x4 ar[AR], br[BR];
+  auto load_chunk = [&](int chunk) {
+    const int k0 = chunk * BK;
+    if (!TAP4) {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ky = tap / p.KW;
+      const int kx = tap - ky * p.KW;
+      const unsigned tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ky * p.W + kx) * p.Cin + c0) * 4);
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = (a_mask[i] >> tap) & 1ull;
+        unsigned vo = a_voff[i] + tap_off;
+        if (MULTI) vo += (unsigned)ky * a_pitch[i];
+        vo = ok ? vo : 0xFFFFFFFFu;
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0));
+      }
+    } else {
+      const int tap = chunk * 8 + lq;
+      const int ky = tap / p.KW;
+      const int kx = tap - ky * p.KW;
+      const bool tv = tap < p.KH * p.KW;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = tv && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_off[i] + iy * p.W + ix) * 4);
+        ar[i] = v;
+      }
+    }
+    if (p.in_relu) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        ar[i].x = fmaxf(ar[i].x, 0.f);
+        ar[i].y = fmaxf(ar[i].y, 0.f);
+        ar[i].z = fmaxf(ar[i].z, 0.f);
+        ar[i].w = fmaxf(ar[i].w, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      br[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], k0 * 4, 0));
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // a 64x64 tile leaves one 32x32 accumulator per wave = one fully dependent MFMA chain: split it into two
+  // independent chains (even / odd k-slots) that are added once at the end
+  f32x16 acc_b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_b[r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = 4 * (lane >> 5);
+  const float* a_base = As + (wm * TM * 32 + frag_row) * LS + frag_k;
+  const float* b_base = Bs + (wn * TN * 32 + frag_row) * LS + frag_k;
+
+  load_chunk(c_begin);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + RPP * i) * LS + 4 * lq) = ar[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + RPP * j) * LS + 4 * lq) = br[j];
+    __syncthreads();
+    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LS + kk * 8);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (TM * TN == 1 && (tt & 1))
+              acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc_b, 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  if (TM * TN == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_b[r];
+  }
+  store_wave_tiles<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
+}
+
+}  // namespace
+
+template <int BM, int BN>
+static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s) {
+  if (tap4)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), 0, s, a);
+  else if (a.nlv > 0 && bk == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), 0, s, a);
+  else if (a.nlv > 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), 0, s, a);
+  else if (bk == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), 0, s, a);
+}
+
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s) {
+  switch (tile) {
+    case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s); break;
+    case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s); break;
+    default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s); break;
+  }
+}
+
+}  // namespace eodconv

@@ -1,15 +1,16 @@
 #!/usr/bin/env python
-"""Ablation of the bf16x3 split-MFMA main loop on the mask-head shape (diagnostic builds of csrc/conv_igemm.hip with -DABL_*;
+"""Ablation of the bf16x3 split-MFMA main loop on the mask-head shape (diagnostic builds of the csrc/conv_*.hip files with -DABL_*;
 wrong results by design).  Build the variants first (CPU container): python tools/ablate/run_bf16x3.py build"""
 import ctypes as C, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE)); sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "embodied_object_detection_amd", "csrc", "conv_igemm.hip")
+CSRC = os.path.join(ROOT, "embodied_object_detection_amd", "csrc")
+SRC = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_fp32.hip", "conv_glds.hip", "conv_bf16x3.hip")]
 variants = {"full": [], "no_global": ["-DABL_NOGLOBAL"], "no_split": ["-DABL_NOSPLIT"], "no_ldswrite": ["-DABL_NOLDSW"],
             "no_global_split": ["-DABL_NOGLOBAL", "-DABL_NOSPLIT"], "no_global_split_ldsw": ["-DABL_NOGLOBAL", "-DABL_NOSPLIT", "-DABL_NOLDSW"]}
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     for name, flags in variants.items():
         so = os.path.join(HERE, f"b3_{name}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-ffp-contract=on"] + flags + [SRC, "-o", so])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-ffp-contract=on"] + flags + SRC + ["-o", so])
     sys.exit(0)
 import torch
 from embodied_object_detection_amd import _lib

@@ -25,6 +25,9 @@ struct ConvArgs {
   float* partial;
   const int* m_count;
   int m_unit;
+  const float* fuse_w;      // out_mode 2: predictor weights / bias / unit scatter
+  const int* out_units;
+  float fuse_b;
   int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad;
   int M, nchunks, splitk, cps;
   int relu, res_mode, in_relu, out_mode;
@@ -97,7 +100,8 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
   }
 }
 
-// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (4 waves); bf16x3 also 4 = 256x128 (8 waves, dynamic LDS)
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (4 waves); bf16x3 also 4 = 256x128 (8 waves, dynamic LDS); fp32 also 5 = 64x256
+// (one whole deconv quadrant per workgroup: the fused mask-head tail, out_mode 2)
 void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s);
 void launch_conv_glds(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
 void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);

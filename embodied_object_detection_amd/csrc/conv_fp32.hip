@@ -222,6 +222,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_b[r];
   }
+  if constexpr (BM == 64 && BN == 256) {
+    if (p.out_mode == 2) {
+      // Fused mask-head tail: this workgroup holds deconv quadrant `tile_n` (dy, dx) of 64 input pixels for all 256 channels.
+      // Per pixel: sum_co relu(acc + b[co]) * pw[co]; reduced in the lane (4 tiles), across the 32 lanes of a half-wave
+      // (butterfly), then across the two column waves through LDS -- a fixed order, so the result is reproducible.
+      float sred[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sred[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = (wn * TN + j) * 32 + (lane & 31);
+        const float bw = p.bias ? p.bias[co] : 0.f;
+        const float pw = p.fuse_w[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = (acc[0][j][r] + bw) * p.out_scale;
+          if (p.relu) v = fmaxf(v, 0.f);
+          sred[r] += v * pw;
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sred[r] += __shfl_xor(sred[r], off, 64);
+      float* red = lds;      // [wm][wn][32 rows]; the tiles are dead after the loop's final barrier
+      if ((lane & 31) == 0) {
+        const int half = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wm * 2 + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = sred[r];
+      }
+      __syncthreads();
+      if (tid < BM) {
+        const int wr = tid >> 5, rr = tid & 31;
+        const float v = red[(wr * 2 + 0) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr] + p.fuse_b;
+        const int m = m0 + tid;
+        if (m < M) {
+          const int tq = (int)fdiv((unsigned)m, p.div_ow);
+          const int ox = m - tq * p.OW;
+          const int img = (int)fdiv((unsigned)tq, p.div_oh);
+          const int oy = tq - img * p.OH;
+          const int unit = p.out_units ? p.out_units[img] : img;
+          const int dy = tile_n >> 1, dx = tile_n & 1;
+          p.y[((size_t)unit * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx] = eod_sigmoid_precise(v);
+        }
+      }
+      return;
+    }
+  }
   store_wave_tiles<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
 }
 
@@ -243,6 +291,7 @@ static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hi
 
 void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s) {
   switch (tile) {
+    case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), 0, s, a); break;
     case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s); break;
     case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s); break;
     default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s); break;

@@ -78,7 +78,8 @@ struct Plan {
 };
 
 Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
-  static const int cfg[4][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}};   // the last one: bf16x3 8-wave kernel only
+  // 256x128: bf16x3 8-wave kernel only; 64x256: fused mask-head tail (out_mode 2) only
+  static const int cfg[5][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {64, 256}};
   Plan pl{};
   // Measured on MI355X (tools/conv_bench.py, profiles/r01_conv_bench.log): the 64x64 tile (7 waves/SIMD, finest
   // tile quantisation over 256 CUs) is the fastest or ties on every shape of this path, including the
@@ -98,7 +99,11 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     // 128x128 once it fills two workgroups per CU, else the finest tile
     pick = t256 >= 256 ? 3 : (t128 >= 512 ? 0 : 2);
   }
-  pl.bk = pl.glds ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
+  if (d->out_mode == 2) {   // one workgroup owns all 256 channels of a deconv quadrant; fp32 kernel in every arithmetic mode
+    pick = 4;
+    pl.glds = 0;
+  }
+  pl.bk = (pl.glds || d->out_mode == 2) ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
   const int nchunks = d->Kpad / pl.bk;
   (void)nchunks32;
   pl.nchunks = nchunks;
@@ -109,7 +114,9 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   pl.tiles_n = (d->Cout + pl.bn - 1) / pl.bn;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = 1;
-  if (d->force_splitk > 0) {
+  if (d->out_mode == 2) {
+    splitk = 1;
+  } else if (d->force_splitk > 0) {
     splitk = d->force_splitk;
   } else if (tiles < 256 && nchunks >= 8) {
     int want = (int)((512 + tiles - 1) / tiles);
@@ -154,6 +161,13 @@ int check_desc(const EodConvDesc* d) {
   if (d->KH * d->KW > 64) return EOD_ERR_BAD_DIMS;
   if ((long)total_rows(d) * (d->Cout > d->Cin ? d->Cout : d->Cin) >= (1L << 31)) return EOD_ERR_BAD_DIMS;
   if (d->out_mode == 1 && (d->Cout % 4 != 0)) return EOD_ERR_BAD_DIMS;
+  if (d->out_mode == 2) {
+    if (d->Cout != 1024 || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->tap4 || d->levels > 0 || d->res_mode != 0 || d->in_relu ||
+        d->force_splitk > 1)
+      return EOD_ERR_BAD_DIMS;
+    if (!d->fuse_w) return EOD_ERR_NULL;
+  }
+  if (d->out_mode < 0 || d->out_mode > 2) return EOD_ERR_BAD_DIMS;
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
@@ -187,6 +201,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
   a.partial = d->workspace;
   a.m_count = d->m_count; a.m_unit = d->m_unit;
+  a.fuse_w = d->fuse_w; a.out_units = d->out_units; a.fuse_b = d->fuse_b;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
   a.M = total_rows(d);

@@ -85,6 +85,9 @@ class DeticCascadeROIHeads:
         self.det_masks = torch.zeros((D, 28, 28), **f32)
         self.prop_masks = torch.zeros((R, 28, 28), **f32)
         self._prop_bufs = None      # second activation set, allocated when the proposal pass runs on its own stream
+        # deconv + ReLU + predictor + sigmoid in ONE launch (the [rois,28,28,256] activation never goes to memory); False keeps
+        # the two-launch form (used by the tests as the cross-check)
+        self.fuse_mask_tail = True
         self.selector = ops.DetectionSelector(R, self.C1, self.topk, device)
 
     # ---- cascade box heads ------------------------------------------------------------------------
@@ -123,8 +126,11 @@ class DeticCascadeROIHeads:
         for conv in self.mask_convs:
             conv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=dst)
             src, dst = dst, src
-        self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=mup)
-        ops.mask_predictor_sigmoid(mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out, out_units=rows)
+        if self.fuse_mask_tail:
+            self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=out, fuse=(self.pred_w, self.pred_b, rows))
+        else:
+            self.deconv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=mup)
+            ops.mask_predictor_sigmoid(mup, self.pred_w, self.pred_b, cap * 784, 256, count, 784, out=out, out_units=rows)
         return out
 
     def forward(self, views, shapes, prop_boxes, prop_scores, prop_count, image_hw):

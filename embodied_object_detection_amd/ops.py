@@ -126,9 +126,16 @@ class Conv:
     def __call__(self, x: torch.Tensor, N: int, H: int, W: int, *, res: Optional[torch.Tensor] = None, res_mode: int = 0,
                  relu: bool = False, in_relu: bool = False, out_scale: float = 1.0, m_count: Optional[torch.Tensor] = None,
                  m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0,
-                 levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None) -> torch.Tensor:
-        """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list."""
+                 levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
+                 fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+        """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
+        `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
+        in one launch, `out` = [units, 2H, 2W] probabilities (out_mode 2 of include/eod_hip.h)."""
         _need_cuda(x, res, out)
+        if fuse is not None:
+            if self.out_mode != 1 or out is None:
+                raise ValueError("fuse= needs a deconv layer and an explicit probability buffer `out`")
+            _need_cuda(fuse[0], fuse[2])
         OH, OW = self.out_hw(H, W) if levels is None else (0, 0)
         if levels is not None and out is None:
             out = torch.empty((levels[0][-1], self.Cout), dtype=torch.float32, device=x.device)
@@ -143,6 +150,10 @@ class Conv:
         d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, self.Cin, OH, OW, self.Cout
         d.KH, d.KW, d.stride, d.pad, d.Kpad = self.KH, self.KW, self.stride, self.pad, self.Kpad
         d.relu, d.res_mode, d.in_relu, d.out_mode, d.tap4 = int(relu), res_mode, int(in_relu), self.out_mode, self.tap4
+        if fuse is not None:
+            d.out_mode, d.fuse_w, d.fuse_b, d.out_units = 2, fuse[0].data_ptr(), float(fuse[1]), _ptr(fuse[2])
+        else:
+            d.fuse_w, d.fuse_b, d.out_units = None, 0.0, None
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
         if levels is not None:
             off, shapes = levels

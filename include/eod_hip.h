@@ -56,7 +56,8 @@ typedef struct EodConvDesc {
   int32_t relu;      /* ReLU on the output */
   int32_t res_mode;  /* 0 none, 1 same-shape add, 2 add nearest-x2-upsampled res [N,OH/2,OW/2,Cout] */
   int32_t in_relu;   /* ReLU applied to x on load (p7 = conv(relu(p6)), timm.py:362) */
-  int32_t out_mode;  /* 0 NHWC, 1 ConvTranspose2d(k2,s2) scatter: n = (dy*2+dx)*Cout/4 + co */
+  int32_t out_mode;  /* 0 NHWC, 1 ConvTranspose2d(k2,s2) scatter: n = (dy*2+dx)*Cout/4 + co, 2 = mode 1 fused with the mask
+                        predictor (see fuse_w below) */
   int32_t tap4;      /* 1: Cin == 4 (stem, RGB padded to 4): one float4 per tap */
   int32_t force_tile; /* 0 auto, else tile + 10 * variant: tile 1=128x128 2=128x64 3=64x64; variant 0 default, 1 BK=32, 2 BK=64,
                          4 LDS-DMA staging (experimental), 5 bf16x3 split math (benchmarks/tests) */
@@ -68,6 +69,14 @@ typedef struct EodConvDesc {
   int32_t level_off[6];
   int32_t level_h[5];
   int32_t level_w[5];
+  /* out_mode 2 -- tail of the mask head in one launch (d2 MaskRCNNConvUpsampleHead deconv + ReLU -> predictor 1x1 conv to one
+   * channel, then mask_rcnn_inference's sigmoid; via detic_roi_heads.py:257,268 and custom_rcnn.py:574):
+   *   y[u][2oy+dy][2ox+dx] = sigmoid( sum_co relu(deconv(x)[img][2oy+dy][2ox+dx][co]) * fuse_w[co] + fuse_b )
+   * y is [units, 2OH, 2OW] probabilities; Cout/4 must be 256; u = out_units ? out_units[img] : img (scatter of a compact
+   * ROI list back to per-proposal rows); the 4 x 256-channel deconv activation never goes to memory. */
+  const float* fuse_w;
+  const int32_t* out_units;
+  float fuse_b;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);

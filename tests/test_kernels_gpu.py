@@ -124,6 +124,40 @@ def test_conv_math_mode_switch(dev):
         ops.set_conv_math("fp16")
 
 
+@pytest.mark.parametrize("scatter", [False, True])
+def test_deconv_predictor_sigmoid_fused(dev, scatter):
+    """out_mode 2: ConvTranspose2d(k2,s2) + ReLU + 1x1 predictor + sigmoid in one launch == the torch chain; also with a
+    device-side ROI count and the unit scatter of the lazy variant."""
+    from embodied_object_detection_amd import ops
+    R, Cc = 7, 256
+    x = rnd(R, Cc, 14, 14, seed=31)
+    wd = rnd(Cc, Cc, 2, 2, seed=32, scale=0.05)
+    bd = rnd(Cc, seed=33, scale=0.1)
+    pw = rnd(1, Cc, 1, 1, seed=34, scale=0.1)
+    pb = 0.3
+    ref = torch.sigmoid(F.conv2d(F.relu(F.conv_transpose2d(x, wd, bd, stride=2)), pw, torch.tensor([pb])))[:, 0]   # [R,28,28]
+    conv = ops.Conv(wd, bd, device=dev, deconv=True)
+    xd = nhwc(x).to(dev)
+    count = torch.tensor([5], dtype=torch.int32, device=dev)
+    out = torch.full((R, 28, 28), -1.0, device=dev)
+    rows = torch.tensor([6, 0, 3, 2, 5, 0, 0], dtype=torch.int32, device=dev) if scatter else None
+    conv(xd, R, 14, 14, relu=True, m_count=count, m_unit=196, out=out, fuse=(pw.reshape(-1).contiguous().to(dev), pb, rows))
+    got = out.cpu()
+    if scatter:
+        for k, u in enumerate([6, 0, 3, 2, 5]):
+            close(got[u], ref[k], rtol=1e-5, atol=1e-5)
+        assert bool((got[1] == -1).all()) and bool((got[4] == -1).all())        # rows nobody maps to stay untouched
+    else:
+        close(got[:5], ref[:5], rtol=1e-5, atol=1e-5)
+        assert bool((got[5:] == -1).all())                                        # beyond the device-side count
+    # and it equals the two-launch form
+    mup = conv(xd, R, 14, 14, relu=True)
+    two = ops.mask_predictor_sigmoid(mup, pw.reshape(-1).contiguous().to(dev), pb, R * 784, Cc, None, 784,
+                                     out=torch.empty((R, 28, 28), device=dev))
+    if not scatter:
+        close(got[:5], two.cpu()[:5], rtol=1e-6, atol=1e-6)
+
+
 def test_conv_epilogues(dev):
     from embodied_object_detection_amd import ops
     N, H, W, Cin, Cout = 1, 12, 16, 64, 96

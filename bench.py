@@ -156,7 +156,10 @@ def main():
     log('model built')
 
     headline_math = ops.get_conv_math()          # "fp32" unless EOD_CONV_MATH=bf16x3 is exported
-    n_frames = args.steps + args.warmup
+    # one frame more than is processed: the model starts the NEXT frame's memory-independent bottom-up pass during a step
+    # (look-ahead, model.prefetch_trunk), so the last timed step must have a next frame for the timed region to contain exactly
+    # `steps` bottom-up passes (the first timed frame's was computed during the last warm-up step)
+    n_frames = args.steps + args.warmup + 1
     seq = SyntheticSequence(rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell,
                             projector=None)
     host_frames = [seq.frame(i) for i in range(n_frames)]
@@ -185,7 +188,8 @@ def main():
     def step(i, record):
         if frames[i]["memory_reset"]:
             model.reset_memory(seq.n_cells)      # custom_rcnn.py:470-479
-        out = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=False)
+        out = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=False,
+                                    next_frame=frames[i + 1] if i + 1 < n_frames else None)
         if record:
             counts.append((model.last_stats["prop_count"].clone(), model.last_stats["det_count"].clone(),
                            model.last_stats["mem_k"].clone()))
@@ -199,7 +203,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_frames):
+    for i in range(args.warmup, n_frames - 1):
         step(i, True)
     torch.cuda.synchronize()
     barrier()
@@ -237,7 +241,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         tv = time.perf_counter()
-        for i in range(args.warmup, n_frames):
+        for i in range(args.warmup, n_frames - 1):
             step(i, False)
         torch.cuda.synchronize()
         barrier()
@@ -266,7 +270,7 @@ def main():
             ev2.clear()
             barrier()
             tv = time.perf_counter()
-            for i in range(args.warmup, n_frames):
+            for i in range(args.warmup, n_frames - 1):
                 step(i, False)
             torch.cuda.synchronize()
             barrier()
@@ -325,7 +329,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             tv = time.perf_counter()
-            for i in range(args.warmup, n_frames):
+            for i in range(args.warmup, n_frames - 1):
                 mstep(i)
             torch.cuda.synchronize()
             barrier()
@@ -338,7 +342,7 @@ def main():
 
     # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
     rec = RecordBuffer(max_rows=4 * 108)
-    for j, i in enumerate(range(args.warmup, n_frames)):
+    for j, i in enumerate(range(args.warmup, n_frames - 1)):
         if j % max(1, args.steps // 4) == 0 and j // max(1, args.steps // 4) < 4:
             inst = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=True)["instances"]
             n = min(len(inst), 100)
@@ -400,6 +404,10 @@ def main():
                                    f"(BASELINE.json configs[2]/[3])",
                        "image": f"{H}x{W}", "memory_cells": map_w * map_h, "weights": "random-init (synthetic_state_dict seed 0)",
                        "memory_cls_score_thresh": args.memory_thresh,
+                       "schedule": ("3 HIP streams per scene: main (FPN + memory fusion, proposals, both mask passes), side (box "
+                                    "cascade, memory selection + write-back), look-ahead (the next frame's memory-independent "
+                                    "ResNet trunk); every step does one frame's full work, results bitwise equal to one stream"
+                                    if model.overlap_branches else "one HIP stream"),
                        "proposals_per_frame_mean": round(float(np.mean(pc)), 1), "detections_per_frame_mean": round(float(np.mean(dc)), 1),
                        "memory_instances_per_frame_mean": round(float(np.mean(mk)), 1)},
             "roofline": roofline,

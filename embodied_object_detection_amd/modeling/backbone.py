@@ -110,10 +110,12 @@ class CustomRecurrentFPN:
             self._plans[key] = (shapes, off, feats, views, pooled)
         return self._plans[key]
 
-    def forward(self, x4: torch.Tensor, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor]):
-        """-> (feats [P_total,256], level views, level shapes, level offsets)."""
+    def forward(self, x4: Optional[torch.Tensor], H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor],
+                trunk: Optional[dict] = None):
+        """-> (feats [P_total,256], level views, level shapes, level offsets).  `trunk`: bottom-up features computed earlier
+        (`self.bottom_up.forward` of the same image; they do not depend on the memory)."""
         shapes, off, feats, views, pooled = self._plan(H, W)
-        c = self.bottom_up.forward(x4, H, W)
+        c = trunk if trunk is not None else self.bottom_up.forward(x4, H, W)
         (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
         assert (h3, w3) == shapes[0] and (h5, w5) == shapes[2]
         # top-down (timm.py:118-136): lateral 1x1, + nearest x2 of the coarser level, 3x3 output

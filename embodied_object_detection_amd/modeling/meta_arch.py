@@ -63,6 +63,12 @@ class CustomRCNNRecurrent:
         self.overlap_branches = True
         self._side_stream = None
         self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = None
+        # Look-ahead: the ResNet trunk does not read the memory, so the NEXT frame's bottom-up pass (known from the inner frame
+        # list of `forward`, or passed as `next_frame`) is enqueued on a third stream while this frame's mask passes run.
+        self.prefetch_trunk = True
+        self._trunk_stream = None
+        self._ev_trunk = None
+        self._prefetched = None      # (image object of the frame, padded H, W, bottom-up features)
         self.overlap_memory_write = True    # also the memory selection + write-back, beside the detection mask pass
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
@@ -155,7 +161,8 @@ class CustomRCNNRecurrent:
                 if self.implicit_memory is None:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
-                out = self.inference_frame(frame, refresh_memory_snapshot=refresh)
+                nxt = input_seq[i + 1] if i + 1 < len(input_seq) else None
+                out = self.inference_frame(frame, refresh_memory_snapshot=refresh, next_frame=nxt)
                 if self.save_semmap and i == 0:
                     self.save_memory_snapshot(frame["sequence_name"])          # custom_rcnn.py:518-530
                 batch_output.append(out)
@@ -179,10 +186,26 @@ class CustomRCNNRecurrent:
             p = p.to(torch.int32)
         return p.to(self.device, non_blocking=True).contiguous()
 
-    def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True):
-        """One frame: `inference` (custom_rcnn.py:548-582) + `update_implicit_memory` (681-760)."""
-        image = self._device_image(frame)
-        _, H, W = image.shape
+    def _enqueue_trunk(self, frame: dict):
+        """Bottom-up pass of a coming frame on the trunk stream; must be called after `_ev_props` of the current frame was
+        recorded (the previous look-ahead has been consumed by then, which also makes the allocator's reuse safe)."""
+        if self._trunk_stream is None:
+            self._trunk_stream = torch.cuda.Stream(device=self.device)
+            self._ev_trunk = torch.cuda.Event()
+        ts = self._trunk_stream
+        ts.wait_event(self._ev_props)
+        with torch.cuda.stream(ts):
+            image = self._device_image(frame)
+            x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
+            c = self.backbone.bottom_up.forward(x4, Hp, Wp)
+            self._ev_trunk.record(ts)
+        self._prefetched = (frame["image"], Hp, Wp, c)
+
+    def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
+                        next_frame: Optional[dict] = None):
+        """One frame: `inference` (custom_rcnn.py:548-582) + `update_implicit_memory` (681-760).  `next_frame` (optional) is the
+        frame the caller will pass next: its memory-independent bottom-up pass is started early."""
+        H, W = int(frame["image"].shape[-2]), int(frame["image"].shape[-1])
         if H % 32 or W % 32:
             raise ValueError("H and W must be multiples of 32 (proj_indices is not padded: SURVEY §8 notation)")
         proj = self._device_proj(frame)
@@ -198,8 +221,14 @@ class CustomRCNNRecurrent:
                 ops.memory_normalize_f16(self.implicit_memory, self.observations, out=self._mem_f16)
             mem_f16 = self._mem_f16
 
-        x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
-        feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is frame["image"]:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
+            feats, views, shapes, off = self.backbone.forward(None, pre[1], pre[2], mem_f16, proj, trunk=pre[3])
+        else:
+            x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
+            feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj)
+        del pre
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
@@ -210,6 +239,8 @@ class CustomRCNNRecurrent:
                 self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)     # the small launches go first
                 self._ev_props, self._ev_pm, self._ev_box, self._ev_mem = (torch.cuda.Event() for _ in range(4))
             self._ev_props.record(main)
+            if next_frame is not None and self.prefetch_trunk:
+                self._enqueue_trunk(next_frame)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
                 det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(

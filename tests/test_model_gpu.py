@@ -336,3 +336,26 @@ def test_fused_mask_tail_matches_two_launch_form(setup):
     for a, b in zip(ra, rb):
         assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
         assert (a.pred_masks != b.pred_masks).float().mean().item() < 1e-4
+
+
+def test_trunk_lookahead_gives_identical_results(setup):
+    """The next frame's bottom-up pass, started early on its own stream (inner frame list of `forward`), changes nothing: an
+    episode passed as ONE list equals frame-by-frame calls without look-ahead, bit for bit; a wrong hint is ignored."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    a = build_model(_cfg(), sd)
+    a.prefetch_trunk = False
+    ra = [a([[f]])[0]["instances"] for f in frames]
+    b = build_model(_cfg(), sd)
+    rb = [o["instances"] for o in b([frames])]                       # look-ahead inside the episode
+    c = build_model(_cfg(), sd)
+    rc = []
+    for i, f in enumerate(frames):                                   # deliberately wrong hints
+        if f["memory_reset"]:
+            c.reset_memory(setup["n_cells"])
+        rc.append(c.inference_frame(f, next_frame=frames[0])["instances"])
+    for other, m in ((rb, b), (rc, c)):
+        assert torch.equal(a.implicit_memory, m.implicit_memory) and torch.equal(a.observations, m.observations)
+        for x, y in zip(ra, other):
+            assert torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor) and torch.equal(x.scores, y.scores)
+            assert torch.equal(x.pred_masks, y.pred_masks)

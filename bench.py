@@ -205,10 +205,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, n_frames - 1):
         step(i, True)
+    host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f'host enqueue time {host_enqueue / args.steps * 1e3:.2f} ms/frame')
     log(f'timed region: {elapsed:.3f} s for {args.steps} frames')
     for conv in model.roi_heads.mask_convs:
         conv.event_log = None

@@ -97,8 +97,10 @@ class CustomRecurrentFPN:
         h7, w7 = self.p7.out_hw(h6, w6)
         return hw + [(h6, w6), (h7, w7)]
 
-    def _plan(self, H: int, W: int):
-        key = (H, W)
+    def _plan(self, H: int, W: int, which: int = 0):
+        """Buffers of one pyramid; `which` in {0, 1}: two sets, so that the next frame's top-down pass can be written while the
+        current frame's ROI passes still read theirs."""
+        key = (H, W, which)
         if key not in self._plans:
             shapes = self.level_shapes(H, W)
             off = [0]
@@ -110,22 +112,23 @@ class CustomRecurrentFPN:
             self._plans[key] = (shapes, off, feats, views, pooled)
         return self._plans[key]
 
-    def forward(self, x4: Optional[torch.Tensor], H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor],
-                trunk: Optional[dict] = None):
-        """-> (feats [P_total,256], level views, level shapes, level offsets).  `trunk`: bottom-up features computed earlier
-        (`self.bottom_up.forward` of the same image; they do not depend on the memory)."""
-        shapes, off, feats, views, pooled = self._plan(H, W)
-        c = trunk if trunk is not None else self.bottom_up.forward(x4, H, W)
+    def top_down(self, c: dict, H: int, W: int, which: int = 0):
+        """Memory-independent half (timm.py:118-136): lateral 1x1, + nearest x2 of the coarser level, 3x3 output -> P3..P5 of
+        buffer set `which`."""
+        shapes, off, feats, views, pooled = self._plan(H, W, which)
         (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
         assert (h3, w3) == shapes[0] and (h5, w5) == shapes[2]
-        # top-down (timm.py:118-136): lateral 1x1, + nearest x2 of the coarser level, 3x3 output
         lat5 = self.lateral[5](c5, 1, h5, w5)
         self.output[5](lat5, 1, h5, w5, out=views[2])
         lat4 = self.lateral[4](c4, 1, h4, w4, res=lat5, res_mode=2)
         self.output[4](lat4, 1, h4, w4, out=views[1])
         lat3 = self.lateral[3](c3, 1, h3, w3, res=lat4, res_mode=2)
         self.output[3](lat3, 1, h3, w3, out=views[0])
-        # memory read + fusion (timm.py:142-192)
+
+    def fuse_memory_and_top(self, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor], which: int = 0):
+        """Memory read + fusion into P3..P5 (timm.py:142-192), then P6/P7 on the fused P5 (timm.py:200-205, 359-364)."""
+        shapes, off, feats, views, pooled = self._plan(H, W, which)
+        h5, w5 = shapes[2]
         if self.memory_type == "implicit_memory" and self.feat_fusion != "image_only":
             if memory_f16 is None or proj is None:
                 raise ValueError("implicit_memory needs the fp16 memory table and proj_indices")
@@ -136,10 +139,15 @@ class CustomRecurrentFPN:
                     self.merge[i](pooled[i], 1, h, w, res=views[i], res_mode=1, out_scale=self.map_feature_weight, out=views[i])
                 else:  # mem_only
                     self.merge[i](pooled[i], 1, h, w, out_scale=self.map_feature_weight, out=views[i])
-        # top block on the fused p5 (timm.py:200-205, 359-364)
         self.p6(views[2], 1, h5, w5, out=views[3])
         self.p7(views[3], 1, shapes[3][0], shapes[3][1], in_relu=True, out=views[4])
         return feats, views, shapes, off
+
+    def forward(self, x4: torch.Tensor, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor],
+                which: int = 0):
+        """-> (feats [P_total,256], level views, level shapes, level offsets)."""
+        self.top_down(self.bottom_up.forward(x4, H, W), H, W, which)
+        return self.fuse_memory_and_top(H, W, memory_f16, proj, which)
 
 
 @BACKBONE_REGISTRY.register()

@@ -23,6 +23,20 @@ from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR
 from ..structures import Boxes, Instances
 
 
+# The scheduling streams are created ONCE per device and shared by every model of the process: HIP multiplexes streams onto a
+# few hardware queues, and two of a model's streams landing on the same queue would silently serialise them (measured: 127 vs
+# 104 frames/s for otherwise identical runs when each model created its own).  Models of one process run from one host thread,
+# so sharing the streams only adds the ordering that already exists.
+_SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+
+
+def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, torch.cuda.Stream]:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SCHED_STREAMS:
+        _SCHED_STREAMS[idx] = (torch.cuda.Stream(device=device, priority=-1), torch.cuda.Stream(device=device, priority=-1))
+    return _SCHED_STREAMS[idx]
+
+
 @META_ARCH_REGISTRY.register()
 class CustomRCNNRecurrent:
     def __init__(self, cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -63,12 +77,15 @@ class CustomRCNNRecurrent:
         self.overlap_branches = True
         self._side_stream = None
         self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = None
-        # Look-ahead: the ResNet trunk does not read the memory, so the NEXT frame's bottom-up pass (known from the inner frame
-        # list of `forward`, or passed as `next_frame`) is enqueued on a third stream while this frame's mask passes run.
+        # Look-ahead: the ResNet trunk does not read the memory, so the NEXT frame's bottom-up pass and FPN top-down convs (known from the
+        # inner frame list of `forward`, or passed as `next_frame`) are enqueued on a third stream while this frame's mask passes
+        # run; they write the other of two pyramid buffer sets.
         self.prefetch_trunk = True
+        self.lookahead_first = True      # enqueue the look-ahead before (True) or after (False) this frame's mask passes
         self._trunk_stream = None
         self._ev_trunk = None
-        self._prefetched = None      # (image object of the frame, padded H, W, bottom-up features)
+        self._prefetched = None      # (image object of the frame, padded H, W)
+        self._pyramid = 0            # which of the two FPN buffer sets the current frame uses
         self.overlap_memory_write = True    # also the memory selection + write-back, beside the detection mask pass
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
@@ -190,16 +207,18 @@ class CustomRCNNRecurrent:
         """Bottom-up pass of a coming frame on the trunk stream; must be called after `_ev_props` of the current frame was
         recorded (the previous look-ahead has been consumed by then, which also makes the allocator's reuse safe)."""
         if self._trunk_stream is None:
-            self._trunk_stream = torch.cuda.Stream(device=self.device)
+            # high priority like the side stream: its ~75 launches are small and must not queue behind the mask GEMMs' thousands
+            # of workgroups
+            self._trunk_stream = _sched_streams(self.device)[1]
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
         ts.wait_event(self._ev_props)
         with torch.cuda.stream(ts):
             image = self._device_image(frame)
             x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
-            c = self.backbone.bottom_up.forward(x4, Hp, Wp)
+            self.backbone.top_down(self.backbone.bottom_up.forward(x4, Hp, Wp), Hp, Wp, self._pyramid ^ 1)
             self._ev_trunk.record(ts)
-        self._prefetched = (frame["image"], Hp, Wp, c)
+        self._prefetched = (frame["image"], Hp, Wp)
 
     def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
                         next_frame: Optional[dict] = None):
@@ -222,13 +241,15 @@ class CustomRCNNRecurrent:
             mem_f16 = self._mem_f16
 
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] is frame["image"]:
+        if pre is not None:
+            # whatever was started ahead (used or not) must be finished before this frame touches either pyramid set
             torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
-            feats, views, shapes, off = self.backbone.forward(None, pre[1], pre[2], mem_f16, proj, trunk=pre[3])
+        if pre is not None and pre[0] is frame["image"]:
+            self._pyramid ^= 1          # the look-ahead wrote P3..P5 (memory-independent half) into the other buffer set
+            feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid)
         else:
             x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
-            feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj)
-        del pre
+            feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj, self._pyramid)
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
@@ -236,31 +257,34 @@ class CustomRCNNRecurrent:
         if self.overlap_branches and not self.lazy_proposal_masks:
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)     # the small launches go first
+                self._side_stream = _sched_streams(self.device)[0]     # high priority: the small launches go first
                 self._ev_props, self._ev_pm, self._ev_box, self._ev_mem = (torch.cuda.Event() for _ in range(4))
             self._ev_props.record(main)
-            if next_frame is not None and self.prefetch_trunk:
+            if next_frame is not None and self.prefetch_trunk and self.lookahead_first:
                 self._enqueue_trunk(next_frame)
+            # Host enqueue order matters (the GPU runs behind the host here): first the large launches of the main stream, then
+            # the side stream's ~45 small ones, the look-ahead's ~75 last -- they all execute beside the two mask passes.
+            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
+                                                            bufs=self.roi_heads.proposal_pass_buffers())
+            self._ev_pm.record(main)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
                 det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(
                     views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
                 self._ev_box.record(self._side_stream)
-                if update_mem and self.overlap_memory_write:
-                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
-                                                            bufs=self.roi_heads.proposal_pass_buffers())
+            main.wait_event(self._ev_box)
+            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
             if update_mem and self.overlap_memory_write:
                 # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
                 # stream beside the detection mask pass; the main stream joins at the end of the frame
-                self._ev_pm.record(main)
-                self._side_stream.wait_event(self._ev_pm)
                 with torch.cuda.stream(self._side_stream):
+                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                    self._side_stream.wait_event(self._ev_pm)
                     self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
                     self._ev_mem.record(self._side_stream)
                 mem_done = True
-            main.wait_event(self._ev_box)
-            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            if next_frame is not None and self.prefetch_trunk and not self.lookahead_first:
+                self._enqueue_trunk(next_frame)
         else:
             det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
                 views, shapes, prop_boxes, prop_scores, prop_count, (H, W))

@@ -5,8 +5,9 @@ every inner sequence, three datasets named `semmap` (int32 [N]), `impicit_memory
 (float32 [N]) in `<OUTPUT_DIR>/memory/<sequence_name>`.  Reader: `SMNetDetectionLoader` (SMNet/loader.py:216-223) loads the same
 three names from `MODEL.SEMMAP_PATH/<file>` and shifts the labels by +1 (empty space -1 -> 0).
 
-The reference container is HDF5 through h5py, which this image does not have; the datasets keep their names, dtypes and shapes
-inside a NumPy `.npz` archive instead (`np.load(path)[name]` replaces `h5py.File(path)[name]`).
+The container is HDF5 like the reference's (written / read through `data/h5io.py`, libhdf5 via ctypes; the reference uses h5py) at
+exactly the reference's path.  Only when no libhdf5 can be loaded the same datasets go into a NumPy `.npz` archive next to that
+path (`<name>.npz`); the reader accepts both.
 """
 from __future__ import annotations
 
@@ -28,8 +29,16 @@ def snapshot_path(directory: str, sequence_name: str) -> str:
 def write_snapshot(output_dir: str, sequence_name: str, semmap: np.ndarray, implicit_memory: np.ndarray,
                    observations: np.ndarray) -> str:
     """custom_rcnn.py:520-530; returns the path written."""
+    from . import h5io
     d = os.path.join(output_dir, "memory")
     os.makedirs(d, exist_ok=True)
+    if h5io.available():
+        path = os.path.join(d, sequence_name)
+        with h5io.H5File(path, "w") as f:
+            f.write(KEY_SEMMAP, semmap, dtype=np.int32)
+            f.write(KEY_MEMORY, implicit_memory, dtype=np.float32)
+            f.write(KEY_OBS, observations, dtype=np.float32)
+        return path
     path = snapshot_path(d, sequence_name)
     with open(path, "wb") as f:
         np.savez(f, **{KEY_SEMMAP: np.asarray(semmap, dtype=np.int32), KEY_MEMORY: np.asarray(implicit_memory, dtype=np.float32),
@@ -42,6 +51,11 @@ def read_snapshot(semmap_path: str, file: str, fallback_memory: Optional[np.ndar
     loader falls back to the offline memory and `None` for the other two."""
     if not os.path.exists(semmap_path):
         return {"semmap_real": None, "implicit_memory": fallback_memory, "observations": None}
+    exact = os.path.join(semmap_path, file)
+    if os.path.exists(exact) and not exact.endswith(".npz"):
+        from .h5io import H5File
+        with H5File(exact) as f:
+            return {"semmap_real": f.read(KEY_SEMMAP) + 1, "implicit_memory": f.read(KEY_MEMORY), "observations": f.read(KEY_OBS)}
     with np.load(snapshot_path(semmap_path, file)) as z:
         return {"semmap_real": np.array(z[KEY_SEMMAP]) + 1, "implicit_memory": np.array(z[KEY_MEMORY]),
                 "observations": np.array(z[KEY_OBS])}

@@ -97,8 +97,12 @@ def inference_on_scenes(model, scenes: Iterable, rank: int = 0, max_rows: int = 
                         rec.add([KIND_DET, sid, im_id, float(c[j]), float(s[j]), *b[j].tolist(), idx])
                 gt = inp.get("instances")
                 if gt is not None:
-                    gb = gt_to_coco_xyxy(gt["gt_boxes"])
-                    gc = gt["gt_classes"].tolist()
+                    if isinstance(gt, dict):                                   # synthetic frames
+                        gboxes, gcls = gt["gt_boxes"], gt["gt_classes"]
+                    else:                                                       # Instances (map_mp3d_batch_to_coco)
+                        gboxes, gcls = gt.gt_boxes.tensor, gt.gt_classes
+                    gb = gt_to_coco_xyxy(gboxes)
+                    gc = gcls.tolist()
                     for j in range(len(gc)):
                         rec.add([KIND_GT, sid, im_id, float(gc[j]), 0.0, *gb[j].tolist(), idx])
                 im_id += 1

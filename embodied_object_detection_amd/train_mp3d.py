@@ -8,8 +8,9 @@
 
 One process per GPU (detectron2 `launch` semantics): either started by `torch.distributed.run` (RANK / WORLD_SIZE in the
 environment) or spawned here for `--num-gpus N`; backend `nccl` (= RCCL over xGMI) on GPUs.  Training (`do_train`) is out
-of scope of the hot path.  The real `mp3d_example` needs the h5 reader (not built yet): without it the
-driver evaluates the deterministic synthetic scenes of SURVEY §8d.
+of scope of the hot path.  The driver reads the reference's on-disk episodes when `MODEL.TEST_DATA_PATH` holds them
+(`memory_data/*.h5`, `sensor_data/*.h5`, `JPEGImages/`: `data/mp3d.py`) and otherwise evaluates the
+deterministic synthetic scenes of SURVEY §8d.
 """
 from __future__ import annotations
 
@@ -40,10 +41,22 @@ def default_argument_parser():
 def do_test(cfg, model, args, rank: int, world: int):
     from .data.synthetic import SyntheticSequence
     from .engine.eval_loop import (episode_offsets, evaluate_gathered, gather_records, inference_on_scenes, shard_scenes)
-    H, W = args.synthetic_size
-    mine = shard_scenes(args.synthetic_scenes, rank, world)
-    scenes = [SyntheticSequence(s, H=H, W=W, n_frames=args.synthetic_frames) for s in mine]
-    offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
+    import os
+    data_root = str(cfg.MODEL.TEST_DATA_PATH)
+    if os.path.isdir(os.path.join(data_root, "memory_data")) and os.path.isdir(os.path.join(data_root, "sensor_data")):
+        # the reference's on-disk episodes (train_mp3d.py:393-413): memory_data/*.h5 + sensor_data/*.h5 + JPEGImages/
+        from .data.mp3d import Mp3dScenes, SMNetDetectionLoader
+        clip_path = cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH if cfg.MODEL.MEMORY_TYPE in ("semantic_gt", "map_gt") else None
+        loader = SMNetDetectionLoader(data_path=data_root, test_type=cfg.MODEL.TEST_TYPE, clip_path=clip_path,
+                                      memory_type=cfg.MODEL.MEMORY_TYPE, semmap_path="")
+        ds = Mp3dScenes(loader)
+        scenes, offs = ds.shard(rank, world), ds.episode_offsets()
+        print(f"[rank {rank}] {len(loader)} episode files in {len(ds)} scenes under {data_root}; this rank: {len(scenes)} scenes")
+    else:
+        H, W = args.synthetic_size
+        mine = shard_scenes(args.synthetic_scenes, rank, world)
+        scenes = [SyntheticSequence(s, H=H, W=W, n_frames=args.synthetic_frames) for s in mine]
+        offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
     res = inference_on_scenes(model, scenes, rank, scene_episode_offset=offs)
     buf = gather_records(res["records"], rank, world, model.device)
     out = None

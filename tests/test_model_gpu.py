@@ -359,3 +359,49 @@ def test_trunk_lookahead_gives_identical_results(setup):
         for x, y in zip(ra, other):
             assert torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor) and torch.equal(x.scores, y.scores)
             assert torch.equal(x.pred_masks, y.pred_masks)
+
+
+def test_on_disk_episodes_drive_the_model(setup, tmp_path):
+    """§8f rank 1 end to end: episode files in the reference's layout (HDF5 + JPEG) -> loader mirror -> frame dicts -> model ->
+    records; identical to feeding the decoded frames by hand."""
+    from embodied_object_detection_amd.data import h5io
+    if not h5io.available():
+        pytest.skip("no libhdf5 in this image")
+    from PIL import Image
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.mp3d import Mp3dScenes, SMNetDetectionLoader
+    from embodied_object_detection_amd.engine.eval_loop import inference_on_scenes
+    frames, sd = setup["frames"], setup["sd"]
+    H, W, n_cells = setup["H"], setup["W"], setup["n_cells"]
+    root = str(tmp_path / "ds")
+    for d in ("memory_data", "sensor_data", "JPEGImages"):
+        os.makedirs(os.path.join(root, d))
+    for ep, chunk in enumerate((frames[:2], frames[2:])):              # one scene, two episodes of two frames
+        name = f"scene_x_{ep}.h5"
+        with h5io.H5File(os.path.join(root, "memory_data", name), "w") as f:
+            f.write("memory_features", np.zeros((n_cells, 256), dtype=np.float32))
+            f.write("semmap_gt", np.zeros((n_cells,), dtype=np.int32))
+            f.write("proj_indices", np.stack([fr["proj_indices"] for fr in chunk]).astype(np.int32))
+        recs = []
+        for i, fr in enumerate(chunk):
+            fn = f"scene_x_{ep}_{i}.png"                               # lossless, so the decoded pixels equal the synthetic frame
+            Image.fromarray(fr["image"].permute(1, 2, 0).numpy()).save(os.path.join(root, "JPEGImages", fn))
+            recs.append(str({"file_name": fn, "image": "x", "gt_boxes": [[4, 4, 20, 30]], "gt_classes": [3]}))
+        with h5io.H5File(os.path.join(root, "sensor_data", name), "w") as f:
+            f.write("segmentation_data", np.zeros((len(chunk), H, W), dtype=np.uint8))
+            f.write_strings("detection_data", recs)
+    ds = Mp3dScenes(SMNetDetectionLoader(data_path=root, test_type="default", memory_type="implicit_memory", semmap_path=""))
+    model = build_model(_cfg(), sd)
+    seen = []
+    res = inference_on_scenes(model, ds.shard(0, 1), 0, every=1, on_episode=lambda idx, inp, out: seen.append((idx, inp, out)),
+                              scene_episode_offset=ds.episode_offsets())
+    assert res["frames"] == 4 and [s[0] for s in seen] == [0, 1]
+    assert [f["memory_reset"] for s in seen for f in s[1]] == [True, False, False, False]
+    ref_model = build_model(_cfg(), sd)
+    ref = [ref_model([[f]])[0]["instances"] for f in frames]
+    got = [o["instances"] for s in seen for o in s[2]]
+    for a, b in zip(ref, got):
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+    assert torch.equal(model.implicit_memory, ref_model.implicit_memory)
+    from embodied_object_detection_amd.evaluation.coco_ap import KIND_GT
+    assert sum(1 for r in res["records"].rows if r[0] == KIND_GT) == 4   # one GT box per frame reached the evaluator

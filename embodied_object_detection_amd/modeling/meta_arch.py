@@ -7,8 +7,10 @@ Mirrors `Detic/detic/modeling/meta_arch/custom_rcnn.py`: `forward` eval branch (
 `CustomRCNN._postprocess` -> detectron2 `detector_postprocess` (579-580).
 
 Call convention: `model(batched_inputs: List[List[dict]]) -> List[dict]`; the module is stateful
-between calls.  The whole frame is enqueued on the current HIP stream with no host synchronisation; the only sync
-per frame is the read-back of the final detection count when the result `Instances` are materialised.
+between calls.  A frame is enqueued with no host synchronisation on the current HIP stream plus two scheduling streams
+(box cascade + memory write; next frame's memory-independent trunk) that fork after the proposals and join before the
+frame ends; the only sync per frame is the read-back of the final detection count when the result `Instances` are
+materialised.
 """
 from __future__ import annotations
 
@@ -73,7 +75,8 @@ class CustomRCNNRecurrent:
         # The proposal mask pass (custom_rcnn.py:573) needs only the proposals and the FPN features, not the box cascade: the
         # cascade's small latency-bound launches (15 FC GEMMs, 3 ROIAligns, the selection sorts) are enqueued on a second,
         # high-priority HIP stream and run beside the proposal pass's large GEMMs.  The detection mask pass follows on the main
-        # stream after both (the two large passes never share the chip).  Same kernels, same inputs, same results; `overlap_branches = False` restores one stream.
+        # stream after both (the two large passes never share the chip).  Same kernels, same inputs, same results;
+        # `overlap_branches = False` restores one stream.
         self.overlap_branches = True
         self._side_stream = None
         self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = None

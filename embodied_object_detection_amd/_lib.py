@@ -32,7 +32,7 @@ class EodConvDesc(C.Structure):
         ("Kpad", C.c_int32), ("relu", C.c_int32), ("res_mode", C.c_int32), ("in_relu", C.c_int32),
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
-        ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float),
+        ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
     ]
 
 
@@ -72,6 +72,8 @@ SIGNATURES = {
     "eod_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(EodConvDesc)]),
     "eod_set_conv_math": (C.c_int, [C.c_int]),
     "eod_get_conv_math": (C.c_int, []),
+    "eod_conv_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "eod_conv_split_weights_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "eod_preprocess_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     "eod_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),

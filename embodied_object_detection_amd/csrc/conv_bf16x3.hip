@@ -19,6 +19,7 @@ namespace {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   f32x2_t v = {a, b};
@@ -268,13 +269,16 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs p) {
 //   * every group of six MFMAs (one 32x32 tile, one K=16 step) carries one staging unit of this thread: split one float4
 //     (22 VALU), three ds_write_b64, one buffer load that refills the raw register with chunk c+2;
 //   * the fragments of the second K=16 step are read while the first one is multiplied.
-template <bool MULTI>
+// WS: the weights come pre-split ([Cout][Kpad/32][xh(32)|xm(32)|xl(32)] bf16, eod_conv_split_weights_bf16x3): their LDS image is
+// a plain copy (three 16-byte pieces per thread and chunk), no split arithmetic for the static operand.
+template <bool MULTI, bool WS>
 __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, BN = 128, BK = 32;
   constexpr int ROWB = 3 * 2 * BK + 16;     // 208
   constexpr int STAGE = (BM + BN) * ROWB;   // 79 872
-  constexpr int AR = 4, BR = 2, UNITS = AR + BR;
+  constexpr int AR = 4, BR = WS ? 0 : 2, UNITS = AR + BR;
+  constexpr int BP = 3;                     // WS: 16-byte weight pieces per thread and chunk (128 rows x 12 pieces / 512 threads)
   extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
   char* lds = lds_dyn;
 
@@ -345,12 +349,34 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
     a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);
     if (MULTI) a_pitch[i] = (unsigned)(ww * p.Cin * 4);
   }
-  unsigned w_voff[BR];
+  unsigned w_voff[BR > 0 ? BR : 1];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
     const int n = n0 + lr + 64 * j;
     w_voff[j] = n < p.Cout ? (unsigned)((n * p.Kpad + 4 * lq) * 4) : 0xFFFFFFFFu;
   }
+  // WS: piece q = tid + 512 u of the [128 rows][12 pieces] weight tile
+  unsigned w3_voff[BP];
+  int w3_lds[BP];
+#pragma unroll
+  for (int u = 0; u < BP; ++u) {
+    const int q = tid + 512 * u;
+    const int row = q / 12, pc = q - row * 12;
+    const int n = n0 + row;
+    w3_voff[u] = n < p.Cout ? (unsigned)(n * (p.Kpad / 32) * 192 + pc * 16) : 0xFFFFFFFFu;
+    w3_lds[u] = (BM + row) * ROWB + pc * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, WS ? p.w3_bytes : 0u, 0x00020000);
+  u32x4_t braw[BP];
+  auto load_w3 = [&](int chunk) {
+    if (chunk > c_end - 1) chunk = c_end - 1;
+#pragma unroll
+    for (int u = 0; u < BP; ++u) braw[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w3, w3_voff[u], chunk * 192, 0);
+  };
+  auto stage_w3 = [&](char* stage) {
+#pragma unroll
+    for (int u = 0; u < BP; ++u) *reinterpret_cast<u32x4_t*>(stage + w3_lds[u]) = braw[u];
+  };
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
@@ -429,6 +455,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
     const TapInfo t1 = tap_info(c_begin + 1);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) load_unit(t1, u);
+    if (WS) {
+      load_w3(c_begin);
+      stage_w3(lds);
+      load_w3(c_begin + 1);
+    }
   }
   in_loop = true;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
@@ -472,6 +503,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
             stage_unit(nxt, g);
             load_unit(tn, g);
           }
+          if (WS && g == UNITS) {      // the weight pieces of chunk c+1 -> other stage, then refill with chunk c+2
+            stage_w3(nxt);
+            load_w3(chunk + 2);
+          }
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -479,7 +514,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
             if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (k >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (WS && g == UNITS) __builtin_amdgcn_sched_group_barrier(0x020, BP, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -490,6 +526,27 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
 }
 
 }  // namespace
+
+// [Cout][Kpad] fp32 -> [Cout][Kpad/32][xh(32) | xm(32) | xl(32)] bf16: the LDS row image of the bf16x3 kernels, 192 B per K chunk
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, size_t quads,
+                                                           int kquads) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / kquads;
+    const int kq = (int)(i - n * kquads);               // float4 index inside the row
+    const Split3 s3 = split3(*reinterpret_cast<const f32x4*>(w + i * 4));
+    unsigned char* dst = out + (n * (kquads / 8) + kq / 8) * 192 + (kq & 7) * 8;
+    *reinterpret_cast<uint2*>(dst) = s3.h;
+    *reinterpret_cast<uint2*>(dst + 64) = s3.m;
+    *reinterpret_cast<uint2*>(dst + 128) = s3.l;
+  }
+}
+
+void launch_split_weights(const float* w, void* out, int Cout, int Kpad, hipStream_t s) {
+  const size_t quads = (size_t)Cout * Kpad / 4;
+  int blocks = (int)((quads + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, s, w, static_cast<unsigned char*>(out), quads, Kpad / 4);
+}
 
 template <int BM, int BN>
 static void launch_b3_tile(const ConvArgs& a, dim3 grid, hipStream_t s) {
@@ -502,13 +559,22 @@ void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s) {
     case 4: {
       constexpr int kLds = 2 * (256 + 128) * 208;
       static const bool attr = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        return true;
+        bool ok = true;
+        for (const void* f : {reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<true, false>),
+                              reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<false, false>),
+                              reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<true, true>),
+                              reinterpret_cast<const void*>(&conv_bf16x3_w8_kernel<false, true>)})
+          ok = (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess) && ok;
+        return ok;
       }();
-      (void)attr;
-      if (a.nlv > 0) hipLaunchKernelGGL((conv_bf16x3_w8_kernel<true>), grid, dim3(512), kLds, s, a);
-      else hipLaunchKernelGGL((conv_bf16x3_w8_kernel<false>), grid, dim3(512), kLds, s, a);
+      (void)attr;      // a refused attribute shows up as a launch error (EOD_ERR_LAUNCH) below
+      if (a.w3) {
+        if (a.nlv > 0) hipLaunchKernelGGL((conv_bf16x3_w8_kernel<true, true>), grid, dim3(512), kLds, s, a);
+        else hipLaunchKernelGGL((conv_bf16x3_w8_kernel<false, true>), grid, dim3(512), kLds, s, a);
+      } else {
+        if (a.nlv > 0) hipLaunchKernelGGL((conv_bf16x3_w8_kernel<true, false>), grid, dim3(512), kLds, s, a);
+        else hipLaunchKernelGGL((conv_bf16x3_w8_kernel<false, false>), grid, dim3(512), kLds, s, a);
+      }
       break;
     }
     case 1: launch_b3_tile<128, 128>(a, grid, s); break;

@@ -37,6 +37,8 @@ struct ConvArgs {
   int nlv;
   int lv_off[6], lv_h[5], lv_w[5];
   unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
+  const void* w3;              // optional pre-split weights of the bf16x3 kernels (eod_conv_split_weights_bf16x3)
+  unsigned w3_bytes;
   FastDiv div_ow, div_oh, div_cd;
 };
 
@@ -105,5 +107,6 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
 void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s);
 void launch_conv_glds(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
 void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
+void launch_split_weights(const float* w, void* out, int Cout, int Kpad, hipStream_t s);
 
 }  // namespace eodconv

@@ -171,7 +171,7 @@ int check_desc(const EodConvDesc* d) {
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
-  if (!eod_aligned16(d->x) || !eod_aligned16(d->w)) return EOD_ERR_ALIGN;
+  if (!eod_aligned16(d->x) || !eod_aligned16(d->w) || !eod_aligned16(d->w_split)) return EOD_ERR_ALIGN;
   return EOD_OK;
 }
 
@@ -183,6 +183,18 @@ extern "C" int eod_set_conv_math(int mode) {
 }
 
 extern "C" int eod_get_conv_math(void) { return math_mode().load(); }
+
+extern "C" size_t eod_conv_split_weights_bytes(int Cout, int Kpad) {
+  return (Cout > 0 && Kpad > 0 && Kpad % 32 == 0) ? (size_t)Cout * Kpad * 6 : 0;
+}
+
+extern "C" int eod_conv_split_weights_bf16x3(const float* w, int Cout, int Kpad, void* out, eod_stream_t stream) {
+  if (!w || !out) return EOD_ERR_NULL;
+  if (Cout <= 0 || Kpad <= 0 || Kpad % 32 != 0 || (long)Cout * Kpad * 6 >= (1L << 32)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(w) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
+  launch_split_weights(w, out, Cout, Kpad, static_cast<hipStream_t>(stream));
+  return eod_launch_status();
+}
 
 extern "C" size_t eod_conv2d_workspace_bytes(const EodConvDesc* d) {
   if (check_desc(d) != EOD_OK) return 0;
@@ -212,6 +224,8 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     const size_t xe = d->levels > 0 ? (size_t)d->level_off[d->levels] * d->Cin : (size_t)d->N * d->H * d->W * d->Cin;
     a.x_bytes = (unsigned)(xe * sizeof(float));
     a.w_bytes = (unsigned)((size_t)d->Cout * d->Kpad * sizeof(float));
+    a.w3 = d->w_split;
+    a.w3_bytes = (unsigned)((size_t)d->Cout * d->Kpad * 6);
   }
   a.nlv = d->levels > 0 ? d->levels : 0;
   for (int l = 0; l < a.nlv; ++l) {

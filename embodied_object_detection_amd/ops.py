@@ -118,6 +118,7 @@ class Conv:
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
         self.desc = EodConvDesc()
         self._lib = _lib.load()
+        self.w_split = None     # bf16x3 pieces of the weights, made on first use in that arithmetic mode
         self.event_log = None   # bench.py: list that receives (start_event, end_event, m_count) per launch
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
@@ -127,7 +128,7 @@ class Conv:
                  relu: bool = False, in_relu: bool = False, out_scale: float = 1.0, m_count: Optional[torch.Tensor] = None,
                  m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0,
                  levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
-                 fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+                 fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True) -> torch.Tensor:
         """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
         `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
         in one launch, `out` = [units, 2H, 2W] probabilities (out_mode 2 of include/eod_hip.h)."""
@@ -164,6 +165,13 @@ class Conv:
                 d.level_h[i], d.level_w[i] = h, w
         else:
             d.levels = 0
+        use_split = force_tile // 10 == 5 if force_tile else (get_conv_math() == "bf16x3")
+        if use_split and self.w_split is None and not self.tap4:
+            nb = self._lib.eod_conv_split_weights_bytes(self.Cout, self.Kpad)
+            self.w_split = torch.empty((nb,), dtype=torch.uint8, device=self.w.device)
+            check(self._lib.eod_conv_split_weights_bf16x3(self.w.data_ptr(), self.Cout, self.Kpad, self.w_split.data_ptr(), _stream()),
+                  f"eod_conv_split_weights_bf16x3[{self.name}]")
+        d.w_split = self.w_split.data_ptr() if (use_split and self.w_split is not None and presplit) else None
         d.workspace, d.workspace_bytes = None, 0
         need = self._lib.eod_conv2d_workspace_bytes(C.byref(d))
         if need:

@@ -77,6 +77,9 @@ typedef struct EodConvDesc {
   const float* fuse_w;
   const int32_t* out_units;
   float fuse_b;
+  /* optional: the same weights pre-split for the bf16x3 kernels (eod_conv_split_weights_bf16x3), Cout * Kpad * 6 bytes; used by
+   * the 256x128 bf16x3 kernel instead of splitting w on the fly; ignored by every other kernel */
+  const void* w_split;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
@@ -91,6 +94,10 @@ size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
 #define EOD_MATH_BF16X3 1
 int eod_set_conv_math(int mode);
 int eod_get_conv_math(void);
+/* w [Cout][Kpad] fp32 -> out [Cout][Kpad/32][ xh(32) | xm(32) | xl(32) ] bf16 (three round-to-nearest bf16 pieces of every
+ * weight, 192 bytes per 32-wide K chunk = the LDS row image of the bf16x3 kernels).  Static weights are split once. */
+size_t eod_conv_split_weights_bytes(int Cout, int Kpad);
+int eod_conv_split_weights_bf16x3(const float* w, int Cout, int Kpad, void* out, eod_stream_t stream);
 
 /* ---- small dense / elementwise ops -------------------------------------------------------------------- */
 /* d2 GeneralizedRCNN.preprocess_image (custom_rcnn.py:557): u8 CHW RGB -> (x-mean)/std, NHWC4 (4th channel

@@ -102,6 +102,25 @@ def test_conv_bf16x3_accuracy(dev, case, spread):
         assert err[name][1] < 3e-6, err
 
 
+@pytest.mark.parametrize("case", [(3, 14, 14, 256, 256, 3, 1, 1), (1, 21, 19, 128, 96, 3, 2, 1), (1, 16, 16, 256, 512, 1, 2, 0)])
+def test_conv_bf16x3_presplit_weights_equal_on_the_fly_split(dev, case):
+    """Weights split once by eod_conv_split_weights_bf16x3 feed the 256x128 kernel the same pieces it would compute itself:
+    bitwise identical outputs (also with N and Cout not multiples of the tile)."""
+    from embodied_object_detection_amd import ops
+    N, H, W, Cin, Cout, k, stride, pad = case
+    x = rnd(N, Cin, H, W, seed=41)
+    w = rnd(Cout, Cin, k, k, seed=42, scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=43)
+    conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
+    xd = nhwc(x).to(dev)
+    y0 = conv(xd, N, H, W, force_tile=54, force_splitk=1, presplit=False).clone()
+    y1 = conv(xd, N, H, W, force_tile=54, force_splitk=1, presplit=True).clone()
+    y2 = conv(xd, N, H, W, force_tile=54, force_splitk=2, presplit=True).clone()
+    assert conv.w_split is not None and torch.equal(y0, y1)
+    close(nchw(y1), F.conv2d(x, w, b, stride=stride, padding=pad))
+    close(y2, y1, rtol=1e-5, atol=1e-5)
+
+
 def test_conv_math_mode_switch(dev):
     """eod_set_conv_math routes force_tile == 0 launches; both modes agree to fp32 noise; unknown modes are refused."""
     from embodied_object_detection_amd import ops

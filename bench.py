@@ -258,6 +258,31 @@ def main():
                                                    "update reads instead of all 256 (the reference computes and discards the rest)"}
         model.lazy_proposal_masks = False
 
+        # worst-case memory write path: MEMORY_CLS_SCORE_THRESH 0.0 keeps up to 100 memory instances per frame
+        thr0 = model.cls_score_thresh
+        model.cls_score_thresh = 0.0
+        ks = []
+        for i in range(args.warmup):
+            step(i, False)
+        torch.cuda.synchronize()
+        barrier()
+        tv = time.perf_counter()
+        for i in range(args.warmup, n_frames - 1):
+            step(i, False)
+            ks.append(model.last_stats["mem_k"].clone())
+        torch.cuda.synchronize()
+        barrier()
+        tv = time.perf_counter() - tv
+        model.cls_score_thresh = thr0
+        if distributed:
+            t = torch.tensor([tv], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tv = float(t.item())
+        variants["memory_cls_score_thresh_0"] = {"value": round(args.steps * world / tv, 3), "unit": "frames/s",
+                                                 "ms_per_step": round(tv / args.steps * 1e3, 3),
+                                                 "memory_instances_per_frame_mean": round(float(np.mean([int(k.item()) for k in ks])), 1),
+                                                 "note": "MODEL.MEMORY_CLS_SCORE_THRESH 0.0: worst-case memory write path"}
+
         # fp32 emulated on the bf16 matrix cores (three-way operand split, six MFMAs per term set, fp32 accumulate): same
         # parity tests, 16/6 of the fp32-MFMA arithmetic ceiling.  Opt-in (EOD_CONV_MATH=bf16x3 / ops.set_conv_math).
         if ops.get_conv_math() == "fp32":

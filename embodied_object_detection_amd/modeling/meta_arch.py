@@ -84,7 +84,8 @@ class CustomRCNNRecurrent:
         # inner frame list of `forward`, or passed as `next_frame`) are enqueued on a third stream while this frame's mask passes
         # run; they write the other of two pyramid buffer sets.
         self.prefetch_trunk = True
-        self.lookahead_first = True      # enqueue the look-ahead before (True) or after (False) this frame's mask passes
+        self.lookahead_at_start = True   # start it at the beginning of the frame (True) or once the proposals exist (False)
+        self._ev_start = None
         self._trunk_stream = None
         self._ev_trunk = None
         self._prefetched = None      # (image object of the frame, padded H, W)
@@ -206,16 +207,17 @@ class CustomRCNNRecurrent:
             p = p.to(torch.int32)
         return p.to(self.device, non_blocking=True).contiguous()
 
-    def _enqueue_trunk(self, frame: dict):
-        """Bottom-up pass of a coming frame on the trunk stream; must be called after `_ev_props` of the current frame was
-        recorded (the previous look-ahead has been consumed by then, which also makes the allocator's reuse safe)."""
+    def _enqueue_trunk(self, frame: dict, after: torch.cuda.Event):
+        """Bottom-up pass + FPN top-down convs of a coming frame on the look-ahead stream, ordered after `after` (an event of the
+        main stream recorded once the previous look-ahead has been consumed and the previous frame has fully finished: the
+        pyramid set written here was last read by that frame)."""
         if self._trunk_stream is None:
             # high priority like the side stream: its ~75 launches are small and must not queue behind the mask GEMMs' thousands
             # of workgroups
             self._trunk_stream = _sched_streams(self.device)[1]
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
-        ts.wait_event(self._ev_props)
+        ts.wait_event(after)
         with torch.cuda.stream(ts):
             image = self._device_image(frame)
             x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
@@ -247,8 +249,18 @@ class CustomRCNNRecurrent:
         if pre is not None:
             # whatever was started ahead (used or not) must be finished before this frame touches either pyramid set
             torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
-        if pre is not None and pre[0] is frame["image"]:
+        hit = pre is not None and pre[0] is frame["image"]
+        if hit:
             self._pyramid ^= 1          # the look-ahead wrote P3..P5 (memory-independent half) into the other buffer set
+        look_ahead = (next_frame is not None and self.prefetch_trunk and self.overlap_branches and not self.lazy_proposal_masks)
+        if look_ahead and self.lookahead_at_start:
+            # start it NOW: while this frame's memory fusion, tower and proposal decoding (a short latency-bound chain that
+            # leaves most of the chip idle) run on the main stream
+            if self._ev_start is None:
+                self._ev_start = torch.cuda.Event()
+            self._ev_start.record(torch.cuda.current_stream(self.device))
+            self._enqueue_trunk(next_frame, self._ev_start)
+        if hit:
             feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid)
         else:
             x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
@@ -263,8 +275,8 @@ class CustomRCNNRecurrent:
                 self._side_stream = _sched_streams(self.device)[0]     # high priority: the small launches go first
                 self._ev_props, self._ev_pm, self._ev_box, self._ev_mem = (torch.cuda.Event() for _ in range(4))
             self._ev_props.record(main)
-            if next_frame is not None and self.prefetch_trunk and self.lookahead_first:
-                self._enqueue_trunk(next_frame)
+            if look_ahead and not self.lookahead_at_start:
+                self._enqueue_trunk(next_frame, self._ev_props)
             # Host enqueue order matters (the GPU runs behind the host here): first the large launches of the main stream, then
             # the side stream's ~45 small ones, the look-ahead's ~75 last -- they all execute beside the two mask passes.
             prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
@@ -286,8 +298,6 @@ class CustomRCNNRecurrent:
                     self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
                     self._ev_mem.record(self._side_stream)
                 mem_done = True
-            if next_frame is not None and self.prefetch_trunk and not self.lookahead_first:
-                self._enqueue_trunk(next_frame)
         else:
             det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
                 views, shapes, prop_boxes, prop_scores, prop_count, (H, W))

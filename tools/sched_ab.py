@@ -26,7 +26,7 @@ for rep in range(2):
     for math in ("fp32", "bf16x3"):
         ops.set_conv_math(math)
         for first in (True, False):
-            m = build_model(cfg, sd); m.lookahead_first = first
-            print(f"{math:7s} lookahead_first={first!s:5s}  {run(m):7.1f} frames/s", flush=True)
+            m = build_model(cfg, sd); m.lookahead_at_start = first
+            print(f"{math:7s} lookahead_at_start={first!s:5s}  {run(m):7.1f} frames/s", flush=True)
             del m
 ops.set_conv_math("fp32")

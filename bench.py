@@ -47,6 +47,21 @@ def parse():
     return ap.parse_args()
 
 
+def frame_roofline(H: int, W: int, n_prop: float, n_det: float, sec_per_frame: float, math: str) -> dict:
+    """Algorithmic FLOPs of one whole frame (2 x MAC of every conv / linear layer) against the time of a frame."""
+    px = (H // 8) * (W // 8)                                   # P3 positions; P4 = /4, P5 = /16, P6 ~ /64, P7 ~ /256
+    lv = px * (1 + 1 / 4 + 1 / 16) + ((H // 64) * (W // 64)) + (-(-H // 128) * -(-W // 128))
+    s = H * W / (640.0 * 640.0)
+    g = {"resnet50": 66.8 * s, "fpn_p6p7": 13.0 * s, "memory_projections": 2.2 * s,
+         "centernet_head": 2.0 * lv * 2304 * (4 * 256 + 5) / 1e9, "cascade_box_heads": 23.8 * n_prop / 256.0,
+         "mask_head": 1.028 * (n_prop + n_det)}
+    total = sum(g.values())
+    ach = total / sec_per_frame / 1e3
+    return {"algorithmic_gflop_per_frame": round(total, 1), "by_stage_gflop": {k: round(v, 1) for k, v in g.items()},
+            "achieved_tflops": round(ach, 2), "frac_of_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "note": "every FLOP of the frame over the frame time" + ("" if math == "fp32" else " (bf16x3 arithmetic: algorithmic fp32 FLOPs)")}
+
+
 def available_cores() -> int:
     """Cores this process may really use: affinity mask and cgroup quota, not the host's total."""
     n = os.cpu_count() or 1
@@ -438,6 +453,7 @@ def main():
                        "proposals_per_frame_mean": round(float(np.mean(pc)), 1), "detections_per_frame_mean": round(float(np.mean(dc)), 1),
                        "memory_instances_per_frame_mean": round(float(np.mean(mk)), 1)},
             "roofline": roofline,
+            "frame_roofline": frame_roofline(H, W, float(np.mean(pc)), float(np.mean(dc)), elapsed / args.steps, headline_math),
             "variants": variants,
             "eval_allreduce_ms": round(t_ar * 1e3, 3),
             "ap50_synthetic": None if ap is None else round(ap["AP50"], 3),

@@ -3,8 +3,8 @@
 Mirrors the per-frame preparation of `Detic/robot_demo.py:489-534` and `EmbodiedPredictor.__call__`
 (`Detic/detic/predictor.py:406-439`): nearest-timestamp association of RGB / depth / pose files, depth in millimetres -> metres,
 the fixed RealSense intrinsics, the axis-swapped camera transform `T @ R` (`robot_demo.py:40-90`), grid-cell indexing with the
-robot's `x * map_h + y` ordering (`robot_demo.py:533`), and the frame dict the model takes.  Image decoding (cv2 / PIL) is the
-caller's: this module takes arrays.  The un-projection + indexing runs in the HIP kernel (`order=1`).
+robot's `x * map_h + y` ordering (`robot_demo.py:533`), and the frame dict the model takes.  `RobotFrontEnd` takes arrays; `RobotRun` reads a recorded run from disk (16-bit depth PNGs and
+RGB images through Pillow, poses through numpy).  The un-projection + indexing runs in the HIP kernel (`order=1`).
 """
 from __future__ import annotations
 
@@ -77,3 +77,51 @@ class RobotFrontEnd:
         p = (np.asarray(pose_xyt[:2], dtype=np.float32) - self.map_shift[[0, 2]]) / np.float32(self.res)
         q = np.rint(p).astype(np.int64)
         return int(q[0]), int(q[1])
+
+
+def read_depth_mm(path: str) -> np.ndarray:
+    """`cv2.imread(path, cv2.IMREAD_ANYDEPTH)` (robot_demo.py:498): the 16-bit depth PNG as uint16 millimetres, via Pillow."""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    if a.ndim != 2:
+        raise ValueError(f"{path}: expected a single-channel depth image, got shape {a.shape}")
+    return a.astype(np.uint16) if a.dtype != np.uint16 else a
+
+
+def read_rgb(path: str) -> np.ndarray:
+    """The Detic loader's own decode, inlined at robot_demo.py:503-507: Pillow, EXIF orientation, RGB uint8 HWC."""
+    from PIL import Image, ImageOps
+    with Image.open(path) as im:
+        return np.asarray(ImageOps.exif_transpose(im).convert("RGB"))
+
+
+class RobotRun:
+    """One recorded robot run on disk (`<root>/images`, `<root>/depth`, `<root>/pose`, file stems = timestamps): every second RGB
+    image (~10 Hz) with the depth image and the odometry sample closest in time (robot_demo.py:485-499), turned into model frames
+    by a `RobotFrontEnd`."""
+
+    def __init__(self, root: str, front_end: Optional[RobotFrontEnd] = None, every: int = 2):
+        import os
+        self.root = root
+        self.images = sorted(os.listdir(os.path.join(root, "images")))
+        self.depth = sorted(os.listdir(os.path.join(root, "depth")))
+        self.pose = sorted(os.listdir(os.path.join(root, "pose")))
+        self.every = every
+        self.front_end = front_end or RobotFrontEnd(sequence_name=os.path.basename(os.path.normpath(root)))
+
+    def __len__(self) -> int:
+        return len(self.images[::self.every])
+
+    def __iter__(self):
+        import os
+        for image in self.images[::self.every]:
+            stamp = image.split(".")[0]
+            d = nearest_by_timestamp(stamp, self.depth)
+            p = nearest_by_timestamp(stamp, self.pose)
+            depth_mm = read_depth_mm(os.path.join(self.root, "depth", d))
+            pose = np.load(os.path.join(self.root, "pose", p))
+            rgb = read_rgb(os.path.join(self.root, "images", image))
+            f = self.front_end.frame(rgb, depth_mm, pose, file_name=image)
+            f["depth_file"], f["pose_file"] = d, p
+            yield f

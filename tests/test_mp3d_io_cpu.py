@@ -133,3 +133,39 @@ def test_snapshot_is_hdf5_with_the_reference_names(tmp_path):
         assert sorted(f.keys()) == ["impicit_memory", "observations", "semmap"] and f.read("semmap").dtype == np.int32
     got = S.read_snapshot(os.path.join(str(tmp_path), "memory"), "scene0_1.h5")
     assert np.array_equal(got["semmap_real"], sem + 1) and got["implicit_memory"].dtype == np.float32
+
+
+def test_robot_run_reads_a_recorded_run(tmp_path):
+    """robot_demo.py:485-517 on disk: every second image, nearest depth / pose by timestamp, 16-bit depth in millimetres."""
+    from PIL import Image
+    from embodied_object_detection_amd.data import robot as R
+    from oracle import projector as OP
+    root = tmp_path / "run7"
+    for d in ("images", "depth", "pose"):
+        os.makedirs(root / d)
+    rng = np.random.RandomState(3)
+    H, W = 64, 96
+    stamps = [1000, 1050, 1100, 1150, 1200]
+    for t in stamps:
+        Image.fromarray(rng.randint(0, 255, size=(H, W, 3)).astype(np.uint8)).save(root / "images" / f"{t}.png")
+    depths = {}
+    for t in (990, 1110, 1190):
+        depths[t] = rng.randint(500, 9000, size=(H, W)).astype(np.uint16)
+        Image.fromarray(depths[t]).save(root / "depth" / f"{t}.png")           # 16-bit single-channel PNG
+    for t, pose in ((1001, [1.0, 2.0, 0.1]), (1125, [1.5, 2.5, 0.2]), (1210, [2.0, 3.0, 0.3])):
+        np.save(root / "pose" / f"{t}.npy", np.array(pose, dtype=np.float32))
+    fe = R.RobotFrontEnd(projector=lambda d, T_, intr, ps, ms, cell, mw, mh, order=0: OP.depth_to_proj_indices(d, T_, intr, ps, ms, cell, mw, mh, order),
+                         sequence_name="run7")
+    run = R.RobotRun(str(root), fe)
+    frames = list(run)
+    assert len(run) == 3 and [f["file_name"] for f in frames] == ["1000.png", "1100.png", "1200.png"]
+    assert [f["depth_file"] for f in frames] == ["990.png", "1110.png", "1190.png"]
+    assert [f["pose_file"] for f in frames] == ["1001.npy", "1125.npy", "1210.npy"]
+    assert [f["memory_reset"] for f in frames] == [True, False, False] and frames[0]["sequence_name"] == "run7"
+    assert np.array_equal(R.read_depth_mm(str(root / "depth" / "1110.png")), depths[1110])
+    f1 = frames[1]
+    assert tuple(f1["image"].shape) == (3, H, W) and f1["proj_indices"].shape == (H, W, 1) and f1["proj_indices"].dtype == np.int32
+    depth_m = (depths[1110].astype(np.float64) / 1000).astype(np.float32)
+    ref = OP.depth_to_proj_indices(depth_m, R.robot_transform([1.5, 2.5, 0.2]), R.ROBOT_INTRINSICS, (0.0, 0.0, 0.0),
+                                   np.asarray(R.ROBOT_MAP_SHIFT, dtype=np.float32), R.ROBOT_RES, R.ROBOT_MAP_W, R.ROBOT_MAP_H, 1)
+    assert np.array_equal(f1["proj_indices"][..., 0], ref)

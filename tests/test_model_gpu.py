@@ -405,3 +405,27 @@ def test_on_disk_episodes_drive_the_model(setup, tmp_path):
     assert torch.equal(model.implicit_memory, ref_model.implicit_memory)
     from embodied_object_detection_amd.evaluation.coco_ap import KIND_GT
     assert sum(1 for r in res["records"].rows if r[0] == KIND_GT) == 4   # one GT box per frame reached the evaluator
+
+
+def test_embodied_predictor_mirrors_the_robot_demo_call(synthetic_sd):
+    """`EmbodiedPredictor(cfg)(data)` (predictor.py:406-439): channel reversal under INPUT.FORMAT RGB, original height / width,
+    one frame through `model([[inputs]])`; a frame the reference would resize is refused."""
+    from embodied_object_detection_amd.engine.predictor import EmbodiedPredictor
+    frames, seq = _frames(480, 640, 2, 24, 24)
+    cfg = _cfg(**{"INPUT.FORMAT": "RGB", "INPUT.MAX_SIZE_TEST": 640})
+    pred = EmbodiedPredictor(cfg, synthetic_sd)
+    ref = EmbodiedPredictor(_cfg(**{"INPUT.FORMAT": "BGR", "INPUT.MAX_SIZE_TEST": 640}), synthetic_sd)
+    outs = []
+    for f in frames:
+        hwc = f["image"].permute(1, 2, 0).numpy()
+        data = {"image": hwc, "memory": f["memory"], "proj_indices": f["proj_indices"], "memory_reset": f["memory_reset"],
+                "sequence_name": f["sequence_name"]}
+        a = pred(data)["instances"]
+        b = ref(dict(data, image=hwc[:, :, ::-1]))["instances"]          # same pixels reach the model either way
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+        assert a.image_size == (480, 640)
+        outs.append(a)
+    assert len(outs[0]) > 0
+    with pytest.raises(ValueError):
+        pred({"image": np.zeros((256, 320, 3), np.uint8), "memory": frames[0]["memory"], "proj_indices": np.zeros((256, 320, 1), np.int32),
+              "memory_reset": True, "sequence_name": "x"})

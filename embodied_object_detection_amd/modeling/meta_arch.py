@@ -79,7 +79,7 @@ class CustomRCNNRecurrent:
         # `overlap_branches = False` restores one stream.
         self.overlap_branches = True
         self._side_stream = None
-        self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = None
+        self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = self._ev_sel = None
         # Look-ahead: the ResNet trunk does not read the memory, so the NEXT frame's bottom-up pass and FPN top-down convs (known from the
         # inner frame list of `forward`, or passed as `next_frame`) are enqueued on a third stream while this frame's mask passes
         # run; they write the other of two pyramid buffer sets.
@@ -252,7 +252,7 @@ class CustomRCNNRecurrent:
         hit = pre is not None and pre[0] is frame["image"]
         if hit:
             self._pyramid ^= 1          # the look-ahead wrote P3..P5 (memory-independent half) into the other buffer set
-        look_ahead = (next_frame is not None and self.prefetch_trunk and self.overlap_branches and not self.lazy_proposal_masks)
+        look_ahead = next_frame is not None and self.prefetch_trunk and self.overlap_branches
         if look_ahead and self.lookahead_at_start:
             # start it NOW: while this frame's memory fusion, tower and proposal decoding (a short latency-bound chain that
             # leaves most of the chip idle) run on the main stream
@@ -269,31 +269,46 @@ class CustomRCNNRecurrent:
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
         mem_done = False
-        if self.overlap_branches and not self.lazy_proposal_masks:
+        if self.overlap_branches:
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = _sched_streams(self.device)[0]     # high priority: the small launches go first
-                self._ev_props, self._ev_pm, self._ev_box, self._ev_mem = (torch.cuda.Event() for _ in range(4))
+                self._ev_props, self._ev_pm, self._ev_box, self._ev_mem, self._ev_sel = (torch.cuda.Event() for _ in range(5))
             self._ev_props.record(main)
             if look_ahead and not self.lookahead_at_start:
                 self._enqueue_trunk(next_frame, self._ev_props)
+            lazy = self.lazy_proposal_masks and update_mem
             # Host enqueue order matters (the GPU runs behind the host here): first the large launches of the main stream, then
-            # the side stream's ~45 small ones, the look-ahead's ~75 last -- they all execute beside the two mask passes.
-            prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
-                                                            bufs=self.roi_heads.proposal_pass_buffers())
-            self._ev_pm.record(main)
+            # the side stream's ~45 small ones -- they all execute beside the two mask passes.
+            if not lazy:
+                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
+                                                                bufs=self.roi_heads.proposal_pass_buffers())
+                self._ev_pm.record(main)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
                 det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(
                     views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
                 self._ev_box.record(self._side_stream)
+                if lazy:
+                    # select the memory instances first, then run the mask head only on those proposals (same results: the
+                    # other proposals' masks are never read, custom_rcnn.py:875-880)
+                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                    ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
+                    self._ev_sel.record(self._side_stream)
             main.wait_event(self._ev_box)
             self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            if lazy:
+                main.wait_event(self._ev_sel)
+                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
+                                                                rows_count=self._uniq_count,
+                                                                bufs=self.roi_heads.proposal_pass_buffers())
+                self._ev_pm.record(main)
             if update_mem and self.overlap_memory_write:
                 # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
                 # stream beside the detection mask pass; the main stream joins at the end of the frame
                 with torch.cuda.stream(self._side_stream):
-                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                    if not lazy:
+                        mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
                     self._side_stream.wait_event(self._ev_pm)
                     self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
                     self._ev_mem.record(self._side_stream)

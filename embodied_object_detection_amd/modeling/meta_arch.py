@@ -254,18 +254,19 @@ class CustomRCNNRecurrent:
             self._pyramid ^= 1          # the look-ahead wrote P3..P5 (memory-independent half) into the other buffer set
         look_ahead = next_frame is not None and self.prefetch_trunk and self.overlap_branches
         if look_ahead and self.lookahead_at_start:
-            # start it NOW: while this frame's memory fusion, tower and proposal decoding (a short latency-bound chain that
-            # leaves most of the chip idle) run on the main stream
+            # it may start NOW, beside this frame's memory fusion, tower and proposal decoding (a short latency-bound chain
+            # that leaves most of the chip idle); the host enqueues that chain first so that the main stream never starves
             if self._ev_start is None:
                 self._ev_start = torch.cuda.Event()
             self._ev_start.record(torch.cuda.current_stream(self.device))
-            self._enqueue_trunk(next_frame, self._ev_start)
         if hit:
             feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid)
         else:
             x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
             feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj, self._pyramid)
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
+        if look_ahead and self.lookahead_at_start:
+            self._enqueue_trunk(next_frame, self._ev_start)
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
         mem_done = False

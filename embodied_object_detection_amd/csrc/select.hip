@@ -281,8 +281,9 @@ struct CnArgs {
   float level_scale[5];
   float score_thresh;
   int topk;
-  u64* cand_keys;  // [levels*topk]
+  u64* cand_keys;  // packed per level: level l owns slots [pk_off[l], pk_off[l+1]), min(level size, topk) each
   int* cand_cnt;   // [levels]
+  int pk_off[6];
 };
 
 #define EOD_SORT_MAX 16384
@@ -320,24 +321,25 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int r = threadIdx.x * E + e;
-    if (r < p.topk) {
+    if (r < p.pk_off[level + 1] - p.pk_off[level]) {
       u64 k = 0;
       if (r < take) {
         const float heat = key_score(v[e]);
         const unsigned i = key_index(v[e]);
         k = make_key(sqrtf(heat), (unsigned)(r0 + (int)i));
       }
-      p.cand_keys[level * p.topk + r] = k;
+      p.cand_keys[p.pk_off[level] + r] = k;
     }
   }
   if (threadIdx.x == 0) p.cand_cnt[level] = take;
 }
 
-// single block: merge the per-level lists, sort by sqrt-score, decode boxes (E*1024 >= levels*topk slots)
+// single block: merge the per-level lists, sort by sqrt-score, decode boxes (E*1024 >= packed slots: E = 4 covers the usual
+// 1000 + 1000 + <=1000 + ... <= 4096 candidates with half the sort of E = 8)
 template <int E>
 __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_sorted) {
   __shared__ u64 xch[1024 * E];
-  const int total_slots = p.levels * p.topk;
+  const int total_slots = p.pk_off[p.levels];
   u64 v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -518,17 +520,19 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
     a.level_scale[l] = d->level_scale[l];
   }
   a.score_thresh = d->score_thresh; a.topk = d->pre_nms_topk; a.cand_keys = w.cand_keys; a.cand_cnt = w.cand_cnt;
+  // the per-level candidate lists are packed: level l holds at most min(level size, topk) entries
+  a.pk_off[0] = 0;
+  for (int l = 0; l < d->levels; ++l) a.pk_off[l + 1] = a.pk_off[l] + std::min(d->level_off[l + 1] - d->level_off[l], d->pre_nms_topk);
   int max_level = 0;
   for (int l = 0; l < d->levels; ++l) max_level = std::max(max_level, d->level_off[l + 1] - d->level_off[l]);
   if (max_level <= 8192)
     hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels), dim3(1024), 0, s, a);
   else
     hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels), dim3(1024), 0, s, a);
-  // the per-level lists are packed level-major without holes only up to min(level size, topk) entries each
-  int packed = 0;
-  for (int l = 0; l < d->levels; ++l) packed += std::min(d->level_off[l + 1] - d->level_off[l], d->pre_nms_topk);
-  (void)packed;
-  hipLaunchKernelGGL(cn_merge_decode_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
+  if (a.pk_off[d->levels] <= 4096)
+    hipLaunchKernelGGL(cn_merge_decode_kernel<4>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
+  else
+    hipLaunchKernelGGL(cn_merge_decode_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
   const int nb = (slots + 63) / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, s, w.sorted_boxes, (const int*)nullptr, w.n_sorted, nb, d->nms_thresh,
                      w.mask);

@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         ix0 = (local - oy * ww) - p.pad;
         off = p.lv_off[l];
       } else {
-        const int ox = m % p.OW;
-        const int t2 = m / p.OW;
-        const int oy = t2 % p.OH;
-        const int img = t2 / p.OH;
+        const int t2 = (int)fdiv((unsigned)m, p.div_ow);      // invariant divisors: one mul_hi instead of a division sequence
+        const int ox = m - t2 * p.OW;
+        const int img = (int)fdiv((unsigned)t2, p.div_oh);
+        const int oy = t2 - img * p.OH;
         iy0 = oy * p.stride - p.pad;
         ix0 = ox * p.stride - p.pad;
         off = img * p.H * p.W;

@@ -74,6 +74,20 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
   p.y[oidx] = v;
 }
 
+// Bit tp = ky * KW + kx is set when tap (ky, kx) of the window anchored at (iy0, ix0) falls inside an hh x ww image.
+__device__ __forceinline__ unsigned long long tap_mask(int iy0, int ix0, int hh, int ww, int KH, int KW) {
+  unsigned long long mask = 0;
+  int tp = 0;
+  for (int ky = 0; ky < KH; ++ky) {
+    const bool rok = (unsigned)(iy0 + ky) < (unsigned)hh;
+    for (int kx = 0; kx < KW; ++kx, ++tp) {
+      const bool ok = rok && ((unsigned)(ix0 + kx) < (unsigned)ww);
+      mask |= (unsigned long long)ok << tp;
+    }
+  }
+  return mask;
+}
+
 // Stores one wave's accumulators (TM x TN tiles of 32x32, MFMA C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
 // through the fused epilogue, or as a split-K slab.
 template <int TM, int TN>

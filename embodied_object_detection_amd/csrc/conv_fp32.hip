@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   unsigned a_voff[AR];
   unsigned long long a_mask[AR];
   unsigned a_pitch[MULTI ? AR : 1];
-  const int ntaps = p.KH * p.KW;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + lr + RPP * i;
@@ -106,11 +105,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     if (!TAP4) {
       unsigned long long mask = 0;
       if (rowok) {
-        for (int tp = 0; tp < ntaps; ++tp) {
-          const int ky = tp / p.KW, kx = tp - ky * p.KW;
-          const bool ok = ((unsigned)(iy0 + ky) < (unsigned)hh) && ((unsigned)(ix0 + kx) < (unsigned)ww);
-          mask |= (unsigned long long)ok << tp;
-        }
+        mask = tap_mask(iy0, ix0, hh, ww, p.KH, p.KW);
       }
       a_mask[i] = mask;
       a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);   // may wrap for padded taps: only used when the tap bit is set

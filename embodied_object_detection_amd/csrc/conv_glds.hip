@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs p) {
   unsigned a_voff[AI];
   unsigned long long a_mask[AI];
   unsigned a_pitch[MULTI ? AI : 1];
-  const int ntaps = p.KH * p.KW;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int row = 8 * (wave + 4 * i) + lr8;          // tile row written by this lane in DMA instruction i
@@ -82,11 +81,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs p) {
     }
     unsigned long long mask = 0;
     if (rowok) {
-      for (int tp = 0; tp < ntaps; ++tp) {
-        const int ky = tp / p.KW, kx = tp - ky * p.KW;
-        const bool ok = ((unsigned)(iy0 + ky) < (unsigned)hh) && ((unsigned)(ix0 + kx) < (unsigned)ww);
-        mask |= (unsigned long long)ok << tp;
-      }
+      mask = tap_mask(iy0, ix0, hh, ww, p.KH, p.KW);
     }
     a_mask[i] = mask;
     a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * gslot) * 4);

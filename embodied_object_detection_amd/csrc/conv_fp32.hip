@@ -122,13 +122,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
   f32x4 ar[AR], br[BR];
+  // (tap, channel offset) of the NEXT chunk to fetch: chunks are fetched in order, so the position is advanced instead of
+  // re-derived with two divisions per chunk (Cin is a multiple of BK on this path)
+  int nx_tap = 0, nx_c0 = 0, nx_ky = 0, nx_kx = 0;
+  if (!TAP4) {
+    const int k0 = c_begin * BK;
+    nx_tap = k0 / p.Cin;
+    nx_c0 = k0 - nx_tap * p.Cin;
+    nx_ky = nx_tap / p.KW;
+    nx_kx = nx_tap - nx_ky * p.KW;
+  }
   auto load_chunk = [&](int chunk) {
     const int k0 = chunk * BK;
     if (!TAP4) {
-      const int tap = k0 / p.Cin;
-      const int c0 = k0 - tap * p.Cin;
-      const int ky = tap / p.KW;
-      const int kx = tap - ky * p.KW;
+      const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
+      nx_c0 += BK;
+      if (nx_c0 >= p.Cin) {
+        nx_c0 = 0;
+        ++nx_tap;
+        if (++nx_kx == p.KW) {
+          nx_kx = 0;
+          ++nx_ky;
+        }
+      }
       const unsigned tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ky * p.W + kx) * p.Cin + c0) * 4);
 #pragma unroll
       for (int i = 0; i < AR; ++i) {

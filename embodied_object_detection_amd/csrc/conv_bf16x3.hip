@@ -135,16 +135,30 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs p) {
 #ifdef ABL_NOGLOBAL
   bool chunk_guard = false;
 #endif
-  auto tap_info = [&](int chunk) {
-    if (chunk > c_end - 1) chunk = c_end - 1;          // past-the-end prefetches re-read the last chunk (never used)
-    const int k0 = chunk * BK;
+  // tap_info() is called for consecutive chunks (c_begin, c_begin + 1, ...): the (tap, channel) position is advanced instead of
+  // re-derived with two divisions per chunk.  The one or two calls past c_end describe chunks that are fetched (range-checked
+  // buffer loads) and never used.
+  int nx_tap, nx_c0, nx_ky, nx_kx, nx_k0 = c_begin * BK;
+  nx_tap = nx_k0 / p.Cin;
+  nx_c0 = nx_k0 - nx_tap * p.Cin;
+  nx_ky = nx_tap / p.KW;
+  nx_kx = nx_tap - nx_ky * p.KW;
+  auto tap_info = [&](int) {
     TapInfo ti;
-    ti.tap = k0 / p.Cin;
-    const int c0 = k0 - ti.tap * p.Cin;
-    ti.ky = ti.tap / p.KW;
-    const int kx = ti.tap - ti.ky * p.KW;
-    ti.tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ti.ky * p.W + kx) * p.Cin + c0) * 4);
-    ti.k0b = (unsigned)(k0 * 4);
+    ti.tap = nx_tap < 63 ? nx_tap : 63;
+    ti.ky = nx_ky;
+    ti.tap_off = MULTI ? (unsigned)((nx_kx * p.Cin + nx_c0) * 4) : (unsigned)(((nx_ky * p.W + nx_kx) * p.Cin + nx_c0) * 4);
+    ti.k0b = (unsigned)(nx_k0 * 4);
+    nx_k0 += BK;
+    nx_c0 += BK;
+    if (nx_c0 >= p.Cin) {
+      nx_c0 = 0;
+      ++nx_tap;
+      if (++nx_kx == p.KW) {
+        nx_kx = 0;
+        ++nx_ky;
+      }
+    }
     return ti;
   };
   auto load_unit = [&](const TapInfo& ti, int u) {
@@ -374,16 +388,30 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
   bool in_loop = false;     // diagnostic builds (tools/ablate/run_bf16x3.py) drop parts of the loop body
   (void)in_loop;
   struct TapInfo { int tap, ky; unsigned tap_off, k0b; };
-  auto tap_info = [&](int chunk) {
-    if (chunk > c_end - 1) chunk = c_end - 1;          // past-the-end prefetches re-read the last chunk (never used)
-    const int k0 = chunk * BK;
+  // tap_info() is called for consecutive chunks (c_begin, c_begin + 1, ...): the (tap, channel) position is advanced instead of
+  // re-derived with two divisions per chunk.  The one or two calls past c_end describe chunks that are fetched (range-checked
+  // buffer loads) and never used.
+  int nx_tap, nx_c0, nx_ky, nx_kx, nx_k0 = c_begin * BK;
+  nx_tap = nx_k0 / p.Cin;
+  nx_c0 = nx_k0 - nx_tap * p.Cin;
+  nx_ky = nx_tap / p.KW;
+  nx_kx = nx_tap - nx_ky * p.KW;
+  auto tap_info = [&](int) {
     TapInfo ti;
-    ti.tap = k0 / p.Cin;
-    const int c0 = k0 - ti.tap * p.Cin;
-    ti.ky = ti.tap / p.KW;
-    const int kx = ti.tap - ti.ky * p.KW;
-    ti.tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ti.ky * p.W + kx) * p.Cin + c0) * 4);
-    ti.k0b = (unsigned)(k0 * 4);
+    ti.tap = nx_tap < 63 ? nx_tap : 63;
+    ti.ky = nx_ky;
+    ti.tap_off = MULTI ? (unsigned)((nx_kx * p.Cin + nx_c0) * 4) : (unsigned)(((nx_ky * p.W + nx_kx) * p.Cin + nx_c0) * 4);
+    ti.k0b = (unsigned)(nx_k0 * 4);
+    nx_k0 += BK;
+    nx_c0 += BK;
+    if (nx_c0 >= p.Cin) {
+      nx_c0 = 0;
+      ++nx_tap;
+      if (++nx_kx == p.KW) {
+        nx_kx = 0;
+        ++nx_ky;
+      }
+    }
     return ti;
   };
   auto load_unit = [&](const TapInfo& ti, int u) {

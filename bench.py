@@ -33,8 +33,8 @@ PEAK_HBM_GBPS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=15, help="untimed frames (clocks and the caching allocator settle in ~10)")
     ap.add_argument("--size", type=int, nargs=2, default=[640, 640], metavar=("H", "W"))
     ap.add_argument("--grid", type=int, nargs=2, default=[200, 200], metavar=("MAP_W", "MAP_H"))
     ap.add_argument("--cell", type=float, default=0.2)

@@ -39,7 +39,7 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
   const void* w3;              // optional pre-split weights of the bf16x3 kernels (eod_conv_split_weights_bf16x3)
   unsigned w3_bytes;
-  FastDiv div_ow, div_oh, div_cd;
+  FastDiv div_ow, div_oh, div_cd, div_row;
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {

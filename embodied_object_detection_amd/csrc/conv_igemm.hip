@@ -15,6 +15,9 @@ namespace {
 
 using namespace eodconv;
 
+// Sums the K slabs in slab order and applies the fused epilogue.  VEC = 4: one float4 of four consecutive output channels per
+// thread and slab (Cout % 4 == 0); VEC = 1 for the odd-width heads.  32-bit indices (check_desc bounds rows x Cout below 2^31).
+template <int VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   int M = p.M;
   if (p.m_count) {
@@ -22,14 +25,25 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
     const int lim = c * p.m_unit;
     M = lim < M ? lim : M;
   }
-  const size_t total = (size_t)M * p.Cout;
+  const unsigned per_row = (unsigned)p.Cout / VEC;
+  const unsigned total = (unsigned)M * per_row;
   const size_t slab = (size_t)p.M * p.Cout;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int z = 0; z < p.splitk; ++z) v += p.partial[z * slab + idx];
-    const int m = (int)(idx / p.Cout);
-    const int n = (int)(idx - (size_t)m * p.Cout);
-    epilogue_store(p, v, m, n);
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const unsigned m = fdiv(idx, p.div_row);
+    const unsigned n = (idx - m * per_row) * VEC;
+    const float* src = p.partial + (size_t)m * p.Cout + n;
+    if (VEC == 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4*>(src + z * slab);
+      epilogue_store(p, v.x, (int)m, (int)n);
+      epilogue_store(p, v.y, (int)m, (int)n + 1);
+      epilogue_store(p, v.z, (int)m, (int)n + 2);
+      epilogue_store(p, v.w, (int)m, (int)n + 3);
+    } else {
+      float v = 0.f;
+      for (int z = 0; z < p.splitk; ++z) v += src[z * slab];
+      epilogue_store(p, v, (int)m, (int)n);
+    }
   }
 }
 
@@ -219,6 +233,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.M = total_rows(d);
   a.div_ow = make_fastdiv((unsigned)(d->OW > 0 ? d->OW : 1));
   a.div_oh = make_fastdiv((unsigned)(d->OH > 0 ? d->OH : 1));
+  a.div_row = make_fastdiv((unsigned)(d->Cout % 4 == 0 ? d->Cout / 4 : d->Cout));   // split-K reduce: work items per output row
   a.div_cd = make_fastdiv((unsigned)((d->Cout >> 2) > 0 ? (d->Cout >> 2) : 1));
   {
     const size_t xe = d->levels > 0 ? (size_t)d->level_off[d->levels] * d->Cin : (size_t)d->N * d->H * d->W * d->Cin;
@@ -249,9 +264,12 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s);
   if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;
-    int blocks = (int)((total + 255) / 256);
+    const bool vec = a.Cout % 4 == 0;
+    int blocks = (int)((total / (vec ? 4 : 1) + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
   }
   return eod_launch_status();
 }

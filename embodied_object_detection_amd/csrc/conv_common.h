@@ -7,15 +7,6 @@
 namespace eodconv {
 
 
-// Division by a launch-invariant integer with one mul_hi + shifts (Granlund-Montgomery, exact for every 32-bit n).
-struct FastDiv {
-  unsigned mp, sh1, sh2, d;
-};
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-  const unsigned t = __umulhi(f.mp, n);
-  return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-
 struct ConvArgs {
   const float* x;
   const float* w;

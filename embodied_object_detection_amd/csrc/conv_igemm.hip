@@ -47,18 +47,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
-FastDiv make_fastdiv(unsigned d) {
-  FastDiv f{};
-  if (d == 0) d = 1;
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;
-  f.mp = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
-  f.sh1 = l < 1 ? l : 1;
-  f.sh2 = l > 0 ? l - 1 : 0;
-  f.d = d;
-  return f;
-}
-
 inline int big_tile_env() {
   static const int v = [] {
     const char* e = getenv("EOD_CONV_BIG_TILE");
@@ -231,10 +219,10 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;
   a.M = total_rows(d);
-  a.div_ow = make_fastdiv((unsigned)(d->OW > 0 ? d->OW : 1));
-  a.div_oh = make_fastdiv((unsigned)(d->OH > 0 ? d->OH : 1));
-  a.div_row = make_fastdiv((unsigned)(d->Cout % 4 == 0 ? d->Cout / 4 : d->Cout));   // split-K reduce: work items per output row
-  a.div_cd = make_fastdiv((unsigned)((d->Cout >> 2) > 0 ? (d->Cout >> 2) : 1));
+  a.div_ow = eod_make_fastdiv((unsigned)(d->OW > 0 ? d->OW : 1));
+  a.div_oh = eod_make_fastdiv((unsigned)(d->OH > 0 ? d->OH : 1));
+  a.div_row = eod_make_fastdiv((unsigned)(d->Cout % 4 == 0 ? d->Cout / 4 : d->Cout));   // split-K reduce: work items per output row
+  a.div_cd = eod_make_fastdiv((unsigned)((d->Cout >> 2) > 0 ? (d->Cout >> 2) : 1));
   {
     const size_t xe = d->levels > 0 ? (size_t)d->level_off[d->levels] * d->Cin : (size_t)d->N * d->H * d->W * d->Cin;
     a.x_bytes = (unsigned)(xe * sizeof(float));

@@ -47,3 +47,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + k;
 }
+
+// Division by a launch-invariant integer with one mul_hi + shifts (Granlund-Montgomery, exact for every 32-bit n).
+struct FastDiv {
+  unsigned mp, sh1, sh2, d;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.mp, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+static inline FastDiv eod_make_fastdiv(unsigned d) {
+  FastDiv f{};
+  if (d == 0) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mp = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.sh1 = l < 1 ? l : 1;
+  f.sh2 = l > 0 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}

@@ -22,6 +22,7 @@ struct RoiArgs {
   int R_cap;
   int S;
   float* out;
+  FastDiv div_bins, div_s;   // wave id -> (roi, bin) -> (ph, pw) without integer division sequences
 };
 
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
@@ -33,11 +34,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int bins = p.S * p.S;
-  const long total = (long)R * bins;
-  for (long wid = (long)blockIdx.x * wpb + (threadIdx.x >> 6); wid < total; wid += (long)gridDim.x * wpb) {
-    const int r = (int)(wid / bins);
-    const int b = (int)(wid - (long)r * bins);
-    const int ph = b / p.S, pw = b - ph * p.S;
+  const int total = R * bins;                       // < 2^31: checked on the host
+  for (int wid = blockIdx.x * wpb + (threadIdx.x >> 6); wid < total; wid += gridDim.x * wpb) {
+    const int r = (int)fdiv((unsigned)wid, p.div_bins);
+    const int b = wid - r * bins;
+    const int ph = (int)fdiv((unsigned)b, p.div_s), pw = b - ph * p.S;
     const int br = p.box_rows ? p.box_rows[r] : r;
     const float bx1 = p.boxes[br * 4 + 0], by1 = p.boxes[br * 4 + 1], bx2 = p.boxes[br * 4 + 2], by2 = p.boxes[br * 4 + 3];
     // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [3,5]
@@ -122,12 +123,15 @@ extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, 
                              eod_stream_t stream) {
   if (!p3 || !p4 || !p5 || !boxes || !out) return EOD_ERR_NULL;
   if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
+  if ((long)R_cap * out_size * out_size >= (1L << 30)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(p3) || !eod_aligned16(p4) || !eod_aligned16(p5) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
   RoiArgs a{};
   a.feat[0] = p3; a.feat[1] = p4; a.feat[2] = p5;
   a.h[0] = h3; a.w[0] = w3; a.h[1] = h3 / 2; a.w[1] = w3 / 2; a.h[2] = h3 / 4; a.w[2] = w3 / 4;
   a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
   a.C = C; a.boxes = boxes; a.box_rows = box_rows; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
+  a.div_bins = eod_make_fastdiv((unsigned)(out_size * out_size));
+  a.div_s = eod_make_fastdiv((unsigned)out_size);
   const long waves = (long)R_cap * out_size * out_size;
   long blocks = (waves + 3) / 4;
   if (blocks > 8192) blocks = 8192;

@@ -3,6 +3,7 @@ the single-collective aggregation over a world_size-2 gloo group."""
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -325,3 +326,33 @@ def test_memory_snapshot_roundtrip(tmp_path):
     assert np.array_equal(got["implicit_memory"], mem.astype(np.float32)) and np.array_equal(got["observations"], obs)
     miss = S.read_snapshot(os.path.join(str(tmp_path), "nope"), "x", fallback_memory=mem)
     assert miss["semmap_real"] is None and miss["observations"] is None and miss["implicit_memory"] is mem
+
+
+def test_bench_contract_helpers_and_committed_line():
+    """bench.py's pure helpers and the JSON line committed under profiles/ keep the driver's contract (keys, types, units)."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eod_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fr = bench.frame_roofline(640, 640, 256, 300, 0.00715, "fp32")
+    assert abs(fr["algorithmic_gflop_per_frame"] - 717.8) < 0.5          # SURVEY §8d: 66.8 + 13.0 + 2.2 + 40.4 + 23.8 + 1.028 * 556
+    assert abs(fr["by_stage_gflop"]["centernet_head"] - 40.4) < 0.1 and 0.6 < fr["frac_of_fp32_mfma_peak"] < 0.7
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and a.steps > 0 and a.warmup > 0
+    assert bench.available_cores() >= 1
+    line = json.load(open(os.path.join(root, "profiles", "r01_bench_640_default.json")))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict)):
+        assert isinstance(line[k], t), k
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and isinstance(c["sample"], str) and c["value"] > 0

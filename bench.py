@@ -429,7 +429,7 @@ def main():
         b3 = headline_math == "bf16x3"
         peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
         kname = ("conv_bf16x3_w8_kernel 256x128 (bf16 MFMA, 3-way operand split: 6 issued MFMA flops per algorithmic flop)" if b3
-                 else "conv_igemm_kernel<64,64,BK=64>") + " (mask_fcn 3x3 implicit GEMM, M=rois*196, N=256, K=2304)"
+                 else "conv_igemm_kernel<64,64,BK=32>") + " (mask_fcn 3x3 implicit GEMM, M=rois*196, N=256, K=2304)"
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / peak, 4), "traffic": None if b3 else pmc_traffic(),

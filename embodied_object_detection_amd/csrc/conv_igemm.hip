@@ -58,7 +58,10 @@ inline int big_tile_env() {
 inline int default_bk() {
   static const int v = [] {
     const char* e = getenv("EOD_CONV_BK");
-    return (e && atoi(e) == 32) ? 32 : 64;   // measured: BK=64 (half the barriers) +16 % on the mask GEMM
+    // measured end to end on the final schedule (profiles/r01_bench_640_default.log era): BK=32 140.8 frames/s / 119.6 TFLOP/s on the
+    // mask GEMM vs BK=64 139.4 / 117.4 (smaller LDS tile -> one more workgroup per CU; the halved barrier count of BK=64 stopped
+    // paying once the K-loop bookkeeping became incremental)
+    return (e && atoi(e) == 64) ? 64 : 32;
   }();
   return v;
 }

@@ -169,3 +169,40 @@ def test_robot_run_reads_a_recorded_run(tmp_path):
     ref = OP.depth_to_proj_indices(depth_m, R.robot_transform([1.5, 2.5, 0.2]), R.ROBOT_INTRINSICS, (0.0, 0.0, 0.0),
                                    np.asarray(R.ROBOT_MAP_SHIFT, dtype=np.float32), R.ROBOT_RES, R.ROBOT_MAP_W, R.ROBOT_MAP_H, 1)
     assert np.array_equal(f1["proj_indices"][..., 0], ref)
+
+
+def test_loader_semantic_gt_map_gt_and_realtime_snapshot(tmp_path):
+    """The baseline memory types of the loader (loader.py:229-243,262-269) and the real-time snapshot path (:214-223)."""
+    from embodied_object_detection_amd.data import snapshot as S
+    from embodied_object_detection_amd.data.mp3d import SMNET_CLASS_MAPPING, SMNetDetectionLoader
+    root = str(tmp_path / "ds")
+    w = _write_dataset(root)
+    clip = np.random.RandomState(5).rand(20, 512).astype(np.float32)
+    clip_path = str(tmp_path / "clip.npy")
+    np.save(clip_path, clip)
+    name = "sA_1_0.h5"
+    # semantic_gt: memory = [zero row; clip rows], proj_indices = the segmentation image of the frame
+    ld = SMNetDetectionLoader(data_path=root, clip_path=clip_path, memory_type="semantic_gt", semmap_path="")
+    ep = ld[0]
+    with h5io.H5File(os.path.join(root, "sensor_data", name)) as f:
+        seg = f.read("segmentation_data")
+    assert ep[0]["memory_features"].shape == (21, 512) and not ep[0]["memory_features"][0].any()
+    assert np.array_equal(ep[0]["memory_features"][1:], clip)
+    assert np.array_equal(ep[1]["proj_indices"][..., 0], seg[1]) and ep[1]["observations"] is None
+    # map_gt without a snapshot: class-mapped clip rows, indices looked up in the GT semantic map
+    lm = SMNetDetectionLoader(data_path=root, clip_path=clip_path, memory_type="map_gt", semmap_path="")
+    em = lm[0]
+    full = np.insert(clip, 0, np.zeros((1, 512)), axis=0)
+    assert np.array_equal(em[0]["memory_features"], full[SMNET_CLASS_MAPPING])
+    assert np.array_equal(em[2]["proj_indices"], w[name]["sem"][w[name]["proj"]][2])
+    # implicit_memory with a real-time snapshot directory: memory / observations come from the dump, labels are shifted by +1
+    snap_dir = str(tmp_path / "out")
+    mem = np.random.RandomState(6).rand(50, 512).astype(np.float32)
+    obs = np.arange(50, dtype=np.float32)
+    S.write_snapshot(snap_dir, name, np.full((50,), -1, dtype=np.int32), mem, obs)
+    ls = SMNetDetectionLoader(data_path=root, memory_type="implicit_memory", semmap_path=os.path.join(snap_dir, "memory"))
+    es = ls[0]
+    assert np.array_equal(es[0]["memory_features"], mem) and np.array_equal(es[0]["observations"], obs)
+    # map_gt WITH the snapshot: indices go through the (+1 shifted) real-time semantic map
+    lms = SMNetDetectionLoader(data_path=root, clip_path=clip_path, memory_type="map_gt", semmap_path=os.path.join(snap_dir, "memory"))
+    assert int(lms[0][0]["proj_indices"].max()) == 0 and lms[0][0]["memory_features"].shape == (21, 512)

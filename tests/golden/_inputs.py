@@ -128,3 +128,109 @@ def robot_case(seed: int = 21, H: int = 120, W: int = 160):
     depth_mm[:3] = 0                         # no-return pixels
     pose = np.array([1.75, -2.5, 0.6], dtype=np.float32)
     return dict(depth_mm=depth_mm, pose=pose)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: decode / cascade / memory-update cases
+# ---------------------------------------------------------------------------------------------------------
+DECODE_HW = (256, 320)             # P3 = 32x40 = 1280 positions > PRE_NMS_TOPK_TEST (1000): the per-level top-k cut is exercised
+
+
+def centernet_decode_case(variant: str = "plain", seed: int = 31):
+    """Raw head outputs (agn_hm logits, ReLU'd regressions in stride units) for a 256x320 image.
+
+    `plain`: continuous logits (no exact ties anywhere).  `ties`: a band of logits is quantised so that many positions share a
+    score; boxes are small (little NMS suppression), so more than 256 survive and the `>= kth` rule has ties to keep."""
+    g = torch.Generator().manual_seed(seed + (0 if variant == "plain" else 1000))
+    H, W = DECODE_HW
+    agn, reg = [], []
+    for l, s in enumerate((8, 16, 32, 64, 128)):
+        h, w = (H + s - 1) // s, (W + s - 1) // s
+        a = torch.randn((1, 1, h, w), generator=g) * 1.5 - 1.0
+        a[0, 0, ::5, ::7] = -20.0                      # sigmoid < 1e-4: not a candidate
+        if variant == "ties":
+            a = torch.round(a * 2.0) / 2.0              # half-integer logits: heavy ties, incl. at the kth value
+            r = torch.rand((1, 4, h, w), generator=g) * 0.6 + 0.1
+        else:
+            r = torch.rand((1, 4, h, w), generator=g) * 3.0
+            r[0, 2:, 1::3, :] = 0.0                     # zero extent to the right / bottom: the +0.01 minimum size applies
+        agn.append(a)
+        reg.append(r)
+    return agn, reg
+
+
+CASCADE_HW = (128, 160)
+
+
+def cascade_case(seed: int = 41, R: int = 48):
+    """P3..P5 of a 128x160 image, R proposals (xyxy, some partly outside the image) with CenterNet scores."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = CASCADE_HW
+    feats = [torch.randn((1, 256, H // s, W // s), generator=g) for s in (8, 16, 32)]
+    cx = torch.rand((R,), generator=g) * W
+    cy = torch.rand((R,), generator=g) * H
+    bw = torch.rand((R,), generator=g) * 90 + 4
+    bh = torch.rand((R,), generator=g) * 70 + 4
+    boxes = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], dim=1)
+    scores = torch.rand((R,), generator=g) * 0.9 + 0.05
+    return feats, boxes, scores
+
+
+def cascade_weights(seed: int = 42):
+    """Reference-keyed weights of the three box heads / predictors (FC_DIM 1024, 7x7x256 input)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rn(*shape, std):
+        return torch.randn(shape, generator=g) * std
+
+    for k in range(3):
+        sd[f"roi_heads.box_head.{k}.fc1.weight"] = rn(1024, 12544, std=(2.0 / 12544) ** 0.5)
+        sd[f"roi_heads.box_head.{k}.fc1.bias"] = rn(1024, std=0.05)
+        sd[f"roi_heads.box_head.{k}.fc2.weight"] = rn(1024, 1024, std=(2.0 / 1024) ** 0.5)
+        sd[f"roi_heads.box_head.{k}.fc2.bias"] = rn(1024, std=0.05)
+        p = f"roi_heads.box_predictor.{k}"
+        sd[f"{p}.cls_score.linear.weight"] = rn(512, 1024, std=(1.0 / 1024) ** 0.5)
+        sd[f"{p}.cls_score.linear.bias"] = rn(512, std=0.05)
+        sd[f"{p}.bbox_pred.0.weight"] = rn(1024, 1024, std=(2.0 / 1024) ** 0.5)
+        sd[f"{p}.bbox_pred.0.bias"] = rn(1024, std=0.05)
+        sd[f"{p}.bbox_pred.2.weight"] = rn(4, 1024, std=0.05)        # large enough that the cascade moves the boxes
+        sd[f"{p}.bbox_pred.2.bias"] = rn(4, std=0.2)
+    return sd
+
+
+N_CELLS_200 = 200 * 200
+
+
+def memory_update_case(seed: int = 51, n_frames: int = 4, R: int = 40):
+    """Canned per-frame proposals (what `inference` hands to `update_implicit_memory`) and projection images for a 480x640
+    camera over the 200x200 fallback map.  Frame f looks at a window of the map shifted by a few cells, so cells are re-observed."""
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    H, W = H480, W640
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    for f in range(n_frames):
+        oy, ox = 40 + 3 * f, 30 + 5 * f
+        iz = oy + yy // 7
+        ix = ox + xx // 7
+        proj = iz * 200 + ix
+        noise = rng.randint(0, N_CELLS_200, size=(H, W))
+        proj = np.where(rng.rand(H, W) < 0.01, noise, proj).astype(np.int32)[..., None]      # [H,W,1] int32 as the loader gives it
+        cx = torch.rand((R,), generator=g) * W
+        cy = torch.rand((R,), generator=g) * H
+        bw = torch.rand((R,), generator=g) * 200 + 20
+        bh = torch.rand((R,), generator=g) * 160 + 20
+        boxes = torch.stack([(cx - bw / 2).clamp(0, W), (cy - bh / 2).clamp(0, H), (cx + bw / 2).clamp(0, W), (cy + bh / 2).clamp(0, H)], 1)
+        scores = torch.rand((R,), generator=g) * 0.9 + 0.05
+        scores[3] = 1.0                                   # a GT-style row (score == 1) that `< 1` must drop
+        feat = torch.randn((R, 512), generator=g) * 2.0
+        low = torch.randn((R, 1, 7, 7), generator=g) * 3.0
+        m28 = torch.sigmoid(torch.nn.functional.interpolate(low, size=(28, 28), mode="bilinear", align_corners=False))
+        frames.append(dict(proj=proj, boxes=boxes, scores=scores, feat=feat, masks28=m28))
+    return frames
+
+
+def digest_matrix(seed: int = 99, cols: int = 8) -> np.ndarray:
+    """Fixed [512, cols] float64 matrix: fixtures keep `rows @ digest_matrix` instead of full 512-d rows."""
+    return np.random.RandomState(seed).randn(512, cols)

@@ -123,3 +123,117 @@ def test_robot_front_end_against_robot_demo(golden_dir):
     assert fe.frame(np.zeros(c["depth_mm"].shape + (3,), np.uint8), c["depth_mm"], c["pose"])["memory_reset"] is False
     assert R.nearest_by_timestamp(1005, ["0990.png", "1010.png", "1000.png"]) == "1010.png"   # first minimum wins
     assert R.nearest_by_timestamp(1000, ["0990.png", "1010.png"]) == "0990.png"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2 pins: proposal decoding, the cascade, the memory update / state machine
+# ---------------------------------------------------------------------------------------------------------
+def _lexsorted(boxes, scores):
+    order = np.lexsort((boxes[:, 3], boxes[:, 2], boxes[:, 1], boxes[:, 0], -scores))
+    return boxes[order], scores[order]
+
+
+def test_centernet_decode_topk_nms_kth(golden_dir):
+    """a11 against `CenterNet.inference/predict_single_level/nms_and_topK` + `compute_grids` (centernet.py:321-339,603-745)."""
+    g = _load(golden_dir, "centernet_decode.npz")
+    cfg = M.OracleCfg()
+    for variant in ("plain", "ties"):
+        agn, reg = I.centernet_decode_case(variant)
+        boxes, scores = M.centernet_proposals(agn, reg, cfg)
+        ref_b, ref_s = g[f"{variant}_boxes"], g[f"{variant}_scores"]
+        assert boxes.shape == ref_b.shape, (variant, boxes.shape, ref_b.shape)
+        if variant == "plain":
+            # no ties: same boxes in the same (NMS = descending score) order, bit for bit
+            np.testing.assert_array_equal(scores.numpy(), ref_s)
+            np.testing.assert_array_equal(boxes.numpy(), ref_b)
+        else:
+            # `>= kth` keeps every tie at the cut (297 > 256 rows); the order among EQUAL scores follows torch.topk(sorted=False)
+            # in the reference, which is unspecified: compare as sets
+            assert boxes.shape[0] > cfg.post_nms_topk
+            b1, s1 = _lexsorted(boxes.numpy(), scores.numpy())
+            b2, s2 = _lexsorted(ref_b, ref_s)
+            np.testing.assert_array_equal(s1, s2)
+            np.testing.assert_array_equal(b1, b2)
+    # compute_grids: stride * i + stride // 2
+    for l, s in enumerate(M.FPN_STRIDES):
+        grid = g[f"plain_grid{l}"]
+        h, w = agn[l].shape[2:]
+        assert grid.shape == (h * w, 2)
+        np.testing.assert_array_equal(grid[:, 0].reshape(h, w)[0], np.arange(w) * s + s // 2)
+        np.testing.assert_array_equal(grid[:, 1].reshape(h, w)[:, 0], np.arange(h) * s + s // 2)
+    np.testing.assert_array_equal(g["plain_level_counts"], [1000, 308, 76, 19, 5])
+
+
+def test_cascade_box_heads_score_merge(golden_dir):
+    """a12 against `DeticCascadeROIHeads._forward_box/_run_stage/_create_proposals_from_boxes` (detic_roi_heads.py:88-222,306-349)
+    and `DeticFastRCNNOutputLayers.forward/predict_probs` (detic_fast_rcnn.py:437-466,325-339)."""
+    g = _load(golden_dir, "cascade.npz")
+    feats, boxes, scores = I.cascade_case()
+    sd = I.cascade_weights()
+    for k in range(3):
+        sd[f"roi_heads.box_predictor.{k}.cls_score.zs_weight"] = torch.from_numpy(g["zs_weight"])
+    cas = M.cascade_box_heads(feats, boxes, scores, sd, M.OracleCfg(), I.CASCADE_HW)
+    np.testing.assert_allclose(cas["feat0"].numpy(), g["feat0"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cas["stage_boxes"][1].numpy(), g["stage1_boxes"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cas["stage_boxes"][2].numpy(), g["stage2_boxes"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cas["final_boxes"].numpy(), g["final_boxes"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cas["final_scores"].numpy(), g["final_scores"], rtol=1e-5, atol=1e-6)
+    assert g["final_scores"].shape == (48, 21) and float(g["final_scores"][:, 20].max()) > 0   # bg column: sigmoid(0)=.5 merged
+
+
+def _digest(t):
+    a = t.numpy().astype(np.float64)
+    rows = np.nonzero(np.abs(a).sum(axis=1) > 0)[0].astype(np.int32)
+    return rows, a[rows] @ I.digest_matrix()
+
+
+def test_memory_update_state_machine(golden_dir, monkeypatch):
+    """a3, a4, a16-a20 against the eval branch of `CustomRCNNRecurrent.forward` and `update_implicit_memory` with all its
+    callees (custom_rcnn.py:435-546,681-1042), TEST_TYPE default and longterm, two calls x two frames."""
+    g = _load(golden_dir, "memory_update.npz")
+    frames_in = I.memory_update_case()
+    zs = torch.from_numpy(_load(golden_dir, "cascade.npz")["zs_weight"])
+    for test_type in ("default", "longterm"):
+        seen, cursor = [], [0]
+
+        def canned(sd, cfg, image, mem_f16, proj, out_hw):
+            seen.append(mem_f16.clone())
+            c = frames_in[cursor[0]]
+            cursor[0] += 1
+            return dict(proposal_boxes=c["boxes"], scores=c["scores"], feat=c["feat"], pred_masks=c["masks28"]), None
+
+        monkeypatch.setattr(M, "inference", canned)
+        orc = OM.RecurrentOracle({"roi_heads.box_predictor.0.cls_score.zs_weight": zs}, M.OracleCfg(test_type=test_type))
+
+        def frame(f, reset):
+            return {"image": torch.zeros((3, I.H480, I.W640), dtype=torch.uint8), "memory": np.zeros((I.N_CELLS_200, 1), np.float32),
+                    "proj_indices": frames_in[f]["proj"], "memory_reset": reset}
+
+        orc([[frame(0, True), frame(1, False)]])
+        orc([[frame(2, False), frame(3, False)]])
+        for f, m in enumerate(seen):
+            rows, dg = _digest(m.float())
+            np.testing.assert_array_equal(rows, g[f"{test_type}_seen{f}_rows"])
+            # fp16 rows: a 1e-7 difference of the f32 per-cell mean can flip one fp16 ulp (2^-7 for |v| in [8,16)) of one element
+            np.testing.assert_allclose(dg, g[f"{test_type}_seen{f}_digest"], rtol=1e-5, atol=3e-2)
+        rows, dg = _digest(orc.implicit_memory)
+        np.testing.assert_array_equal(rows, g[f"{test_type}_mem_rows"])                       # written-cell set: bit-exact
+        np.testing.assert_allclose(dg, g[f"{test_type}_mem_digest"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_array_equal(orc.observations.numpy(), g[f"{test_type}_observations"])   # counters: exact
+        lab = OM.semmap_labels(orc.semmap_features, orc.observation_count, zs, 0.4).numpy()
+        ref = g[f"{test_type}_semmap"]
+        assert (lab >= 0).sum() == (ref >= 0).sum() and (lab == ref).mean() > 0.9995, (lab == ref).mean()
+
+
+def test_inference_with_proposals(golden_dir):
+    """a16 against `inference_with_proposals` (custom_rcnn.py:825-882): `< 1` filter, 50 x normalise, sqrt(sigmoid x score),
+    threshold .3 / NMS .5 / top 100, unique rows, pasted masks."""
+    g = _load(golden_dir, "memory_update.npz")
+    zs = torch.from_numpy(_load(golden_dir, "cascade.npz")["zs_weight"])
+    c = I.memory_update_case()[0]
+    boxes, feats, masks, rows = OM.inference_with_proposals(
+        dict(proposal_boxes=c["boxes"], scores=c["scores"], feat=c["feat"], pred_masks=c["masks28"]), zs, 0.3, (I.H480, I.W640))
+    np.testing.assert_array_equal(boxes.numpy(), g["iwp_boxes"])
+    np.testing.assert_allclose(feats.numpy(), g["iwp_feats"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(np.packbits(masks.numpy()), g["iwp_masks"])
+    assert 3 not in rows.tolist()                                          # the score == 1 row is dropped

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 dense (v_mfma_f32_32x32x16_bf16, 32 cycles per SIMD)
 PEAK_HBM_GBPS = 8000.0
+EPISODE_LEN = 20               # Detic/SMNet/loader.py: episodes of 20 frames; train_mp3d.py:186 passes one episode per call
 
 
 def parse():
@@ -42,7 +43,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
-    ap.add_argument("--streams", type=int, default=4, help="variant: independent scenes per GPU on separate HIP streams (1 = off)")
     ap.add_argument("--no-variants", dest="variants", action="store_false", help="skip the extra (non-headline) variant timings")
     return ap.parse_args()
 
@@ -131,17 +131,41 @@ def cpu_baseline(sd, frames, args, budget_s):
         pass
     return {"value": round(n / tot, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} consecutive frame(s) of the same synthetic sequence (incl. the first, memory empty), "
-                      f"oracle/ torch fp32, {tot:.1f} s", "cpu_model": model_name}
+                      f"oracle/ torch fp32, {tot:.1f} s", "cpu_model": model_name,
+            "cores_note": f"{torch.get_num_threads()} threads = this job's CPU share (affinity / cgroup quota, capped at 32) of the "
+                          f"host's {os.cpu_count()} logical cores"}
+
+
+def relaunch_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh one-GPU worker processes through
+    `torch.distributed.run` BEFORE this process has touched the GPU, and return their exit code.  Refuses (non-zero) when the
+    node does not have N devices -- never silently runs one rank and reports n_gpus: 1."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if n_dev < args.gpus and os.environ.get("EOD_BENCH_ONE_DEVICE") != "1":
+        print(f"[bench] --gpus {args.gpus} requested but only {n_dev} device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no RANK in the environment: launching " + " ".join(cmd))
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     distributed = world > 1
-    if args.gpus != world and distributed:
-        print(f"[bench] warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} != WORLD_SIZE {world}: refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
     # rehearsal knobs for a one-GPU box: EOD_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, EOD_BENCH_BACKEND=gloo replaces RCCL
     # (RCCL refuses two ranks on one device).  The driver's real runs use neither.
     if os.environ.get("EOD_BENCH_ONE_DEVICE") == "1":
@@ -171,9 +195,8 @@ def main():
     log('model built')
 
     headline_math = ops.get_conv_math()          # "fp32" unless EOD_CONV_MATH=bf16x3 is exported
-    # one frame more than is processed: the model starts the NEXT frame's memory-independent bottom-up pass during a step
-    # (look-ahead, model.prefetch_trunk), so the last timed step must have a next frame for the timed region to contain exactly
-    # `steps` bottom-up passes (the first timed frame's was computed during the last warm-up step)
+    # one frame more than is processed: in the enqueue-only variant the model starts the NEXT frame's memory-independent
+    # bottom-up pass during a step, so the last timed step needs a next frame for the region to hold exactly `steps` trunks
     n_frames = args.steps + args.warmup + 1
     seq = SyntheticSequence(rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell,
                             projector=None)
@@ -190,114 +213,123 @@ def main():
 
     # dominant-kernel instrumentation: events around every mask-head 3x3 conv launch (fp32 MFMA implicit GEMM)
     ev = []
-    if not args.no_kernel_events:
-        for conv in model.roi_heads.mask_convs:
-            conv.event_log = ev
 
     def barrier():
         if distributed:
             dist.barrier()
 
-    counts = []
+    def run_boundary(fr, lo, hi):
+        """The reference's call shape (train_mp3d.py:186): `model([episode])` with episodes of 20 frames, `Instances`
+        (boxes, scores, classes, bool masks) materialised for every frame."""
+        n = 0
+        for e0 in range(lo, hi, EPISODE_LEN):
+            outs = model([fr[e0:min(hi, e0 + EPISODE_LEN)]])
+            n += len(outs)
+            assert all(o["instances"].pred_masks.dtype == torch.bool for o in outs)
+        return n
 
-    def step(i, record):
-        if frames[i]["memory_reset"]:
-            model.reset_memory(seq.n_cells)      # custom_rcnn.py:470-479
-        out = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=False,
-                                    next_frame=frames[i + 1] if i + 1 < n_frames else None)
-        if record:
-            counts.append((model.last_stats["prop_count"].clone(), model.last_stats["det_count"].clone(),
-                           model.last_stats["mem_k"].clone()))
-        return out
+    def run_enqueue(fr, lo, hi):
+        """Round-1 headline form: frames enqueued back to back, results left in the device buffers (no Instances)."""
+        for i in range(lo, hi):
+            if fr[i]["memory_reset"]:
+                model.reset_memory(seq.n_cells)      # custom_rcnn.py:470-479
+            model.inference_frame(fr[i], refresh_memory_snapshot=True, materialize=False,
+                                  next_frame=fr[i + 1] if i + 1 < n_frames else None)
+        return hi - lo
 
-    for i in range(args.warmup):
-        step(i, False)
+    def timed_pass(run, fr, what):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        run(fr, 0, args.warmup)
         torch.cuda.synchronize()
-        log(f'warmup frame {i} done')
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = run(fr, args.warmup, args.warmup + args.steps)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert n == args.steps
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        log(f'{what}: {el:.3f} s for {args.steps} frames ({args.steps * world / el:.1f} frames/s), host side {host / args.steps * 1e3:.2f} ms/frame')
+        return el
+
+    def as_variant(el, note, **extra):
+        v = {"value": round(args.steps * world / el, 3), "unit": "frames/s", "ms_per_step": round(el / args.steps * 1e3, 3)}
+        v.update(extra)
+        v["note"] = note
+        return v
+
+    # ---- headline: through the boundary, inputs resident in HBM -------------------------------------------------------------
+    if not args.no_kernel_events:
+        for conv in model.roi_heads.mask_convs:
+            conv.event_log = ev
+    model.stats_log = None
+    run_boundary(frames, 0, min(args.warmup, 4))       # allocator / clocks
+    torch.cuda.synchronize()
     ev.clear()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_frames - 1):
-        step(i, True)
-    host_enqueue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    log(f'host enqueue time {host_enqueue / args.steps * 1e3:.2f} ms/frame')
-    log(f'timed region: {elapsed:.3f} s for {args.steps} frames')
+    # the events of the warm-up frames are dropped inside timed_pass's caller below: remember where the timed ones start
+    ev_mark = []
+
+    def run_boundary_marked(fr, lo, hi):
+        if lo == args.warmup:
+            ev_mark.append(len(ev))
+            model.stats_log = []
+        return run_boundary(fr, lo, hi)
+
+    elapsed = timed_pass(run_boundary_marked, frames, "boundary, resident inputs")
+    counts = model.stats_log or []
+    model.stats_log = None
+    ev = ev[ev_mark[0]:] if ev_mark else ev
     for conv in model.roi_heads.mask_convs:
         conv.event_log = None
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- the dominant kernel without a concurrent stream (short extra pass, not part of `value`) --------------------------------
     ev_excl = []
     if ev and model.overlap_branches:
         model.overlap_branches = False
-        for i in range(min(args.warmup, 2)):
-            step(i, False)
+        run_enqueue(frames, 0, min(args.warmup, 2))
         for conv in model.roi_heads.mask_convs:
             conv.event_log = ev_excl
-        for i in range(args.warmup, min(n_frames, args.warmup + 8)):
-            step(i, False)
+        run_enqueue(frames, args.warmup, min(n_frames - 1, args.warmup + 8))
         torch.cuda.synchronize()
         for conv in model.roi_heads.mask_convs:
             conv.event_log = None
         model.overlap_branches = True
 
-    # ---- variant (reported beside, never as `value`): proposal masks computed only for the proposals the memory reads -----
+    # ---- siblings and variants (reported beside, never as `value`) ----------------------------------------------------------------
     variants = {}
+    boundary_host = None
     if args.variants:
+        tv = timed_pass(run_boundary, host_frames, "boundary, host inputs")
+        boundary_host = as_variant(tv, "same call, but every frame dict carries HOST buffers as the reference's loader hands them over "
+                                       "(u8 CHW torch tensor, np.int32 [H,W,1] proj_indices, pageable memory): PCIe-inclusive rate")
+        tv = timed_pass(run_enqueue, frames, "enqueue only")
+        variants["enqueue_only"] = as_variant(tv, "round-1 headline form: model.inference_frame(materialize=False) back to back, next "
+                                                  "frame hinted across the whole run, results left in device buffers (no Instances, "
+                                                  "no per-frame host wait)")
+
         model.lazy_proposal_masks = True
-        for i in range(args.warmup):
-            step(i, False)
-        torch.cuda.synchronize()
-        barrier()
-        tv = time.perf_counter()
-        for i in range(args.warmup, n_frames - 1):
-            step(i, False)
-        torch.cuda.synchronize()
-        barrier()
-        tv = time.perf_counter() - tv
-        if distributed:
-            t = torch.tensor([tv], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tv = float(t.item())
-        variants["lazy_proposal_masks"] = {"value": round(args.steps * world / tv, 3), "unit": "frames/s",
-                                           "ms_per_step": round(tv / args.steps * 1e3, 3),
-                                           "note": "bitwise identical outputs; the mask head runs only on the <=100 proposals the "
-                                                   "memory update reads instead of all 256 (the reference computes and discards the "
-                                                   "rest); same three-stream schedule"}
+        tv = timed_pass(run_boundary, frames, "lazy proposal masks")
+        variants["lazy_proposal_masks"] = as_variant(tv, "bitwise identical outputs; the mask head runs only on the <=100 proposals the "
+                                                         "memory update reads instead of all 256 (the reference computes and discards "
+                                                         "the rest); through the boundary like the headline")
         model.lazy_proposal_masks = False
 
         # worst-case memory write path (SURVEY §8d): MEMORY_CLS_SCORE_THRESH 0.0 keeps up to 100 memory instances per frame
         thr0 = model.cls_score_thresh
         model.cls_score_thresh = 0.0
-        ks = []
-        for i in range(args.warmup):
-            step(i, False)
-        torch.cuda.synchronize()
-        barrier()
-        tv = time.perf_counter()
-        for i in range(args.warmup, n_frames - 1):
-            step(i, False)
-            ks.append(model.last_stats["mem_k"].clone())
-        torch.cuda.synchronize()
-        barrier()
-        tv = time.perf_counter() - tv
+        model.stats_log = []
+        tv = timed_pass(run_boundary, frames, "memory thresh 0")
+        ks = [int(c[2].item()) for c in model.stats_log[-args.steps:]]
+        model.stats_log = None
         model.cls_score_thresh = thr0
-        if distributed:
-            t = torch.tensor([tv], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tv = float(t.item())
-        variants["memory_cls_score_thresh_0"] = {"value": round(args.steps * world / tv, 3), "unit": "frames/s",
-                                                 "ms_per_step": round(tv / args.steps * 1e3, 3),
-                                                 "memory_instances_per_frame_mean": round(float(np.mean([int(k.item()) for k in ks])), 1),
-                                                 "note": "MODEL.MEMORY_CLS_SCORE_THRESH 0.0: worst-case memory write path"}
+        variants["memory_cls_score_thresh_0"] = as_variant(tv, "MODEL.MEMORY_CLS_SCORE_THRESH 0.0: worst-case memory write path",
+                                                           memory_instances_per_frame_mean=round(float(np.mean(ks)), 1))
 
         # fp32 emulated on the bf16 matrix cores (three-way operand split, six MFMAs per term set, fp32 accumulate): same
         # parity tests, 16/6 of the fp32-MFMA arithmetic ceiling.  Opt-in (EOD_CONV_MATH=bf16x3 / ops.set_conv_math).
@@ -307,44 +339,25 @@ def main():
             if not args.no_kernel_events:
                 for conv in model.roi_heads.mask_convs:
                     conv.event_log = ev2
-            for i in range(args.warmup):
-                step(i, False)
-            torch.cuda.synchronize()
-            ev2.clear()
-            barrier()
-            tv = time.perf_counter()
-            for i in range(args.warmup, n_frames - 1):
-                step(i, False)
-            torch.cuda.synchronize()
-            barrier()
-            tv = time.perf_counter() - tv
+            mark2 = []
+
+            def run_b3(fr, lo, hi):
+                if lo == args.warmup:
+                    mark2.append(len(ev2))
+                return run_boundary(fr, lo, hi)
+
+            tv = timed_pass(run_b3, frames, "bf16x3")
+            ev2 = ev2[mark2[0]:] if mark2 else ev2
             for conv in model.roi_heads.mask_convs:
                 conv.event_log = None
-            # both opt-ins together: bf16x3 arithmetic + lazy proposal masks
             model.lazy_proposal_masks = True
-            for i in range(args.warmup):
-                step(i, False)
-            torch.cuda.synchronize()
-            barrier()
-            tl = time.perf_counter()
-            for i in range(args.warmup, n_frames - 1):
-                step(i, False)
-            torch.cuda.synchronize()
-            barrier()
-            tl = time.perf_counter() - tl
+            tl = timed_pass(run_boundary, frames, "bf16x3 + lazy")
             model.lazy_proposal_masks = False
             ops.set_conv_math(prev_math)
-            if distributed:
-                t = torch.tensor([tv, tl], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tv, tl = float(t[0].item()), float(t[1].item())
-            variants["bf16x3_and_lazy_proposal_masks"] = {"value": round(args.steps * world / tl, 3), "unit": "frames/s",
-                                                          "ms_per_step": round(tl / args.steps * 1e3, 3),
-                                                          "note": "both opt-ins: bf16x3 arithmetic and proposal masks only where read"}
-            v = {"value": round(args.steps * world / tv, 3), "unit": "frames/s", "ms_per_step": round(tv / args.steps * 1e3, 3),
-                 "note": "every eligible conv/linear on the bf16 MFMA pipe with fp32 operands split into three bf16 pieces "
-                         "(6 MFMAs per K=16 step, fp32 accumulate); passes the same 1e-3 parity tests; error vs an fp64 conv "
-                         "within 2x of the fp32-MFMA kernel's (tests/test_kernels_gpu.py::test_conv_bf16x3_accuracy)"}
+            variants["bf16x3_and_lazy_proposal_masks"] = as_variant(tl, "both opt-ins: bf16x3 arithmetic and proposal masks only where read")
+            v = as_variant(tv, "every eligible conv/linear on the bf16 MFMA pipe with fp32 operands split into three bf16 pieces "
+                               "(6 MFMAs per K=16 step, fp32 accumulate); passes the same parity tests; error vs an fp64 conv "
+                               "within 2x of the fp32-MFMA kernel's (tests/test_kernels_gpu.py::test_conv_bf16x3_accuracy)")
             if ev2:
                 durs = [s_.elapsed_time(e_) for (s_, e_, _c) in ev2]
                 fl = [2.0 * (int(c.item()) if c is not None else 0) * 196 * 256 * 2304 for (_s, _e, c) in ev2]
@@ -355,49 +368,6 @@ def main():
                                   "frac_of_bf16_dense_peak_issued": round(6.0 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
                                   "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
             variants["bf16x3_split_mfma"] = v
-
-        # independent scenes interleaved on separate HIP streams of the same GPU (config 5 batches 4 sequences per GPU):
-        # each scene keeps its own model state; small kernels of one scene overlap the mask-head GEMMs of another
-        if args.streams > 1:
-            S = args.streams
-            models = [model] + [build_model(cfg, sd) for _ in range(S - 1)]
-            for m_ in models:
-                m_.overlap_branches = False      # the scenes already overlap each other; one stream per scene
-            streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-            seqs = [seq] + [SyntheticSequence(rank + 1000 * j, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell)
-                            for j in range(1, S)]
-            fr = [frames]
-            for sq in seqs[1:]:
-                lst = []
-                for i in range(n_frames):
-                    f = sq.frame(i)
-                    f["image"] = f["image"].to(dev)
-                    f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
-                    lst.append(f)
-                fr.append(lst)
-            torch.cuda.synchronize()
-
-            def mstep(i):
-                for j in range(S):
-                    with torch.cuda.stream(streams[j]):
-                        if fr[j][i]["memory_reset"]:
-                            models[j].reset_memory(seqs[j].n_cells)
-                        models[j].inference_frame(fr[j][i], refresh_memory_snapshot=True, materialize=False)
-            for i in range(args.warmup):
-                mstep(i)
-            torch.cuda.synchronize()
-            barrier()
-            tv = time.perf_counter()
-            for i in range(args.warmup, n_frames - 1):
-                mstep(i)
-            torch.cuda.synchronize()
-            barrier()
-            tv = time.perf_counter() - tv
-            variants[f"{S}_scenes_per_gpu_on_streams"] = {
-                "value": round(args.steps * S * world / tv, 3), "unit": "frames/s", "ms_per_step": round(tv / args.steps * 1e3, 3),
-                "note": f"{S} independent scenes per GPU, one HIP stream each (a step = {S} frames)"}
-            model.overlap_branches = True
-            del models, fr
 
     # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
     rec = RecordBuffer(max_rows=4 * 108)
@@ -465,10 +435,14 @@ def main():
                        "memory_cls_score_thresh": args.memory_thresh,
                        "schedule": ("3 HIP streams per scene: main (FPN + memory fusion, proposals, both mask passes), side (box "
                                     "cascade, memory selection + write-back), look-ahead (the next frame's memory-independent "
-                                    "ResNet trunk); every step does one frame's full work, results bitwise equal to one stream"
+                                    "ResNet trunk, inside an episode); frame t's Instances are sliced out after frame t+1 has been "
+                                    "enqueued; every step does one frame's full work, results bitwise equal to one stream"
                                     if model.overlap_branches else "one HIP stream"),
                        "proposals_per_frame_mean": round(float(np.mean(pc)), 1), "detections_per_frame_mean": round(float(np.mean(dc)), 1),
                        "memory_instances_per_frame_mean": round(float(np.mean(mk)), 1)},
+            "boundary": "model([episode of <=20 frame dicts]) -> [{'instances': Instances(pred_boxes, scores, pred_classes i64, "
+                        "pred_masks bool [D,H,W])}] per frame (train_mp3d.py:186, custom_rcnn.py:537-546); inputs resident in HBM",
+            "boundary_host_inputs": boundary_host,
             "roofline": roofline,
             "frame_roofline": frame_roofline(H, W, float(np.mean(pc)), float(np.mean(dc)), elapsed / args.steps, headline_math),
             "variants": variants,

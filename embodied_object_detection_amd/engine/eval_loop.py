@@ -37,8 +37,21 @@ def gt_to_coco_xyxy(gt_boxes: torch.Tensor) -> np.ndarray:
     return np.asarray(out, dtype=np.float64).reshape(-1, 4)
 
 
+class RecordBufferOverflow(RuntimeError):
+    pass
+
+
+def rows_needed(frames_per_rank: int, every: int = 5, max_dets: int = 100, max_gt: int = 156) -> int:
+    """Capacity of the fixed-shape collective buffer for a rank that evaluates `frames_per_rank` frames: every `every`-th
+    frame contributes at most `max_dets` detections (COCO maxDets) and its GT boxes.  Every rank must pass the SAME number
+    (the buffer shape is part of the collective), so callers take the maximum over ranks of the per-rank frame counts."""
+    imgs = (int(frames_per_rank) + every - 1) // every + 1
+    return max(1024, imgs * (max_dets + max_gt))
+
+
 class RecordBuffer:
-    """Host-side staging of this rank's records; `to_tensor` pads to the fixed [rows, ROW] shape of the collective."""
+    """Host-side staging of this rank's records; `to_tensor` pads to the fixed [rows, ROW] shape of the collective.
+    A row that does not fit raises: a silently truncated buffer would give a wrong AP without an error."""
 
     def __init__(self, max_rows: int):
         self.max_rows = max_rows
@@ -46,10 +59,12 @@ class RecordBuffer:
         self.dropped = 0
 
     def add(self, row: Sequence[float]):
-        if len(self.rows) < self.max_rows:
-            self.rows.append(list(row))
-        else:
+        if len(self.rows) >= self.max_rows:
             self.dropped += 1
+            raise RecordBufferOverflow(
+                f"record buffer full ({self.max_rows} rows): size it with eval_loop.rows_needed(frames_per_rank) -- the "
+                "aggregate AP would silently lose detections otherwise")
+        self.rows.append(list(row))
 
     def to_tensor(self, device) -> torch.Tensor:
         t = torch.zeros((self.max_rows, ROW), dtype=torch.float32)
@@ -116,10 +131,15 @@ def inference_on_scenes(model, scenes: Iterable, rank: int = 0, max_rows: int = 
 
 def gather_records(rec: RecordBuffer, rank: int, world: int, device) -> np.ndarray:
     """ONE collective: every rank writes its slice of a zero [world, rows, ROW] buffer, all_reduce(SUM)."""
+    if rec.dropped:
+        raise RecordBufferOverflow(f"{rec.dropped} records were dropped")
     local = rec.to_tensor(device)
-    if world == 1:
-        return local.cpu().numpy()[None]
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if world != 1:
+            raise RuntimeError(f"world={world} but torch.distributed is not initialised")
+        return local.cpu().numpy()[None]
+    # also with ONE rank the buffer goes through the collective (RCCL on GPUs, gloo on CPU): same code path at every size
     buf = torch.zeros((world,) + tuple(local.shape), dtype=torch.float32, device=device)
     buf[rank] = local
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)

@@ -127,7 +127,10 @@ class CustomRCNNRecurrent:
         self._writer = None
         self._writer_key = None
         self._post = None
+        self._posts = None
+        self._post_slot = 0
         self.last_stats: Dict[str, torch.Tensor] = {}
+        self.stats_log = None
 
     # detectron2 nn.Module surface used by the drivers
     def eval(self):
@@ -158,15 +161,20 @@ class CustomRCNNRecurrent:
         if self._writer_key != key:
             self._writer = ops.MemoryWriter(H, W, n_cells, 100, self.proposal_generator.cap, self.device, mask_thresh=0.5)
             self._writer_key = key
-        if self._post is None or self._post["hw"] != (H, W):
+        if self._posts is None or self._posts[0]["hw"] != (H, W):
+            # two result sets: frame t's `Instances` are sliced out of set t % 2 only after frame t+1 has been enqueued
+            # (`forward`), so the host's read-back of the detection count never leaves the GPU idle
             D = self.roi_heads.topk
             dev = self.device
-            self._post = dict(
+            self._posts = [dict(
                 hw=(H, W),
                 boxes=torch.zeros((D, 4), dtype=torch.float32, device=dev), scores=torch.zeros((D,), dtype=torch.float32, device=dev),
                 classes=torch.zeros((D,), dtype=torch.int32, device=dev), src=torch.zeros((D,), dtype=torch.int32, device=dev),
                 count=torch.zeros((1,), dtype=torch.int32, device=dev),
-                masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev))
+                masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev),
+                count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), ready=torch.cuda.Event()) for _ in range(2)]
+            self._post_slot = 0
+        self._post = self._posts[self._post_slot]
 
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, batched_inputs: List[List[dict]]):
@@ -174,6 +182,7 @@ class CustomRCNNRecurrent:
         if self.training:
             raise NotImplementedError("training forward is out of scope for the hot path (SURVEY §8f rank 4)")
         batch_output = []
+        pending = None            # ticket of the previous frame: its Instances are built after this frame has been enqueued
         for input_seq in batched_inputs:
             for i, frame in enumerate(input_seq):
                 n_cells = int(input_seq[0]["memory"].shape[0])
@@ -183,11 +192,24 @@ class CustomRCNNRecurrent:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
                 nxt = input_seq[i + 1] if i + 1 < len(input_seq) else None
-                out = self.inference_frame(frame, refresh_memory_snapshot=refresh, next_frame=nxt)
+                self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt)
+                ticket = self._post_ticket()
+                if pending is not None:
+                    batch_output.append({"instances": self._materialize(pending)})
+                pending = ticket
                 if self.save_semmap and i == 0:
                     self.save_memory_snapshot(frame["sequence_name"])          # custom_rcnn.py:518-530
-                batch_output.append(out)
+        if pending is not None:
+            batch_output.append({"instances": self._materialize(pending)})
         return batch_output
+
+    def _post_ticket(self):
+        """Async read-back of the frame's detection count into pinned host memory + an event; flips the result set."""
+        P = self._post
+        P["count_host"].copy_(P["count"], non_blocking=True)
+        P["ready"].record(torch.cuda.current_stream(self.device))
+        self._post_slot ^= 1
+        return P
 
     def _device_image(self, frame) -> torch.Tensor:
         img = frame["image"]
@@ -343,9 +365,11 @@ class CustomRCNNRecurrent:
         elif update_mem:
             self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
         self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
+        if self.stats_log is not None:      # bench.py: device-side copies of the frame's counters, read after the timed region
+            self.stats_log.append((prop_count.clone(), P["count"].clone(), self._writer.k_out.clone()))
         if not materialize:
             return None
-        return {"instances": self._materialize((out_h, out_w))}
+        return {"instances": self._materialize(self._post_ticket())}
 
     def select_memory_instances(self, prop_boxes, prop_scores, prop_count, image_hw):
         """`inference_with_proposals` up to the NMS (custom_rcnn.py:825-875): CLIP re-score of the proposals, threshold
@@ -367,15 +391,16 @@ class CustomRCNNRecurrent:
         return write_snapshot(self.output_dir, sequence_name, semmap.cpu().numpy(), self.implicit_memory.cpu().numpy(),
                               self.observations.cpu().numpy())
 
-    def _materialize(self, out_hw) -> Instances:
-        """Slice the fixed-capacity device buffers by the detection count (the frame's only host sync)."""
-        P = self._post
-        n = int(P["count"].item())
-        inst = Instances(out_hw)
+    def _materialize(self, P) -> Instances:
+        """Slice a result set by its detection count (the frame's only host wait: on the event recorded after the count's
+        async copy).  The paste kernel writes 0/1 bytes, so the masks are handed out as a bool view's copy."""
+        P["ready"].synchronize()
+        n = int(P["count_host"][0])
+        inst = Instances(P["hw"])
         inst.pred_boxes = Boxes(P["boxes"][:n].clone())
         inst.scores = P["scores"][:n].clone()
         inst.pred_classes = P["classes"][:n].to(torch.int64)
-        inst.pred_masks = P["masks"][:n].to(torch.bool)
+        inst.pred_masks = P["masks"][:n].view(torch.bool).clone()
         return inst
 
     def semantic_map(self) -> torch.Tensor:

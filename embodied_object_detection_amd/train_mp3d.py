@@ -40,7 +40,8 @@ def default_argument_parser():
 
 def do_test(cfg, model, args, rank: int, world: int):
     from .data.synthetic import SyntheticSequence
-    from .engine.eval_loop import (episode_offsets, evaluate_gathered, gather_records, inference_on_scenes, shard_scenes)
+    from .engine.eval_loop import (episode_offsets, evaluate_gathered, gather_records, inference_on_scenes, rows_needed,
+                                   shard_scenes)
     import os
     data_root = str(cfg.MODEL.TEST_DATA_PATH)
     if os.path.isdir(os.path.join(data_root, "memory_data")) and os.path.isdir(os.path.join(data_root, "sensor_data")):
@@ -51,13 +52,16 @@ def do_test(cfg, model, args, rank: int, world: int):
                                       memory_type=cfg.MODEL.MEMORY_TYPE, semmap_path="")
         ds = Mp3dScenes(loader)
         scenes, offs = ds.shard(rank, world), ds.episode_offsets()
+        # same capacity on every rank (the buffer shape is part of the collective): the busiest rank's frame count
+        per_rank = [sum(len(sc.indices) for sc in ds.shard(r, world)) * 20 for r in range(world)]
         print(f"[rank {rank}] {len(loader)} episode files in {len(ds)} scenes under {data_root}; this rank: {len(scenes)} scenes")
     else:
         H, W = args.synthetic_size
         mine = shard_scenes(args.synthetic_scenes, rank, world)
         scenes = [SyntheticSequence(s, H=H, W=W, n_frames=args.synthetic_frames) for s in mine]
         offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
-    res = inference_on_scenes(model, scenes, rank, scene_episode_offset=offs)
+        per_rank = [len(shard_scenes(args.synthetic_scenes, r, world)) * args.synthetic_frames for r in range(world)]
+    res = inference_on_scenes(model, scenes, rank, max_rows=rows_needed(max(per_rank)), scene_episode_offset=offs)
     buf = gather_records(res["records"], rank, world, model.device)
     out = None
     if rank == 0:

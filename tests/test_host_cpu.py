@@ -356,3 +356,34 @@ def test_bench_contract_helpers_and_committed_line():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and isinstance(c["sample"], str) and c["value"] > 0
+
+
+def test_record_buffer_overflow_raises():
+    """A full record buffer must fail loudly (a truncated buffer would give a wrong AP without an error)."""
+    import pytest
+    from embodied_object_detection_amd.engine.eval_loop import RecordBuffer, RecordBufferOverflow, rows_needed
+    rec = RecordBuffer(2)
+    rec.add([1] * 10)
+    rec.add([1] * 10)
+    with pytest.raises(RecordBufferOverflow):
+        rec.add([1] * 10)
+    assert rows_needed(2000) >= (2000 // 5) * 200
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """`python bench.py --gpus 8` without a launcher must start 8 workers or exit non-zero -- never run one rank and print n_gpus 1."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only" in r.stderr and not r.stdout.strip()
+    # and a launcher whose world size disagrees with --gpus is refused too
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr

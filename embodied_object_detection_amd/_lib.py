@@ -61,7 +61,7 @@ class EodMemWriteDesc(C.Structure):
         ("det_count", C.c_void_p), ("K_cap", C.c_int32), ("R_cap", C.c_int32), ("proj", C.c_void_p),
         ("H", C.c_int32), ("W", C.c_int32), ("D", C.c_int32), ("n_cells", C.c_int32), ("mask_thresh", C.c_float),
         ("mem", C.c_void_p), ("obs", C.c_void_p), ("k_out", C.c_void_p), ("workspace", C.c_void_p),
-        ("workspace_bytes", C.c_size_t),
+        ("workspace_bytes", C.c_size_t), ("dirty", C.c_void_p), ("err_flags", C.c_void_p),
     ]
 
 
@@ -103,12 +103,16 @@ SIGNATURES = {
                                            C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_memory_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "eod_memory_normalize_dirty_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_gather_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p]),
+                                         C.c_void_p]),
+    "eod_memory_project_weights_bytes": (C.c_size_t, []),
+    "eod_memory_project_prepare": (C.c_int, [C.c_void_p] * 8),
+    "eod_memory_project_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),
     "eod_memory_write_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
-    "eod_memory_write_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "eod_memory_write_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_write": (C.c_int, [C.POINTER(EodMemWriteDesc), C.c_void_p]),
     "eod_semmap_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

@@ -1,5 +1,6 @@
 // SMNet-style spatial feature memory on device: depth un-projection + integer grid-cell indexing, the memory
-// READ (observation normalise -> fp16 -> gather by cell index -> cascaded average pooling) and the memory
+// READ (full observation normalise -> fp16; the incremental normalise, the gather + pooling and the projection live in
+// memory_read.hip) and the memory
 // WRITE (instance CLIP features -> per-pixel mean over covering instances -> every 8th observed pixel ->
 // per-cell mean -> accumulate, observation counters).
 //
@@ -90,106 +91,6 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------
-// a8: gather + cascaded average pooling
-// ------------------------------------------------------------------------------------------------------
-// One workgroup = one 32x32 pixel tile (= one stride-32 cell); wave q owns the 16x16 quadrant (= one stride-16
-// cell); each lane owns 8 consecutive channels (16 B of fp16 -> one 1 KiB coalesced row read per pixel).
-// Pooling order mirrors torch: avg_pool2d(4) sums the 16 pixels row-major in f32 and divides by 16; each
-// following avg_pool2d(2) sums 4 values row-major, divides by 4 and rounds to fp16 (timm.py:152,168).
-__device__ __forceinline__ float round_f16(float v) { return __half2float(__float2half_rn(v)); }
-
-__global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W, int D,
-                                                           float* __restrict__ p8, float* __restrict__ p16, float* __restrict__ p32) {
-  __shared__ int sidx[32 * 32];
-  __shared__ float s16[4][512];
-  const int tiles_x = W >> 5;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 1024; i += 256) {
-    const int yy = i >> 5, xx = i & 31;
-    sidx[i] = proj[(size_t)(ty * 32 + yy) * W + tx * 32 + xx];
-  }
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const int qy = wave >> 1, qx = wave & 1;  // quadrant
-  const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5;
-  for (int c0 = lane * 8; c0 < D; c0 += 512) {
-    float acc16[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
-    // 2x2 stride-8 cells in this quadrant, row-major
-#pragma unroll 1
-    for (int cy8 = 0; cy8 < 2; ++cy8) {
-#pragma unroll 1
-      for (int cx8 = 0; cx8 < 2; ++cx8) {
-        float acc8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
-        // 2x2 blocks of 4x4 pixels, row-major
-#pragma unroll 1
-        for (int by = 0; by < 2; ++by) {
-#pragma unroll 1
-          for (int bx = 0; bx < 2; ++bx) {
-            float acc4[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-            const int py0 = qy * 16 + cy8 * 8 + by * 4, px0 = qx * 16 + cx8 * 8 + bx * 4;
-#pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-              uint4 raw[4];
-#pragma unroll
-              for (int dx = 0; dx < 4; ++dx) {
-                const int cell = sidx[(py0 + dy) * 32 + px0 + dx];
-                raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * D + c0);
-              }
-#pragma unroll
-              for (int dx = 0; dx < 4; ++dx) {
-                const __half2* h = reinterpret_cast<const __half2*>(&raw[dx]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const float2 f = __half22float2(h[q]);
-                  acc4[2 * q] += f.x;
-                  acc4[2 * q + 1] += f.y;
-                }
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
-          }
-        }
-        float v8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          v8[q] = round_f16(acc8[q] * 0.25f);
-          acc16[q] += v8[q];
-        }
-        const int oy = ty * 4 + qy * 2 + cy8, ox = tx * 4 + qx * 2 + cx8;
-        float* o = p8 + ((size_t)oy * w8 + ox) * D + c0;
-        *reinterpret_cast<f32x4*>(o) = f32x4{v8[0], v8[1], v8[2], v8[3]};
-        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
-      }
-    }
-    float v16[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      v16[q] = round_f16(acc16[q] * 0.25f);
-      s16[wave][c0 + q] = v16[q];
-    }
-    {
-      const int oy = ty * 2 + qy, ox = tx * 2 + qx;
-      float* o = p16 + ((size_t)oy * w16 + ox) * D + c0;
-      *reinterpret_cast<f32x4*>(o) = f32x4{v16[0], v16[1], v16[2], v16[3]};
-      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v16[4], v16[5], v16[6], v16[7]};
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < D; c += 256) {
-    const float s = ((s16[0][c] + s16[1][c]) + s16[2][c]) + s16[3][c];
-    p32[((size_t)ty * w32 + tx) * D + c] = round_f16(s * 0.25f);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // a16-a19 write path
 // ------------------------------------------------------------------------------------------------------
 struct MwWs {
@@ -203,7 +104,7 @@ struct MwWs {
   int* cell_slot;   // [N]
   int* slot_cell;   // [U_max]
   int* n_slots;     // [1]
-  long long* acc;   // [U_max, D] fixed point 2^-32
+  long long* wtab;  // [U_max, K_cap] fixed point 2^-32: sum over the slot's sampled pixels of 1/cover for every instance
   int* slot_cnt;    // [U_max]
   int* blk_pix;     // [ceil(P/4096)]
   int* blk_cell;    // [ceil(N/4096)]
@@ -212,7 +113,8 @@ struct MwWs {
 
 inline size_t up(size_t v) { return (v + 255) / 256 * 256; }
 
-MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap) {
+MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap) {
+  (void)D;
   MwWs w{};
   char* b = static_cast<char*>(base);
   size_t off = 0;
@@ -234,7 +136,7 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap) {
   w.cell_slot = (int*)take((size_t)n_cells * 4);
   w.slot_cell = (int*)take(umax * 4);
   w.n_slots = (int*)take(4);
-  w.acc = (long long*)take(umax * (size_t)D * 8);
+  w.wtab = (long long*)take(umax * (size_t)K_cap * 8);
   w.slot_cnt = (int*)take(umax * 4);
   w.blk_pix = (int*)take(((P + 4095) / 4096 + 1) * 4);
   w.blk_cell = (int*)take((((size_t)n_cells + 4095) / 4096 + 1) * 4);
@@ -292,10 +194,12 @@ __device__ __forceinline__ bool mask_hit(const float* __restrict__ m, float x0, 
 // per pixel: number of covering instances; marks every cell the frame hits (for the observation counters)
 __global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
                                                            const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                           const int* __restrict__ proj, int H, int W, float thr,
-                                                           unsigned char* __restrict__ cover, int* __restrict__ cell_flag) {
+                                                           const int* __restrict__ proj, int H, int W, int n_cells, float thr,
+                                                           unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
+                                                           int* __restrict__ err) {
   const int K = *k_u;
   if (K == 0) return;
+  bool bad = false;
   const int total = H * W;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
     const int y = p / W, x = p - y * W;
@@ -310,9 +214,17 @@ __global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restric
       if (mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr)) ++cnt;
     }
     cover[p] = (unsigned char)cnt;
-    cell_flag[proj[p]] = 1;
+    int cell = proj[p];
+    if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
+      bad = true;
+      cell = cell < 0 ? 0 : n_cells - 1;
+    }
+    cell_flag[cell] = 1;
   }
+  if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
 }
+
+__device__ __forceinline__ int clamp_cell(int cell, int n_cells) { return cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell); }
 
 // Stream compaction in two launches: per-block counts, then per-block local scan + prefix of the block counts.
 // Block = 1024 threads x 4 consecutive elements.  Used for (a) observed pixels -> every 8th in row-major order
@@ -359,7 +271,7 @@ __global__ __launch_bounds__(1024) void mw_count_pixels_kernel(const unsigned ch
 }
 
 __global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
-                                                          const int* __restrict__ proj, const int* __restrict__ block_cnt,
+                                                          const int* __restrict__ proj, int n_cells, const int* __restrict__ block_cnt,
                                                           int* __restrict__ sel_pix, int* __restrict__ n_sel, int* __restrict__ cell_mark) {
   if (*k_u == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_sel = 0;
@@ -387,7 +299,7 @@ __global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __
     if (ob[j]) {
       if ((rank & 7) == 0) {
         sel_pix[rank >> 3] = base + j;
-        cell_mark[proj[base + j]] = 1;
+        cell_mark[clamp_cell(proj[base + j], n_cells)] = 1;
       }
       ++rank;
     }
@@ -443,22 +355,24 @@ __global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ 
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_slots = sh_off + total;
 }
 
-__global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ acc, int* __restrict__ slot_cnt,
-                                                             const int* __restrict__ n_slots, int D) {
-  const size_t total = (size_t)(*n_slots) * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) acc[i] = 0;
+__global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ wtab, int* __restrict__ slot_cnt,
+                                                             const int* __restrict__ n_slots, int K_cap) {
+  const size_t total = (size_t)(*n_slots) * K_cap;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) wtab[i] = 0;
   const int ns = *n_slots;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) slot_cnt[i] = 0;
 }
 
-// one wave per selected pixel: mean of the covering instances' features (instance order), added exactly
-// (2^-32 fixed point, integer atomics: order independent, bitwise reproducible) to the pixel's cell slot
-__global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restrict__ featn, const float* __restrict__ boxes,
-                                                             const float* __restrict__ masks, const int* __restrict__ inst_rows,
-                                                             const int* __restrict__ k_u, const int* __restrict__ sel_pix,
-                                                             const int* __restrict__ n_sel, const unsigned char* __restrict__ cover,
-                                                             const int* __restrict__ proj, const int* __restrict__ cell_slot, int W,
-                                                             int D, float thr, long long* __restrict__ acc, int* __restrict__ slot_cnt) {
+// The per-cell mean of the per-pixel means (custom_rcnn.py:884-936) is linear in the instance features:
+//   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
+// so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
+// bitwise reproducible) instead of 512 channel atomics.  One wave per sampled pixel, lanes over the instances.
+__global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                             const int* __restrict__ inst_rows, const int* __restrict__ k_u,
+                                                             const int* __restrict__ sel_pix, const int* __restrict__ n_sel,
+                                                             const unsigned char* __restrict__ cover, const int* __restrict__ proj,
+                                                             int n_cells, const int* __restrict__ cell_slot, int W, int K_cap, float thr,
+                                                             long long* __restrict__ wtab, int* __restrict__ slot_cnt) {
   const int K = *k_u;
   const int S = *n_sel;
   const int lane = threadIdx.x & 63;
@@ -466,65 +380,59 @@ __global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restr
   for (int s = blockIdx.x * wpb + (threadIdx.x >> 6); s < S; s += gridDim.x * wpb) {
     const int p = sel_pix[s];
     const int y = p / W, x = p - y * W;
-    const float cnt = (float)cover[p];
-    // lane owns channels q*64 + lane: every wave-instruction (load and atomic) covers 64 consecutive elements
-    float a[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a[q] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-      const int k = k0 + lane;
-      bool hit = false;
-      int r = 0;
-      if (k < K) {
-        r = inst_rows[k];
-        const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
-        hit = mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr);
-      }
-      u64 bal = __ballot(hit);
-      while (bal) {
-        const int src = __ffsll((long long)bal) - 1;
-        bal &= bal - 1;
-        const int rr = __shfl(r, src, 64);
-        const float* f = featn + (size_t)rr * D + lane;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] += f[q * 64];
-      }
-    }
-    const int slot = cell_slot[proj[p]];
-    long long* dst = acc + (size_t)slot * D + lane;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float v = a[q] / cnt;
-      const long long fx = (long long)llrintf(v * 4294967296.0f);
-      atomicAdd(reinterpret_cast<unsigned long long*>(dst + q * 64), (unsigned long long)fx);
+    const long long share = (long long)llrint(4294967296.0 / (double)cover[p]);
+    const int slot = cell_slot[clamp_cell(proj[p], n_cells)];
+    long long* dst = wtab + (size_t)slot * K_cap;
+    for (int k = lane; k < K; k += 64) {
+      const int r = inst_rows[k];
+      const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
+      if (mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr))
+        atomicAdd(reinterpret_cast<unsigned long long*>(dst + k), (unsigned long long)share);
     }
     if (lane == 0) atomicAdd(slot_cnt + slot, 1);
   }
 }
 
-// per slot: mean -> mem[cell] += mean  (semmap_features + semmap_update, custom_rcnn.py:738-743)
-__global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restrict__ acc, const int* __restrict__ slot_cnt,
-                                                        const int* __restrict__ slot_cell, const int* __restrict__ n_slots, int D,
-                                                        float* __restrict__ mem) {
-  const size_t total = (size_t)(*n_slots) * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int slot = (int)(i / D);
-    const int c = (int)(i - (size_t)slot * D);
-    const double sum = (double)acc[i] * (1.0 / 4294967296.0);
-    const float mean = (float)sum / (float)slot_cnt[slot];
-    float* m = mem + (size_t)slot_cell[slot] * D + c;
-    *m = *m + mean;
+// one wave per slot: mean = (sum_k W_k f_k) / n in f64 (instance order), mem[cell] += mean (custom_rcnn.py:738-743)
+__global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restrict__ wtab, const int* __restrict__ slot_cnt,
+                                                        const int* __restrict__ slot_cell, const int* __restrict__ n_slots,
+                                                        const float* __restrict__ featn, const int* __restrict__ inst_rows,
+                                                        const int* __restrict__ k_u, int K_cap, int D, float* __restrict__ mem) {
+  const int K = *k_u;
+  const int NS = *n_slots;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int slot = blockIdx.x * wpb + (threadIdx.x >> 6); slot < NS; slot += gridDim.x * wpb) {
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.0;
+    const long long* wt = wtab + (size_t)slot * K_cap;
+    for (int k = 0; k < K; ++k) {
+      const long long wk = wt[k];
+      if (wk == 0) continue;                      // wave-uniform
+      const double w = (double)wk * (1.0 / 4294967296.0);
+      const float* f = featn + (size_t)inst_rows[k] * D + lane;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += w * (double)f[q * 64];
+    }
+    const double inv = 1.0 / (double)slot_cnt[slot];
+    float* m = mem + (size_t)slot_cell[slot] * D + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q * 64] = m[q * 64] + (float)(a[q] * inv);
   }
 }
 
 // observation counters (custom_rcnn.py:699-701,743) + reset of the per-frame cell flags
+// `dirty` (caller-owned, may be NULL): every cell whose observation count (hence its normalised row) changed; consumed and
+// cleared by eod_memory_normalize_dirty_f16.  Cells written by mw_apply are a subset (sampled pixels are pixels of the frame).
 __global__ __launch_bounds__(256) void mw_obs_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark, const int* __restrict__ k_u,
-                                                      int N, float* __restrict__ obs) {
+                                                      int N, float* __restrict__ obs, int* __restrict__ dirty) {
   if (*k_u == 0) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     if (cell_flag[i]) {
       obs[i] += 1.0f;
       cell_flag[i] = 0;
+      if (dirty) dirty[i] = 1;
     }
     cell_mark[i] = 0;
   }
@@ -567,26 +475,16 @@ extern "C" int eod_memory_normalize_f16(const float* mem, const float* obs, uint
   return eod_launch_status();
 }
 
-extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, float* pooled8,
-                                      float* pooled16, float* pooled32, eod_stream_t stream) {
-  if (!mem_f16 || !proj || !pooled8 || !pooled16 || !pooled32) return EOD_ERR_NULL;
-  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0) return EOD_ERR_BAD_DIMS;
-  if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled8) || !eod_aligned16(pooled16)) return EOD_ERR_ALIGN;
-  hipLaunchKernelGGL(gather_pool_kernel, dim3((H >> 5) * (W >> 5)), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const __half*>(mem_f16), proj, H, W, D, pooled8, pooled16, pooled32);
-  return eod_launch_status();
-}
-
 extern "C" size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap) {
-  (void)K_cap;
-  return mw_carve(nullptr, H, W, D, n_cells, R_cap).bytes;
+  return mw_carve(nullptr, H, W, D, n_cells, R_cap, K_cap).bytes;
 }
 
-extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int R_cap,
+extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int K_cap, int R_cap,
                                      eod_stream_t stream) {
   // the per-frame cell flags must start at zero; every eod_memory_write leaves them zero again
   if (!workspace) return EOD_ERR_NULL;
-  const MwWs w = mw_carve(workspace, H, W, D, n_cells, R_cap);
+  if (K_cap <= 0) return EOD_ERR_BAD_DIMS;
+  const MwWs w = mw_carve(workspace, H, W, D, n_cells, R_cap, K_cap);
   if (workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   if (hipMemsetAsync(w.cell_flag, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
   if (hipMemsetAsync(w.cell_mark, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
@@ -608,27 +506,28 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
     return EOD_ERR_NULL;
   if (d->H <= 0 || d->W <= 0 || d->D != 512 || d->n_cells <= 0 || d->R_cap <= 0 || d->R_cap > 512 || d->K_cap <= 0)
     return EOD_ERR_BAD_DIMS;
-  const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap);
+  const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap, d->K_cap);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
   hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, s, d->det_rows, d->det_count, d->K_cap, d->R_cap, w.inst_rows, w.k_u,
                      d->k_out);
   hipLaunchKernelGGL(mw_coverage_kernel, dim3(blocks_for((size_t)P)), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
-                     d->proj, d->H, d->W, d->mask_thresh, w.cover, w.cell_flag);
+                     d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, d->err_flags);
   const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS, cb = (d->n_cells + SCAN_ELEMS - 1) / SCAN_ELEMS;
   hipLaunchKernelGGL(mw_count_pixels_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, w.blk_pix);
-  hipLaunchKernelGGL(mw_select_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, w.blk_pix, w.sel_pix, w.n_sel,
+  hipLaunchKernelGGL(mw_select_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, d->n_cells, w.blk_pix, w.sel_pix, w.n_sel,
                      w.cell_mark);
   hipLaunchKernelGGL(mw_count_cells_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell);
   hipLaunchKernelGGL(mw_slots_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell, w.cell_slot, w.slot_cell,
                      w.n_slots);
-  hipLaunchKernelGGL(mw_zero_slots_kernel, dim3(1024), dim3(256), 0, s, w.acc, w.slot_cnt, w.n_slots, d->D);
-  hipLaunchKernelGGL(mw_accumulate_kernel, dim3(2048), dim3(256), 0, s, d->featn, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
-                     w.sel_pix, w.n_sel, w.cover, d->proj, w.cell_slot, d->W, d->D, d->mask_thresh, w.acc, w.slot_cnt);
-  hipLaunchKernelGGL(mw_apply_kernel, dim3(1024), dim3(256), 0, s, w.acc, w.slot_cnt, w.slot_cell, w.n_slots, d->D, d->mem);
+  hipLaunchKernelGGL(mw_zero_slots_kernel, dim3(512), dim3(256), 0, s, w.wtab, w.slot_cnt, w.n_slots, d->K_cap);
+  hipLaunchKernelGGL(mw_accumulate_kernel, dim3(2048), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.sel_pix,
+                     w.n_sel, w.cover, d->proj, d->n_cells, w.cell_slot, d->W, d->K_cap, d->mask_thresh, w.wtab, w.slot_cnt);
+  hipLaunchKernelGGL(mw_apply_kernel, dim3(1024), dim3(256), 0, s, w.wtab, w.slot_cnt, w.slot_cell, w.n_slots, d->featn, w.inst_rows,
+                     w.k_u, d->K_cap, d->D, d->mem);
   hipLaunchKernelGGL(mw_obs_kernel, dim3(blocks_for((size_t)d->n_cells)), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u, d->n_cells,
-                     d->obs);
+                     d->obs, d->dirty);
   return eod_launch_status();
 }
 

@@ -1,0 +1,466 @@
+// Memory READ path of the spatial feature memory (SURVEY §8 rows a4 + a8), second generation.
+//
+//   a4  create_implicit_memory + fp16 cast      custom_rcnn.py:762-774,1036   -> normalize_dirty_f16_kernel
+//   a8  mem_fp16[proj] -> avg_pool 4,2,2,2      backbone/timm.py:147-168       -> gather_pool_kernel
+//   a8  Conv2d(512->256,1x1) x3, x weight, sum  backbone/timm.py:174-189       -> project_fuse_kernel
+//
+// What changed against the first generation (memory.hip of round 1) and why (profiles/r01_bench_640_kernel_stats.csv):
+//  * the fp16 table is kept INCREMENTALLY: the write path marks the cells whose accumulator row or observation count changed
+//    (`dirty`), and only those rows are re-normalised.  The reference clones and divides the whole map every frame (O(N):
+//    123 MB at 40 000 cells, 805 MB at 262 144) for a few thousand changed rows.
+//  * the gather fetches every DISTINCT cell of a 32x32 pixel tile once into LDS (an LDS hash de-duplicates the 1 024 indices;
+//    round 1 issued one 1 KiB row read per pixel: 420 MB of L2 traffic for <= 60 MB compulsory) and pools out of LDS.  A 4x4
+//    block whose 16 pixels share one cell is the cell's value exactly (n*v is exact in f32 for n <= 16 and an 11-bit v), so
+//    the 16 adds are skipped; every other block is summed in torch's row-major order: results stay bit-identical.
+//  * the three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion are ONE launch on the f16 matrix cores: the pooled operand is
+//    exactly fp16 (timm.py:168 casts it), each fp32 weight is split into three f16 pieces of a per-row power-of-two scaling
+//    (h + m + l reproduces the scaled weight to 2^-25 of the row maximum), every f16 x f16 product is exact in the fp32
+//    accumulator: fp32-class result at 16/3 of the fp32-MFMA rate.  Out-of-range cell indices are clamped and flagged.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+typedef unsigned long long u64;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------------
+// a4, incremental: rows flagged dirty -> out_f16[row] = half(obs > 1 ? mem / obs : mem); flags cleared
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* __restrict__ mem, const float* __restrict__ obs,
+                                                                   int* __restrict__ dirty, __half* __restrict__ out, int n_cells) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int n_groups = (n_cells + 63) >> 6;
+  for (int g = blockIdx.x * wpb + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * wpb) {
+    const int c = (g << 6) + lane;
+    int f = 0;
+    if (c < n_cells) {
+      f = dirty[c];
+      if (f) dirty[c] = 0;
+    }
+    u64 bal = __ballot(f != 0);
+    while (bal) {
+      const int src = __ffsll((long long)bal) - 1;
+      bal &= bal - 1;
+      const int cell = (g << 6) + src;
+      const float o = obs[cell];
+      const float* m = mem + (size_t)cell * 512 + lane * 8;
+      f32x4 a = *reinterpret_cast<const f32x4*>(m);
+      f32x4 b = *reinterpret_cast<const f32x4*>(m + 4);
+      if (o > 1.0f) {
+        a.x = __fdiv_rn(a.x, o); a.y = __fdiv_rn(a.y, o); a.z = __fdiv_rn(a.z, o); a.w = __fdiv_rn(a.w, o);
+        b.x = __fdiv_rn(b.x, o); b.y = __fdiv_rn(b.y, o); b.z = __fdiv_rn(b.z, o); b.w = __fdiv_rn(b.w, o);
+      }
+      __half2 h0 = __floats2half2_rn(a.x, a.y), h1 = __floats2half2_rn(a.z, a.w);
+      __half2 h2 = __floats2half2_rn(b.x, b.y), h3 = __floats2half2_rn(b.z, b.w);
+      uint4 pk;
+      pk.x = *reinterpret_cast<unsigned*>(&h0);
+      pk.y = *reinterpret_cast<unsigned*>(&h1);
+      pk.z = *reinterpret_cast<unsigned*>(&h2);
+      pk.w = *reinterpret_cast<unsigned*>(&h3);
+      *reinterpret_cast<uint4*>(out + (size_t)cell * 512 + lane * 8) = pk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a8: gather + cascaded average pooling, one workgroup per 32x32 pixel tile
+// ------------------------------------------------------------------------------------------------------
+constexpr int GP_CAP = 64;      // distinct rows cached per tile (64 KiB of LDS); pixels beyond it read HBM/L2 directly
+constexpr int GP_HASH = 512;    // open-addressing table (power of two, >= 2 * typical distinct count)
+
+constexpr int GP_PROBES = 16;   // linear-probing bound; a pixel whose cell finds no entry within it reads the table directly
+
+struct GpShared {
+  int key[GP_HASH];             // cell index or -1
+  short slot_of[GP_HASH];       // hash entry -> row slot (or -1 when beyond GP_CAP)
+  short pix[1024];              // per pixel: hash entry, then row slot; -1 = read the table directly
+  int ucell[GP_CAP];
+  short blk[64];                // per 4x4 block: the common slot of its 16 pixels, or -1
+  int wave_cnt[4];
+  int n_unique;
+  float s16[4][512];
+};
+
+__device__ __forceinline__ void add8(float (&acc)[8], const uint4& raw) {
+  const __half2* h = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float2 f = __half22float2(h[q]);
+    acc[2 * q] += f.x;
+    acc[2 * q + 1] += f.y;
+  }
+}
+
+__device__ __forceinline__ float round_f16(float v) { return __half2float(__float2half_rn(v)); }
+
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  __half2 h0 = __floats2half2_rn(v[0], v[1]), h1 = __floats2half2_rn(v[2], v[3]);
+  __half2 h2 = __floats2half2_rn(v[4], v[5]), h3 = __floats2half2_rn(v[6], v[7]);
+  uint4 pk;
+  pk.x = *reinterpret_cast<unsigned*>(&h0);
+  pk.y = *reinterpret_cast<unsigned*>(&h1);
+  pk.z = *reinterpret_cast<unsigned*>(&h2);
+  pk.w = *reinterpret_cast<unsigned*>(&h3);
+  return pk;
+}
+
+// pooled: fp16 [h8*w8 + h16*w16 + h32*w32, 512] row list (P3 rows, then P4, then P5), the layout project_fuse reads
+__global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
+                                                           int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  GpShared& S = *reinterpret_cast<GpShared*>(smem_raw);
+  uint4* rows = reinterpret_cast<uint4*>(smem_raw + ((sizeof(GpShared) + 15) & ~(size_t)15));   // [GP_CAP][64] x 16 B
+
+  const int tiles_x = W >> 5;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+
+  for (int i = tid; i < GP_HASH; i += 256) S.key[i] = -1;
+  __syncthreads();
+  // phase 1: indices (clamped + flagged), inserted into the hash
+  bool bad = false;
+  for (int i = tid; i < 1024; i += 256) {
+    const int yy = i >> 5, xx = i & 31;
+    int cell = proj[(size_t)(ty * 32 + yy) * W + tx * 32 + xx];
+    if ((unsigned)cell >= (unsigned)n_cells) {
+      bad = true;
+      cell = cell < 0 ? 0 : n_cells - 1;
+    }
+    unsigned h = ((unsigned)cell * 2654435761u) >> 23;          // 9 bits
+    int entry = -1;
+    for (int probe = 0; probe < GP_PROBES; ++probe) {
+      const int old = atomicCAS(&S.key[h], -1, cell);
+      if (old == -1 || old == cell) {
+        entry = (int)h;
+        break;
+      }
+      h = (h + 1) & (GP_HASH - 1);
+    }
+    S.pix[i] = (short)entry;
+  }
+  if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
+  __syncthreads();
+  // phase 2: occupied entries -> slots (entry order; which cell gets which slot does not affect the results)
+  {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < GP_HASH / 256; ++j) c += S.key[tid * (GP_HASH / 256) + j] != -1;
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) S.wave_cnt[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += S.wave_cnt[w];
+    int rank = base + inc - c;
+#pragma unroll
+    for (int j = 0; j < GP_HASH / 256; ++j) {
+      const int e = tid * (GP_HASH / 256) + j;
+      const int k = S.key[e];
+      if (k != -1) {
+        if (rank < GP_CAP) {
+          S.slot_of[e] = (short)rank;
+          S.ucell[rank] = k;
+        } else {
+          S.slot_of[e] = -1;
+        }
+        ++rank;
+      }
+    }
+    if (tid == 255) S.n_unique = rank < GP_CAP ? rank : GP_CAP;
+  }
+  __syncthreads();
+  // phase 3: per pixel slot; per 4x4 block the common slot; fetch the distinct rows (all loads independent)
+  for (int i = tid; i < 1024; i += 256) {
+    const int e = S.pix[i];
+    S.pix[i] = e >= 0 ? S.slot_of[e] : (short)-1;
+  }
+  const int nu = S.n_unique;
+  for (int s = wave; s < nu; s += 4) rows[s * 64 + lane] = *reinterpret_cast<const uint4*>(mem + (size_t)S.ucell[s] * 512 + lane * 8);
+  __syncthreads();
+  if (tid < 64) {
+    const int by = tid >> 3, bx = tid & 7;
+    const short first = S.pix[(by * 4) * 32 + bx * 4];
+    bool same = first >= 0;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) same &= S.pix[(by * 4 + dy) * 32 + bx * 4 + dx] == first;
+    S.blk[tid] = same ? first : (short)-1;
+  }
+  __syncthreads();
+
+  // phase 4: pooling.  Wave q owns a 16x16 quadrant (one stride-16 cell), each lane 8 consecutive channels.
+  // Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in f32, /16; each avg_pool2d(2) sums 4 values row-major, /4,
+  // rounds to fp16 (timm.py:152,168).
+  const int qy = wave >> 1, qx = wave & 1;
+  const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
+  __half* p8 = pooled;
+  __half* p16 = pooled + (size_t)h8 * w8 * 512;
+  __half* p32 = p16 + (size_t)h16 * w16 * 512;
+  float acc16[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
+#pragma unroll 1
+  for (int cy8 = 0; cy8 < 2; ++cy8) {
+#pragma unroll 1
+    for (int cx8 = 0; cx8 < 2; ++cx8) {
+      float acc8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
+#pragma unroll 1
+      for (int by = 0; by < 2; ++by) {
+#pragma unroll 1
+        for (int bx = 0; bx < 2; ++bx) {
+          const int py0 = qy * 16 + cy8 * 8 + by * 4, px0 = qx * 16 + cx8 * 8 + bx * 4;
+          const int bslot = __builtin_amdgcn_readfirstlane((int)S.blk[(py0 >> 2) * 8 + (px0 >> 2)]);
+          float acc4[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
+          if (bslot >= 0) {
+            // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
+            add8(acc4, rows[bslot * 64 + lane]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
+          } else {
+#pragma unroll 1
+            for (int dy = 0; dy < 4; ++dy) {
+              uint4 raw[4];
+#pragma unroll
+              for (int dx = 0; dx < 4; ++dx) {
+                const int pi = (py0 + dy) * 32 + px0 + dx;
+                const int s = __builtin_amdgcn_readfirstlane((int)S.pix[pi]);
+                if (s >= 0) {
+                  raw[dx] = rows[s * 64 + lane];
+                } else {      // rare: more distinct cells in the tile than the LDS cache holds
+                  int cell = proj[(size_t)(ty * 32 + py0 + dy) * W + tx * 32 + px0 + dx];
+                  cell = cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell);
+                  raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * 512 + lane * 8);
+                }
+              }
+#pragma unroll
+              for (int dx = 0; dx < 4; ++dx) add8(acc4, raw[dx]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
+          }
+        }
+      }
+      float v8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v8[q] = round_f16(acc8[q] * 0.25f);
+        acc16[q] += v8[q];
+      }
+      const int oy = ty * 4 + qy * 2 + cy8, ox = tx * 4 + qx * 2 + cx8;
+      *reinterpret_cast<uint4*>(p8 + ((size_t)oy * w8 + ox) * 512 + lane * 8) = pack8(v8);
+    }
+  }
+  float v16[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v16[q] = round_f16(acc16[q] * 0.25f);
+    S.s16[wave][lane * 8 + q] = v16[q];
+  }
+  {
+    const int oy = ty * 2 + qy, ox = tx * 2 + qx;
+    *reinterpret_cast<uint4*>(p16 + ((size_t)oy * w16 + ox) * 512 + lane * 8) = pack8(v16);
+  }
+  __syncthreads();
+  for (int c = tid; c < 512; c += 256) {
+    const float s = ((S.s16[0][c] + S.s16[1][c]) + S.s16[2][c]) + S.s16[3][c];
+    p32[((size_t)ty * w32 + tx) * 512 + c] = __float2half_rn(s * 0.25f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a8: three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion into P3..P5, one launch, f16 matrix cores
+// ------------------------------------------------------------------------------------------------------
+// weights: per level and output channel n, scaled by 2^S_n so that max_k |w| lands in [2^13, 2^14), then split
+//   w * 2^S = h + m + l  (h = f16(w'), m = f16(w' - h), l = f16(w' - h - m); the residuals are exact in f32)
+// layout [level][piece][n][k] f16, k contiguous: lane (r = lane & 31, hi = lane >> 5) of a 32x32x16 MFMA reads its B fragment
+// B[k = 16 s + 8 hi + j][col n0 + r] as ONE 16-byte load; the A fragment A[row r][k ...] comes straight from the pooled rows.
+__global__ __launch_bounds__(64) void project_prepare_kernel(const float* __restrict__ w /*[256][512]*/, _Float16* __restrict__ out,
+                                                               float* __restrict__ sinv, int piece_stride) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float mx = 0.f;
+  for (int k = lane; k < 512; k += 64) mx = fmaxf(mx, fabsf(w[n * 512 + k]));
+  mx = wave_reduce_max(mx);
+  int S = 0;
+  if (mx > 0.f && mx < INFINITY) {
+    int e;
+    frexpf(mx, &e);      // mx = f * 2^e, f in [0.5, 1)
+    S = 14 - e;          // mx * 2^S in [2^13, 2^14)
+  }
+  const float sc = ldexpf(1.0f, S);
+  for (int k = lane; k < 512; k += 64) {
+    const float v = w[n * 512 + k] * sc;          // exact (power of two)
+    const _Float16 h = (_Float16)v;
+    const float r1 = v - (float)h;
+    const _Float16 m = (_Float16)r1;
+    const float r2 = r1 - (float)m;
+    const _Float16 l = (_Float16)r2;
+    out[(size_t)0 * piece_stride + n * 512 + k] = h;
+    out[(size_t)1 * piece_stride + n * 512 + k] = m;
+    out[(size_t)2 * piece_stride + n * 512 + k] = l;
+  }
+  if (lane == 0) sinv[n] = ldexpf(1.0f, -S);
+}
+
+struct ProjArgs {
+  int level_off[4];     // row offsets of P3, P4, P5 in the row list (+ end)
+  int tile_off[4];      // first 64-row tile of each level (+ end)
+  float weight;         // MODEL.MAP_FEATURE_WEIGHT
+  int mode;             // 0: P = (x.W + b) * weight + P   (sum)     1: P = (x.W + b) * weight   (mem_only)
+};
+
+__global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Wsplit,
+                                                            const float* __restrict__ sinv, const float* __restrict__ bias,
+                                                            float* __restrict__ P, ProjArgs a) {
+  const int t = blockIdx.x;
+  const int lvl = t >= a.tile_off[2] ? 2 : (t >= a.tile_off[1] ? 1 : 0);
+  const int row0 = a.level_off[lvl] + (t - a.tile_off[lvl]) * 64;
+  const int row_end = a.level_off[lvl + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 31, hi = lane >> 5;
+  const _Float16* Wl = Wsplit + (size_t)lvl * 3 * 256 * 512;
+
+  const _Float16* ap[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    int row = row0 + 32 * m + r;
+    row = row < row_end ? row : row_end - 1;            // clamped read, masked store
+    ap[m] = X + (size_t)row * 512 + 8 * hi;
+  }
+  const _Float16* bp[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bp[n] = Wl + (size_t)(wave * 64 + 32 * n + r) * 512 + 8 * hi;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+#pragma unroll 2
+  for (int s = 0; s < 32; ++s) {
+    f16x8 af[2], bf[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f16x8*>(ap[m] + 16 * s);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + 16 * s);
+    // smallest pieces first: the low-order products enter the fp32 accumulator before the large ones
+#pragma unroll
+    for (int p = 2; p >= 0; --p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf[n][p], acc[m][n], 0, 0, 0);
+  }
+
+  // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = wave * 64 + 32 * n + r;
+    const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = row0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hi;
+        if (row < row_end) {
+          float* o = P + (size_t)row * 256 + col;
+          // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
+          const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][n][i], si), b), a.weight);
+          *o = a.mode == 0 ? __fadd_rn(v, *o) : v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs, int32_t* dirty, uint16_t* out_f16, int n_cells, int D,
+                                              eod_stream_t stream) {
+  if (!mem || !obs || !dirty || !out_f16) return EOD_ERR_NULL;
+  if (n_cells <= 0 || D != 512) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(mem) || !eod_aligned16(out_f16)) return EOD_ERR_ALIGN;
+  int blocks = ((n_cells + 63) / 64 + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(normalize_dirty_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mem, obs, dirty,
+                     reinterpret_cast<__half*>(out_f16), n_cells);
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, uint16_t* pooled_f16,
+                                      int32_t* err_flags, eod_stream_t stream) {
+  if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16)) return EOD_ERR_ALIGN;
+  const size_t lds = ((sizeof(GpShared) + 15) & ~(size_t)15) + (size_t)GP_CAP * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return EOD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gather_pool_kernel, dim3((H >> 5) * (W >> 5)), dim3(256), lds, (hipStream_t)stream,
+                     reinterpret_cast<const __half*>(mem_f16), proj, H, W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+  return eod_launch_status();
+}
+
+extern "C" size_t eod_memory_project_weights_bytes(void) { return (size_t)3 * 3 * 256 * 512 * 2 + (size_t)2 * 3 * 256 * 4; }
+
+extern "C" int eod_memory_project_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                          const float* b3, void* prepared, eod_stream_t stream) {
+  if (!w1 || !w2 || !w3 || !b1 || !b2 || !b3 || !prepared) return EOD_ERR_NULL;
+  if (!eod_aligned16(prepared)) return EOD_ERR_ALIGN;
+  _Float16* ws = static_cast<_Float16*>(prepared);
+  float* sinv = reinterpret_cast<float*>(ws + (size_t)3 * 3 * 256 * 512);
+  float* bias = sinv + 3 * 256;
+  const float* w[3] = {w1, w2, w3};
+  const float* b[3] = {b1, b2, b3};
+  for (int l = 0; l < 3; ++l) {
+    hipLaunchKernelGGL(project_prepare_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream, w[l], ws + (size_t)l * 3 * 256 * 512,
+                       sinv + l * 256, 256 * 512);
+    if (hipMemcpyAsync(bias + l * 256, b[l], 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      return EOD_ERR_LAUNCH;
+  }
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* prepared, float* feats, int H, int W, float weight, int mode,
+                                       eod_stream_t stream) {
+  if (!pooled_f16 || !prepared || !feats) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || (mode != 0 && mode != 1)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(pooled_f16) || !eod_aligned16(prepared)) return EOD_ERR_ALIGN;
+  ProjArgs a{};
+  const int rows[3] = {(H >> 3) * (W >> 3), (H >> 4) * (W >> 4), (H >> 5) * (W >> 5)};
+  a.level_off[0] = 0;
+  a.tile_off[0] = 0;
+  for (int l = 0; l < 3; ++l) {
+    a.level_off[l + 1] = a.level_off[l] + rows[l];
+    a.tile_off[l + 1] = a.tile_off[l] + (rows[l] + 63) / 64;
+  }
+  a.weight = weight;
+  a.mode = mode;
+  const _Float16* ws = static_cast<const _Float16*>(prepared);
+  const float* sinv = reinterpret_cast<const float*>(ws + (size_t)3 * 3 * 256 * 512);
+  const float* bias = sinv + 3 * 256;
+  hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3]), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const _Float16*>(pooled_f16), ws, sinv, bias, feats, a);
+  return eod_launch_status();
+}

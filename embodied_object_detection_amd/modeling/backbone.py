@@ -87,8 +87,8 @@ class CustomRecurrentFPN:
                                       name=f"fpn_output{l}")
         self.p6 = ops.Conv(sd["backbone.top_block.p6.weight"], sd["backbone.top_block.p6.bias"], stride=2, pad=1, device=device, name="p6")
         self.p7 = ops.Conv(sd["backbone.top_block.p7.weight"], sd["backbone.top_block.p7.bias"], stride=2, pad=1, device=device, name="p7")
-        self.merge = [ops.Conv(sd[f"backbone.map_merge_projection{i}.weight"], sd[f"backbone.map_merge_projection{i}.bias"],
-                               device=device, name=f"map_merge_projection{i}") for i in (1, 2, 3)]
+        self.merge = ops.MemoryProjector([sd[f"backbone.map_merge_projection{i}.weight"] for i in (1, 2, 3)],
+                                         [sd[f"backbone.map_merge_projection{i}.bias"] for i in (1, 2, 3)], device)
         self._plans = {}
 
     def level_shapes(self, H: int, W: int) -> List[Tuple[int, int]]:
@@ -108,7 +108,7 @@ class CustomRecurrentFPN:
                 off.append(off[-1] + h * w)
             feats = torch.empty((off[-1], 256), dtype=torch.float32, device=self.device)
             views = [feats[off[i]:off[i + 1]].view(1, shapes[i][0], shapes[i][1], 256) for i in range(5)]
-            pooled = [torch.empty((1, H // s, W // s, 512), dtype=torch.float32, device=self.device) for s in (8, 16, 32)]
+            pooled = torch.empty((ops.pooled_rows(H, W), 512), dtype=torch.float16, device=self.device)
             self._plans[key] = (shapes, off, feats, views, pooled)
         return self._plans[key]
 
@@ -125,29 +125,26 @@ class CustomRecurrentFPN:
         lat3 = self.lateral[3](c3, 1, h3, w3, res=lat4, res_mode=2)
         self.output[3](lat3, 1, h3, w3, out=views[0])
 
-    def fuse_memory_and_top(self, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor], which: int = 0):
+    def fuse_memory_and_top(self, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor], which: int = 0,
+                            err: Optional[torch.Tensor] = None):
         """Memory read + fusion into P3..P5 (timm.py:142-192), then P6/P7 on the fused P5 (timm.py:200-205, 359-364)."""
         shapes, off, feats, views, pooled = self._plan(H, W, which)
         h5, w5 = shapes[2]
         if self.memory_type == "implicit_memory" and self.feat_fusion != "image_only":
             if memory_f16 is None or proj is None:
                 raise ValueError("implicit_memory needs the fp16 memory table and proj_indices")
-            ops.memory_gather_pool(memory_f16, proj, H, W, outs=pooled)
-            for i in range(3):
-                h, w = shapes[i]
-                if self.feat_fusion == "sum":
-                    self.merge[i](pooled[i], 1, h, w, res=views[i], res_mode=1, out_scale=self.map_feature_weight, out=views[i])
-                else:  # mem_only
-                    self.merge[i](pooled[i], 1, h, w, out_scale=self.map_feature_weight, out=views[i])
+            # P3..P5 are the first rows of the pyramid's row list, in the order the pooled rows are written
+            ops.memory_gather_pool(memory_f16, proj, H, W, out=pooled, err=err)
+            self.merge(pooled, feats, H, W, self.map_feature_weight, self.feat_fusion)
         self.p6(views[2], 1, h5, w5, out=views[3])
         self.p7(views[3], 1, shapes[3][0], shapes[3][1], in_relu=True, out=views[4])
         return feats, views, shapes, off
 
     def forward(self, x4: torch.Tensor, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor],
-                which: int = 0):
+                which: int = 0, err: Optional[torch.Tensor] = None):
         """-> (feats [P_total,256], level views, level shapes, level offsets)."""
         self.top_down(self.bottom_up.forward(x4, H, W), H, W, which)
-        return self.fuse_memory_and_top(H, W, memory_f16, proj, which)
+        return self.fuse_memory_and_top(H, W, memory_f16, proj, which, err)
 
 
 @BACKBONE_REGISTRY.register()

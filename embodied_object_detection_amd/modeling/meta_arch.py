@@ -124,6 +124,9 @@ class CustomRCNNRecurrent:
         self.observations: Optional[torch.Tensor] = None      # [N] f32      (== observation_count)
         self.semmap = None
         self._mem_f16: Optional[torch.Tensor] = None
+        self._dirty: Optional[torch.Tensor] = None          # int32 [N]: rows of the fp16 snapshot that are out of date
+        self._f16_valid = False
+        self._err = torch.zeros((1,), dtype=torch.int32, device=self.device)   # device error word (EOD_FLAG_*), read with the count
         self._writer = None
         self._writer_key = None
         self._post = None
@@ -150,11 +153,30 @@ class CustomRCNNRecurrent:
             self.implicit_memory = torch.empty((n_cells, 512), dtype=torch.float32, device=self.device)
             self.observations = torch.empty((n_cells,), dtype=torch.float32, device=self.device)
             self._mem_f16 = torch.empty((n_cells, 512), dtype=torch.float16, device=self.device)
+            self._dirty = torch.empty((n_cells,), dtype=torch.int32, device=self.device)
         lib = _lib.load()
         s = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.eod_fill_f32(self.implicit_memory.data_ptr(), 0.0, self.implicit_memory.numel(), s), "fill")
         _lib.check(lib.eod_fill_f32(self.observations.data_ptr(), 0.0, self.observations.numel(), s), "fill")
+        # the resident fp16 snapshot of an all-zero memory is all zero; from here on it is kept incrementally (dirty rows only)
+        _lib.check(lib.eod_fill_i32(self._mem_f16.data_ptr(), 0, self._mem_f16.numel() // 2, s), "fill")
+        _lib.check(lib.eod_fill_i32(self._dirty.data_ptr(), 0, n_cells, s), "fill")
+        self._f16_valid = True
         self.semmap = None
+
+    def invalidate_memory_snapshot(self):
+        """Call after writing `implicit_memory` / `observations` from outside (e.g. a loaded snapshot): the next frame
+        re-normalises the whole table instead of the dirty rows."""
+        self._f16_valid = False
+
+    def _refresh_memory_snapshot(self):
+        """a4 + fp16 cast (create_implicit_memory + preprocess_spatial_memory): bring the resident fp16 table up to the state."""
+        if self._f16_valid:
+            ops.memory_normalize_dirty_f16(self.implicit_memory, self.observations, self._dirty, self._mem_f16)
+        else:
+            ops.memory_normalize_f16(self.implicit_memory, self.observations, out=self._mem_f16)
+            _lib.check(_lib.load().eod_fill_i32(self._dirty.data_ptr(), 0, self._dirty.numel(), torch.cuda.current_stream().cuda_stream), "fill")
+            self._f16_valid = True
 
     def _ensure_frame_buffers(self, H: int, W: int, n_cells: int):
         key = (H, W, n_cells)
@@ -172,7 +194,8 @@ class CustomRCNNRecurrent:
                 classes=torch.zeros((D,), dtype=torch.int32, device=dev), src=torch.zeros((D,), dtype=torch.int32, device=dev),
                 count=torch.zeros((1,), dtype=torch.int32, device=dev),
                 masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev),
-                count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), ready=torch.cuda.Event()) for _ in range(2)]
+                count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
+                ready=torch.cuda.Event()) for _ in range(2)]
             self._post_slot = 0
         self._post = self._posts[self._post_slot]
 
@@ -207,6 +230,7 @@ class CustomRCNNRecurrent:
         """Async read-back of the frame's detection count into pinned host memory + an event; flips the result set."""
         P = self._post
         P["count_host"].copy_(P["count"], non_blocking=True)
+        P["err_host"].copy_(self._err, non_blocking=True)
         P["ready"].record(torch.cuda.current_stream(self.device))
         self._post_slot ^= 1
         return P
@@ -264,7 +288,7 @@ class CustomRCNNRecurrent:
         mem_f16 = None
         if self.memory_type == "implicit_memory":
             if refresh_memory_snapshot:
-                ops.memory_normalize_f16(self.implicit_memory, self.observations, out=self._mem_f16)
+                self._refresh_memory_snapshot()
             mem_f16 = self._mem_f16
 
         pre, self._prefetched = self._prefetched, None
@@ -282,10 +306,10 @@ class CustomRCNNRecurrent:
                 self._ev_start = torch.cuda.Event()
             self._ev_start.record(torch.cuda.current_stream(self.device))
         if hit:
-            feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid)
+            feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid, self._err)
         else:
             x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
-            feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj, self._pyramid)
+            feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj, self._pyramid, self._err)
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         if look_ahead and self.lookahead_at_start:
             self._enqueue_trunk(next_frame, self._ev_start)
@@ -382,7 +406,8 @@ class CustomRCNNRecurrent:
 
     def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw, mem_sel=None):
         rows, cnt = mem_sel if mem_sel is not None else self.select_memory_instances(prop_boxes, prop_scores, prop_count, image_hw)
-        self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations)
+        self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations,
+                     dirty=self._dirty, err=self._err)
 
     def save_memory_snapshot(self, sequence_name: str) -> str:
         """`MODEL.TEST_SAVE_SEMMAP` dump (custom_rcnn.py:518-530): semmap, impicit_memory [sic], observations -> OUTPUT_DIR/memory/."""
@@ -395,6 +420,12 @@ class CustomRCNNRecurrent:
         """Slice a result set by its detection count (the frame's only host wait: on the event recorded after the count's
         async copy).  The paste kernel writes 0/1 bytes, so the masks are handed out as a bool view's copy."""
         P["ready"].synchronize()
+        flags = int(P["err_host"][0])
+        if flags:
+            self._err.zero_()
+            raise _lib.EodError(
+                f"device error flags {flags:#x}: proj_indices holds cell indices outside [0, {self.implicit_memory.shape[0]}) "
+                "(an index image written for another map size?); they were clamped, the frame's results are not trustworthy")
         n = int(P["count_host"][0])
         inst = Instances(P["hw"])
         inst.pred_boxes = Boxes(P["boxes"][:n].clone())

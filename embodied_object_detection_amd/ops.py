@@ -386,13 +386,46 @@ def memory_normalize_f16(mem: torch.Tensor, obs: torch.Tensor, out: Optional[tor
     return out
 
 
-def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, outs=None):
+def memory_normalize_dirty_f16(mem: torch.Tensor, obs: torch.Tensor, dirty: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """a4, incremental: re-normalise the rows flagged in `dirty` (int32 [N]) into the resident fp16 table and clear the flags."""
+    N, D = mem.shape
+    check(_lib.load().eod_memory_normalize_dirty_f16(mem.data_ptr(), obs.data_ptr(), dirty.data_ptr(), out.data_ptr(), N, D, _stream()),
+          "eod_memory_normalize_dirty_f16")
+    return out
+
+
+def pooled_rows(H: int, W: int) -> int:
+    return (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32)
+
+
+def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None,
+                       err: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a8 gather + cascaded pooling -> fp16 [h8*w8 + h16*w16 + h32*w32, 512] (stride-8 rows, then 16, then 32)."""
     N, D = mem_f16.shape
-    if outs is None:
-        outs = [torch.empty((1, H // s, W // s, D), dtype=torch.float32, device=mem_f16.device) for s in (8, 16, 32)]
-    check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, outs[0].data_ptr(), outs[1].data_ptr(),
-                                             outs[2].data_ptr(), _stream()), "eod_memory_gather_pool")
-    return outs
+    if out is None:
+        out = torch.empty((pooled_rows(H, W), D), dtype=torch.float16, device=mem_f16.device)
+    check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, out.data_ptr(), _ptr(err), _stream()),
+          "eod_memory_gather_pool")
+    return out
+
+
+class MemoryProjector:
+    """`map_merge_projection{1,2,3}` + MAP_FEATURE_WEIGHT + fusion (timm.py:174-189) as one launch on the f16 matrix cores."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], device):
+        self.lib = _lib.load()
+        ws = [w.detach().to(torch.float32).reshape(256, 512).contiguous().to(device) for w in weights]
+        bs = [b.detach().to(torch.float32).contiguous().to(device) for b in biases]
+        self.prepared = torch.empty((self.lib.eod_memory_project_weights_bytes(),), dtype=torch.uint8, device=device)
+        check(self.lib.eod_memory_project_prepare(ws[0].data_ptr(), bs[0].data_ptr(), ws[1].data_ptr(), bs[1].data_ptr(), ws[2].data_ptr(),
+                                                  bs[2].data_ptr(), self.prepared.data_ptr(), _stream()), "eod_memory_project_prepare")
+        torch.cuda.current_stream().synchronize()       # ws / bs die with this frame; the prepare kernels must have read them
+
+    def __call__(self, pooled_f16: torch.Tensor, feats: torch.Tensor, H: int, W: int, weight: float, mode: str):
+        _need_cuda(pooled_f16, feats)
+        check(self.lib.eod_memory_project_fuse(pooled_f16.data_ptr(), self.prepared.data_ptr(), feats.data_ptr(), H, W, float(weight),
+                                               {"sum": 0, "mem_only": 1}[mode], _stream()), "eod_memory_project_fuse")
+        return feats
 
 
 class MemoryWriter:
@@ -402,15 +435,16 @@ class MemoryWriter:
         self.lib = _lib.load()
         nbytes = self.lib.eod_memory_write_workspace_bytes(H, W, 512, n_cells, K_cap, R_cap)
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        check(self.lib.eod_memory_write_init(self.ws.data_ptr(), nbytes, H, W, 512, n_cells, R_cap, _stream()), "eod_memory_write_init")
+        check(self.lib.eod_memory_write_init(self.ws.data_ptr(), nbytes, H, W, 512, n_cells, K_cap, R_cap, _stream()), "eod_memory_write_init")
         self.k_out = torch.zeros((1,), dtype=torch.int32, device=device)
         d = EodMemWriteDesc()
         d.K_cap, d.R_cap, d.H, d.W, d.D, d.n_cells, d.mask_thresh = K_cap, R_cap, H, W, 512, n_cells, mask_thresh
         d.workspace, d.workspace_bytes, d.k_out = self.ws.data_ptr(), nbytes, self.k_out.data_ptr()
         self.desc = d
 
-    def __call__(self, featn, prop_boxes, prop_masks, det_rows, det_count, proj, mem, obs):
+    def __call__(self, featn, prop_boxes, prop_masks, det_rows, det_count, proj, mem, obs, dirty=None, err=None):
         d = self.desc
+        d.dirty, d.err_flags = _ptr(dirty), _ptr(err)
         d.featn, d.prop_boxes, d.prop_masks = featn.data_ptr(), prop_boxes.data_ptr(), prop_masks.data_ptr()
         d.det_rows, d.det_count, d.proj, d.mem, d.obs = det_rows.data_ptr(), det_count.data_ptr(), proj.data_ptr(), mem.data_ptr(), obs.data_ptr()
         check(self.lib.eod_memory_write(C.byref(d), _stream()), "eod_memory_write")

@@ -195,9 +195,26 @@ int eod_unproject_grid_index(const float* depth, int H, int W, const float* T16_
                              int order, float* xyz_or_null, int32_t* idx, eod_stream_t stream);
 /* a4 + fp16 cast (custom_rcnn.py:762-774,1036): out_f16[n] = half(obs>1 ? mem/obs : mem) */
 int eod_memory_normalize_f16(const float* mem, const float* obs, uint16_t* out_f16, int n_cells, int D, eod_stream_t stream);
-/* a8 gather + cascaded average pooling (timm.py:147-168): pooled8/16/32 [h,w,512] hold fp16-rounded values as f32 */
+/* a4, incremental form: re-normalise only the rows flagged in `dirty` (int32 [n_cells], set by eod_memory_write for every cell
+ * whose observation count or accumulator row changed) into the resident fp16 table, and clear the flags.  Equal to
+ * eod_memory_normalize_f16 on those rows; the other rows of out_f16 are left as they are (they did not change). */
+int eod_memory_normalize_dirty_f16(const float* mem, const float* obs, int32_t* dirty, uint16_t* out_f16, int n_cells, int D,
+                                   eod_stream_t stream);
+/* device-side error word (OR of flags); kernels that index with caller data clamp and set it instead of faulting */
+#define EOD_FLAG_BAD_CELL_INDEX 1   /* a proj_indices entry outside [0, n_cells) was clamped */
+/* a8 gather + cascaded average pooling (timm.py:147-168): pooled_f16 = fp16 [h8*w8 + h16*w16 + h32*w32, 512] row list
+ * (stride-8 rows, then stride-16, then stride-32; the values timm.py:168 casts to fp16).  err_flags: int32 [1] or NULL. */
 int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells,
-                           float* pooled8, float* pooled16, float* pooled32, eod_stream_t stream);
+                           uint16_t* pooled_f16, int32_t* err_flags, eod_stream_t stream);
+/* a8 projection + fusion (timm.py:174-189): for the three levels P_l = (pooled_l . W_l^T + b_l) * weight (+ P_l if mode 0
+ * "sum"; mode 1 "mem_only" overwrites), in place on the [h8*w8 + h16*w16 + h32*w32, 256] fp32 row list `feats`.
+ * `prepared` (eod_memory_project_weights_bytes() bytes, 16-byte aligned) is built once from the three Conv2d(512,256,1)
+ * layers `map_merge_projection{1,2,3}` (weights [256,512] fp32, bias [256]). */
+size_t eod_memory_project_weights_bytes(void);
+int eod_memory_project_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                               const float* b3, void* prepared, eod_stream_t stream);
+int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* prepared, float* feats, int H, int W, float weight,
+                            int mode, eod_stream_t stream);
 /* a16 scoring of proposals in CLIP space (custom_rcnn.py:848-855): scores = sqrt(sigmoid(featn@zs)*ps) */
 int eod_memory_scores(const float* featn /*[R,512]*/, const float* zs, const float* prop_scores, float* scores /*[R,C1]*/,
                       const int32_t* count, int R_cap, int D, int C1, eod_stream_t stream);
@@ -219,11 +236,13 @@ typedef struct EodMemWriteDesc {
   float* obs;               /* [N] observation counts */
   int32_t* k_out;           /* [1] number of unique instances written (diagnostic) */
   void* workspace; size_t workspace_bytes;
+  int32_t* dirty;           /* [N] or NULL: set to 1 for every cell whose observation count changed (see normalize_dirty) */
+  int32_t* err_flags;       /* [1] or NULL: EOD_FLAG_* */
 } EodMemWriteDesc;
 size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap);
 int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream);
 /* zero the per-frame cell flags inside the workspace once after allocation (eod_memory_write leaves them zero) */
-int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int R_cap,
+int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int K_cap, int R_cap,
                           eod_stream_t stream);
 
 /* a20: explicit semantic map from the implicit memory (custom_rcnn.py:745-756,938-1017), evaluated lazily (only

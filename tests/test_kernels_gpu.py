@@ -489,25 +489,127 @@ def test_unproject_grid_index_bit_exact(dev):
         assert np.array_equal(idx.cpu().numpy(), idx_ref), "grid-cell indices must be bit-exact"
 
 
-def test_memory_read_matches_oracle(dev):
+def _pooled_rows(pooled_ref):
+    """oracle's three [1,512,h,w] fp16 tensors -> the kernel's [h8*w8 + h16*w16 + h32*w32, 512] row list"""
+    return torch.cat([nhwc(r.float()).reshape(-1, 512) for r in pooled_ref])
+
+
+@pytest.mark.parametrize("pattern", ["blocky", "distinct", "constant", "columns"])
+def test_memory_read_matches_oracle(dev, pattern):
+    """a4 + a8 gather / cascaded pooling.  `blocky`: runs of equal cells with 30 % noise (LDS row cache + mixed blocks);
+    `distinct`: every pixel its own cell (1 024 distinct per tile: hash overflow -> direct reads); `constant`: one cell (every 4x4
+    block takes the n*v shortcut); `columns`: one cell per pixel column (a wall seen at constant depth: 32 distinct per tile)."""
     from embodied_object_detection_amd import ops
     g = torch.Generator().manual_seed(7)
-    N, H, W = 500, 64, 96
+    N, H, W = (8000 if pattern == "distinct" else 500), 64, 96
     mem = torch.randn((N, 512), generator=g) * 30
+    mem[::5] *= 1e-3                                  # wide exponent spread inside the pooling windows
     obs = torch.randint(0, 6, (N,), generator=g).float()
-    proj = torch.randint(0, N, (H, W), generator=g)
-    blocky = ((torch.arange(H)[:, None] // 6) * 17 + (torch.arange(W)[None, :] // 9)) % N
-    proj = torch.where(torch.rand((H, W), generator=g) < 0.7, blocky, proj)
+    if pattern == "blocky":
+        proj = torch.randint(0, N, (H, W), generator=g)
+        blocky = ((torch.arange(H)[:, None] // 6) * 17 + (torch.arange(W)[None, :] // 9)) % N
+        proj = torch.where(torch.rand((H, W), generator=g) < 0.7, blocky, proj)
+    elif pattern == "distinct":
+        proj = torch.randperm(N, generator=g)[:H * W].reshape(H, W)
+    elif pattern == "constant":
+        proj = torch.full((H, W), 123, dtype=torch.int64)
+    else:
+        proj = (torch.arange(W)[None, :] * 5 % N).expand(H, W).contiguous()
     ref_norm = OM.create_implicit_memory(mem, obs).to(torch.half)
     m16 = ops.memory_normalize_f16(mem.to(dev), obs.to(dev))
     assert torch.equal(m16.cpu(), ref_norm), "obs-normalised fp16 memory must be bit-exact"
-    pooled_ref = M.memory_read_pooled(ref_norm, proj)
-    outs = ops.memory_gather_pool(m16, proj.int().to(dev), H, W)
-    for o, r in zip(outs, pooled_ref):
-        r32 = nhwc(r.float())
-        same = (o.cpu() == r32).float().mean().item()
-        assert same > 0.999, f"fp16-rounded pooled values differ on {1 - same:.2e} of elements"
-        close(o, r32, rtol=1e-3, atol=1e-3)
+    ref = _pooled_rows(M.memory_read_pooled(ref_norm, proj))
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
+    out = ops.memory_gather_pool(m16, proj.int().to(dev), H, W, err=err).cpu().float()
+    assert out.shape == ref.shape == (ops.pooled_rows(H, W), 512)
+    same = (out == ref).float().mean().item()
+    print(f"[memory read / {pattern}] identical fp16 values: {same:.6f}")
+    assert same > 0.9995, f"fp16 pooled values differ on {1 - same:.2e} of elements"
+    close(out, ref, rtol=1e-3, atol=1e-3)
+    assert int(err.item()) == 0
+
+
+def test_memory_read_flags_out_of_range_indices(dev):
+    """proj_indices written for another map size: clamped to the table, flagged in the device error word, no fault."""
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(8)
+    N, H, W = 300, 32, 64
+    m16 = (torch.randn((N, 512), generator=g) * 10).half()
+    proj = torch.randint(0, N, (H, W), generator=g)
+    bad = proj.clone()
+    bad[3, 5], bad[20, 40] = N + 7, -2
+    fixed = proj.clone()
+    fixed[3, 5], fixed[20, 40] = N - 1, 0
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
+    a = ops.memory_gather_pool(m16.to(dev), bad.int().to(dev), H, W, err=err).cpu()
+    assert int(err.item()) == 1
+    err.zero_()
+    b = ops.memory_gather_pool(m16.to(dev), fixed.int().to(dev), H, W, err=err).cpu()
+    assert int(err.item()) == 0 and torch.equal(a, b)
+
+
+def test_memory_normalize_dirty_keeps_the_fp16_table_current(dev):
+    """Incremental a4: after changing rows and observation counts and flagging them, the resident table equals a full re-normalise;
+    the flags are consumed."""
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N = 1000
+    mem = (torch.randn((N, 512), generator=g) * 20).to(dev)
+    obs = torch.randint(0, 4, (N,), generator=g).float().to(dev)
+    table = ops.memory_normalize_f16(mem, obs)
+    dirty = torch.zeros((N,), dtype=torch.int32, device=dev)
+    rows = torch.randperm(N, generator=g)[:137].to(dev)
+    mem[rows] += torch.randn((137, 512), generator=g).to(dev)
+    obs[rows] += 1
+    dirty[rows] = 1
+    untouched = table.clone()
+    ops.memory_normalize_dirty_f16(mem, obs, dirty, table)
+    assert torch.equal(table, ops.memory_normalize_f16(mem, obs))
+    assert int(dirty.sum().item()) == 0
+    keep = torch.ones(N, dtype=torch.bool, device=dev); keep[rows] = False
+    assert torch.equal(table[keep], untouched[keep])
+    assert not torch.equal(table[rows], untouched[rows])
+
+
+@pytest.mark.parametrize("mode,weight", [("sum", 5.0), ("mem_only", 500.0)])
+def test_memory_project_fuse_matches_oracle(dev, mode, weight):
+    """a8 projection + fusion: three 1x1 convs (f32 in the reference, timm.py:174) on fp16-exact inputs, x weight, + P_l.  The
+    f16x3 split reproduces the fp32 weights to 2^-25 of each row's maximum; products are exact, accumulation fp32."""
+    from embodied_object_detection_amd import ops
+    g = torch.Generator().manual_seed(31)
+    H, W = 64, 96
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    pooled = [(torch.randn((1, 512, h, w), generator=g) * 8).half() for (h, w) in hw]
+    pooled[0][0, :, 0, 0] = 0                                  # an unobserved location
+    res = [torch.randn((1, 256, h, w), generator=g) for (h, w) in hw]
+    sd = {}
+    for i in (1, 2, 3):
+        wgt = torch.randn((256, 512, 1, 1), generator=g) * (1.0 / 512) ** 0.5 * 0.05
+        wgt[i] *= 1e-4                                          # a row of tiny weights (own power-of-two scale)
+        wgt[7, ::3] *= 1e3                                      # a row with a wide dynamic range
+        sd[f"backbone.map_merge_projection{i}.weight"] = wgt
+        sd[f"backbone.map_merge_projection{i}.bias"] = torch.randn((256,), generator=g) * 0.01
+    ref = M.fuse_memory(res, pooled, sd, M.OracleCfg(map_feat_fusion=mode, map_feature_weight=weight))
+    ref64 = [(F.conv2d(p.double(), sd[f"backbone.map_merge_projection{i + 1}.weight"].double(),
+                       sd[f"backbone.map_merge_projection{i + 1}.bias"].double()) * weight + (r.double() if mode == "sum" else 0))
+             for i, (p, r) in enumerate(zip(pooled, res))]
+    proj = ops.MemoryProjector([sd[f"backbone.map_merge_projection{i}.weight"] for i in (1, 2, 3)],
+                               [sd[f"backbone.map_merge_projection{i}.bias"] for i in (1, 2, 3)], dev)
+    feats = torch.cat([nhwc(r).reshape(-1, 256) for r in res]).contiguous().to(dev)
+    rows16 = torch.cat([nhwc(p).reshape(-1, 512) for p in pooled]).contiguous().to(dev)
+    tail = torch.full((7, 256), 3.25, device=dev)              # rows behind P5 (P6/P7 in the model) must not be touched
+    buf = torch.cat([feats, tail]).contiguous()
+    proj(rows16, buf, H, W, weight, mode)
+    got = buf[:feats.shape[0]].cpu()
+    assert torch.equal(buf[feats.shape[0]:].cpu(), tail.cpu())
+    refrows = torch.cat([nhwc(r).reshape(-1, 256) for r in ref])
+    ref64rows = torch.cat([nhwc(r).reshape(-1, 256) for r in ref64])
+    scale = refrows.abs().max().item()
+    e_hip = (got.double() - ref64rows).abs().max().item()
+    e_cpu = (refrows.double() - ref64rows).abs().max().item()
+    print(f"[project_fuse {mode}] max err vs f64: HIP {e_hip:.3e}, torch CPU f32 {e_cpu:.3e}, scale {scale:.3e}")
+    assert e_hip <= 2.0 * e_cpu + 1e-7 * scale, "the split-f16 projection must be as accurate as an fp32 convolution"
+    close(got, refrows, rtol=1e-5, atol=2e-6 * scale)
 
 
 @pytest.mark.parametrize("K,thresh", [(12, 0.5), (0, 0.5)])
@@ -541,13 +643,32 @@ def test_memory_write_matches_oracle(dev, K, thresh):
     cnt = torch.tensor([K], dtype=torch.int32, device=dev)
     for rep in range(2):   # second call must start from clean per-frame flags
         mem_d, obs_d = mem0.to(dev), obs0.to(dev)
-        k_out = wr(featn.to(dev), boxes.to(dev), masks.to(dev), dr.to(dev), cnt, proj.int().to(dev), mem_d, obs_d)
+        dirty = torch.zeros((N,), dtype=torch.int32, device=dev)
+        err = torch.zeros((1,), dtype=torch.int32, device=dev)
+        k_out = wr(featn.to(dev), boxes.to(dev), masks.to(dev), dr.to(dev), cnt, proj.int().to(dev), mem_d, obs_d, dirty=dirty, err=err)
         assert int(k_out.item()) == (len(torch.unique(det_rows[:K])) if K else 0)
         assert torch.equal(obs_d.cpu(), obs_ref), "observation counters are integers: exact"
+        assert torch.equal(dirty.cpu().bool(), obs_ref != obs0), "dirty rows = cells whose observation count changed"
+        assert int(err.item()) == 0
         touched_ref = (mem_ref != mem0).any(dim=1)
         touched = (mem_d.cpu() != mem0).any(dim=1)
         assert torch.equal(touched, touched_ref), "set of written cells must be bit-exact"
         close(mem_d, mem_ref, rtol=1e-5, atol=1e-4)
+        assert bool(((mem_d.cpu() != mem0).any(dim=1) <= dirty.cpu().bool()).all()), "written cells are a subset of the dirty rows"
+    if K > 0:
+        # an index image written for another map size: clamped and flagged, no fault; valid pixels behave as before
+        bad = proj.clone()
+        bad[0, 0], bad[5, 7] = N + 100, -3
+        fixed = proj.clone()
+        fixed[0, 0], fixed[5, 7] = N - 1, 0
+        res = []
+        for pj in (bad, fixed):
+            mem_d, obs_d = mem0.to(dev), obs0.to(dev)
+            err = torch.zeros((1,), dtype=torch.int32, device=dev)
+            wr(featn.to(dev), boxes.to(dev), masks.to(dev), dr.to(dev), cnt, pj.int().to(dev), mem_d, obs_d, err=err)
+            res.append((mem_d.cpu(), obs_d.cpu(), int(err.item())))
+        assert res[0][2] == 1 and res[1][2] == 0
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 def test_semmap_labels_match_oracle(dev):

@@ -42,25 +42,46 @@ __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* _
     }
     u64 bal = __ballot(f != 0);
     while (bal) {
-      const int src = __ffsll((long long)bal) - 1;
-      bal &= bal - 1;
-      const int cell = (g << 6) + src;
-      const float o = obs[cell];
-      const float* m = mem + (size_t)cell * 512 + lane * 8;
-      f32x4 a = *reinterpret_cast<const f32x4*>(m);
-      f32x4 b = *reinterpret_cast<const f32x4*>(m + 4);
-      if (o > 1.0f) {
-        a.x = __fdiv_rn(a.x, o); a.y = __fdiv_rn(a.y, o); a.z = __fdiv_rn(a.z, o); a.w = __fdiv_rn(a.w, o);
-        b.x = __fdiv_rn(b.x, o); b.y = __fdiv_rn(b.y, o); b.z = __fdiv_rn(b.z, o); b.w = __fdiv_rn(b.w, o);
+      // up to 4 dirty rows per step: their loads are independent and in flight together
+      int cells[4];
+      int nb = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (bal) {
+          cells[j] = (g << 6) + (int)__ffsll((long long)bal) - 1;
+          bal &= bal - 1;
+          ++nb;
+        } else {
+          cells[j] = cells[0];
+        }
       }
-      __half2 h0 = __floats2half2_rn(a.x, a.y), h1 = __floats2half2_rn(a.z, a.w);
-      __half2 h2 = __floats2half2_rn(b.x, b.y), h3 = __floats2half2_rn(b.z, b.w);
-      uint4 pk;
-      pk.x = *reinterpret_cast<unsigned*>(&h0);
-      pk.y = *reinterpret_cast<unsigned*>(&h1);
-      pk.z = *reinterpret_cast<unsigned*>(&h2);
-      pk.w = *reinterpret_cast<unsigned*>(&h3);
-      *reinterpret_cast<uint4*>(out + (size_t)cell * 512 + lane * 8) = pk;
+      f32x4 a[4], b[4];
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* m = mem + (size_t)cells[j] * 512 + lane * 8;
+        a[j] = *reinterpret_cast<const f32x4*>(m);
+        b[j] = *reinterpret_cast<const f32x4*>(m + 4);
+        o[j] = obs[cells[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < nb) {
+          f32x4 x = a[j], y = b[j];
+          if (o[j] > 1.0f) {
+            x.x = __fdiv_rn(x.x, o[j]); x.y = __fdiv_rn(x.y, o[j]); x.z = __fdiv_rn(x.z, o[j]); x.w = __fdiv_rn(x.w, o[j]);
+            y.x = __fdiv_rn(y.x, o[j]); y.y = __fdiv_rn(y.y, o[j]); y.z = __fdiv_rn(y.z, o[j]); y.w = __fdiv_rn(y.w, o[j]);
+          }
+          __half2 h0 = __floats2half2_rn(x.x, x.y), h1 = __floats2half2_rn(x.z, x.w);
+          __half2 h2 = __floats2half2_rn(y.x, y.y), h3 = __floats2half2_rn(y.z, y.w);
+          uint4 pk;
+          pk.x = *reinterpret_cast<unsigned*>(&h0);
+          pk.y = *reinterpret_cast<unsigned*>(&h1);
+          pk.z = *reinterpret_cast<unsigned*>(&h2);
+          pk.w = *reinterpret_cast<unsigned*>(&h3);
+          *reinterpret_cast<uint4*>(out + (size_t)cells[j] * 512 + lane * 8) = pk;
+        }
+      }
     }
   }
 }
@@ -76,22 +97,26 @@ constexpr int GP_PROBES = 16;   // linear-probing bound; a pixel whose cell find
 struct GpShared {
   int key[GP_HASH];             // cell index or -1
   short slot_of[GP_HASH];       // hash entry -> row slot (or -1 when beyond GP_CAP)
-  short pix[1024];              // per pixel: hash entry, then row slot; -1 = read the table directly
+  __attribute__((aligned(8))) short pix[1024];   // per pixel: hash entry, then row slot; -1 = read the table directly
   int ucell[GP_CAP];
-  short blk[64];                // per 4x4 block: the common slot of its 16 pixels, or -1
   int wave_cnt[4];
   int n_unique;
   float s16[4][512];
 };
 
+// acc += float(half): ONE v_fma_mix_f32 (f16 source operand, * 1.0, f32 accumulate; a single rounding, identical to convert + add).
+// The compiler's own choice for this pattern is v_cvt_f32_f16 x2 + v_pk_add_f32, 1.5 instructions per element on a VALU-bound loop.
+__device__ __forceinline__ void mix_lo(float& acc, unsigned pk) {
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk));
+}
+__device__ __forceinline__ void mix_hi(float& acc, unsigned pk) {
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk));
+}
 __device__ __forceinline__ void add8(float (&acc)[8], const uint4& raw) {
-  const __half2* h = reinterpret_cast<const __half2*>(&raw);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float2 f = __half22float2(h[q]);
-    acc[2 * q] += f.x;
-    acc[2 * q + 1] += f.y;
-  }
+  mix_lo(acc[0], raw.x); mix_hi(acc[1], raw.x);
+  mix_lo(acc[2], raw.y); mix_hi(acc[3], raw.y);
+  mix_lo(acc[4], raw.z); mix_hi(acc[5], raw.z);
+  mix_lo(acc[6], raw.w); mix_hi(acc[7], raw.w);
 }
 
 __device__ __forceinline__ float round_f16(float v) { return __half2float(__float2half_rn(v)); }
@@ -107,7 +132,14 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   return pk;
 }
 
-// pooled: fp16 [h8*w8 + h16*w16 + h32*w32, 512] row list (P3 rows, then P4, then P5), the layout project_fuse reads
+// Pooled rows are stored in the A-fragment order of v_mfma_f32_32x32x16_f16 so that project_fuse reads every operand fragment
+// as ONE contiguous 1 KiB wave load: [level][32-row tile][k-step s = 0..31][lane = 32 hi + r][8 halves], element
+// (row = 32 tile + r, channel = 16 s + 8 hi + j).  Each level starts on a tile boundary (its last tile may be partly unused).
+__device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
+  // c8 = channel / 8 = 2 s + hi
+  return ((((size_t)tile32 * 32 + (c8 >> 1)) * 2 + (c8 & 1)) * 32 + r) * 8;
+}
+
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -185,26 +217,13 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   const int nu = S.n_unique;
   for (int s = wave; s < nu; s += 4) rows[s * 64 + lane] = *reinterpret_cast<const uint4*>(mem + (size_t)S.ucell[s] * 512 + lane * 8);
   __syncthreads();
-  if (tid < 64) {
-    const int by = tid >> 3, bx = tid & 7;
-    const short first = S.pix[(by * 4) * 32 + bx * 4];
-    bool same = first >= 0;
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 4; ++dx) same &= S.pix[(by * 4 + dy) * 32 + bx * 4 + dx] == first;
-    S.blk[tid] = same ? first : (short)-1;
-  }
-  __syncthreads();
-
   // phase 4: pooling.  Wave q owns a 16x16 quadrant (one stride-16 cell), each lane 8 consecutive channels.
   // Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in f32, /16; each avg_pool2d(2) sums 4 values row-major, /4,
   // rounds to fp16 (timm.py:152,168).
   const int qy = wave >> 1, qx = wave & 1;
   const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
-  __half* p8 = pooled;
-  __half* p16 = pooled + (size_t)h8 * w8 * 512;
-  __half* p32 = p16 + (size_t)h16 * w16 * 512;
+  const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
+  const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
   float acc16[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
@@ -220,26 +239,52 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll 1
         for (int bx = 0; bx < 2; ++bx) {
           const int py0 = qy * 16 + cy8 * 8 + by * 4, px0 = qx * 16 + cx8 * 8 + bx * 4;
-          const int bslot = __builtin_amdgcn_readfirstlane((int)S.blk[(py0 >> 2) * 8 + (px0 >> 2)]);
+          // the block's 16 row slots: 4 x 8 bytes of LDS, wave-uniform -> scalar registers
+          int sl[16];
+          int lo = 0x7fff, hi = -0x8000;
+#pragma unroll
+          for (int dy = 0; dy < 4; ++dy) {
+            const uint2 v = *reinterpret_cast<const uint2*>(&S.pix[(py0 + dy) * 32 + px0]);
+            const unsigned a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)v.x), a1 = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y);
+            sl[4 * dy + 0] = (int)(short)(a0 & 0xffffu);
+            sl[4 * dy + 1] = (int)(short)(a0 >> 16);
+            sl[4 * dy + 2] = (int)(short)(a1 & 0xffffu);
+            sl[4 * dy + 3] = (int)(short)(a1 >> 16);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            lo = sl[i] < lo ? sl[i] : lo;
+            hi = sl[i] > hi ? sl[i] : hi;
+          }
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          if (bslot >= 0) {
+          if (lo == hi && lo >= 0) {
             // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
-            add8(acc4, rows[bslot * 64 + lane]);
+            add8(acc4, rows[lo * 64 + lane]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
+          } else if (lo >= 0) {
+            // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
+            uint4 raw[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) raw[i] = rows[sl[i] * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) add8(acc4, raw[i]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
           } else {
+            // rare: more distinct cells in the tile than the LDS cache holds
 #pragma unroll 1
             for (int dy = 0; dy < 4; ++dy) {
               uint4 raw[4];
 #pragma unroll
               for (int dx = 0; dx < 4; ++dx) {
                 const int pi = (py0 + dy) * 32 + px0 + dx;
-                const int s = __builtin_amdgcn_readfirstlane((int)S.pix[pi]);
-                if (s >= 0) {
-                  raw[dx] = rows[s * 64 + lane];
-                } else {      // rare: more distinct cells in the tile than the LDS cache holds
+                const int sidx = __builtin_amdgcn_readfirstlane((int)S.pix[pi]);
+                if (sidx >= 0) {
+                  raw[dx] = rows[sidx * 64 + lane];
+                } else {
                   int cell = proj[(size_t)(ty * 32 + py0 + dy) * W + tx * 32 + px0 + dx];
                   cell = cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell);
                   raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * 512 + lane * 8);
@@ -260,7 +305,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
         acc16[q] += v8[q];
       }
       const int oy = ty * 4 + qy * 2 + cy8, ox = tx * 4 + qx * 2 + cx8;
-      *reinterpret_cast<uint4*>(p8 + ((size_t)oy * w8 + ox) * 512 + lane * 8) = pack8(v8);
+      {
+        const int row = oy * w8 + ox;
+        *reinterpret_cast<uint4*>(pooled + frag_half_offset(row >> 5, row & 31, lane)) = pack8(v8);
+      }
     }
   }
   float v16[8];
@@ -271,12 +319,19 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   }
   {
     const int oy = ty * 2 + qy, ox = tx * 2 + qx;
-    *reinterpret_cast<uint4*>(p16 + ((size_t)oy * w16 + ox) * 512 + lane * 8) = pack8(v16);
+    const int row = oy * w16 + ox;
+    *reinterpret_cast<uint4*>(pooled + frag_half_offset(t16 + (row >> 5), row & 31, lane)) = pack8(v16);
   }
   __syncthreads();
-  for (int c = tid; c < 512; c += 256) {
-    const float s = ((S.s16[0][c] + S.s16[1][c]) + S.s16[2][c]) + S.s16[3][c];
-    p32[((size_t)ty * w32 + tx) * 512 + c] = __float2half_rn(s * 0.25f);
+  if (tid < 64) {
+    float v32[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = tid * 8 + q;
+      v32[q] = (((S.s16[0][c] + S.s16[1][c]) + S.s16[2][c]) + S.s16[3][c]) * 0.25f;
+    }
+    const int row = ty * w32 + tx;
+    *reinterpret_cast<uint4*>(pooled + frag_half_offset(t32 + (row >> 5), row & 31, tid)) = pack8(v32);
   }
 }
 
@@ -285,8 +340,8 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 // ------------------------------------------------------------------------------------------------------
 // weights: per level and output channel n, scaled by 2^S_n so that max_k |w| lands in [2^13, 2^14), then split
 //   w * 2^S = h + m + l  (h = f16(w'), m = f16(w' - h), l = f16(w' - h - m); the residuals are exact in f32)
-// layout [level][piece][n][k] f16, k contiguous: lane (r = lane & 31, hi = lane >> 5) of a 32x32x16 MFMA reads its B fragment
-// B[k = 16 s + 8 hi + j][col n0 + r] as ONE 16-byte load; the A fragment A[row r][k ...] comes straight from the pooled rows.
+// layout [level][piece][32-column tile][k-step s][lane = 32 hi + r][8 halves]: the B fragment B[k = 16 s + 8 hi + j][col 32 tile + r]
+// of a wave is ONE contiguous 1 KiB load, like the A fragments gather_pool writes.
 __global__ __launch_bounds__(64) void project_prepare_kernel(const float* __restrict__ w /*[256][512]*/, _Float16* __restrict__ out,
                                                                float* __restrict__ sinv, int piece_stride) {
   const int n = blockIdx.x, lane = threadIdx.x;
@@ -307,16 +362,18 @@ __global__ __launch_bounds__(64) void project_prepare_kernel(const float* __rest
     const _Float16 m = (_Float16)r1;
     const float r2 = r1 - (float)m;
     const _Float16 l = (_Float16)r2;
-    out[(size_t)0 * piece_stride + n * 512 + k] = h;
-    out[(size_t)1 * piece_stride + n * 512 + k] = m;
-    out[(size_t)2 * piece_stride + n * 512 + k] = l;
+    const size_t o = ((((size_t)(n >> 5) * 32 + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32 + (n & 31)) * 8 + (k & 7);
+    out[(size_t)0 * piece_stride + o] = h;
+    out[(size_t)1 * piece_stride + o] = m;
+    out[(size_t)2 * piece_stride + o] = l;
   }
   if (lane == 0) sinv[n] = ldexpf(1.0f, -S);
 }
 
 struct ProjArgs {
-  int level_off[4];     // row offsets of P3, P4, P5 in the row list (+ end)
-  int tile_off[4];      // first 64-row tile of each level (+ end)
+  int level_off[4];     // row offsets of P3, P4, P5 in the fp32 row list `feats` (+ end)
+  int tile_off[4];      // first 64-row workgroup tile of each level (+ end)
+  int frag_tile_off[3]; // first 32-row fragment tile of each level in the pooled buffer
   float weight;         // MODEL.MAP_FEATURE_WEIGHT
   int mode;             // 0: P = (x.W + b) * weight + P   (sum)     1: P = (x.W + b) * weight   (mem_only)
 };
@@ -332,16 +389,19 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
   const int r = lane & 31, hi = lane >> 5;
   const _Float16* Wl = Wsplit + (size_t)lvl * 3 * 256 * 512;
 
+  // fragment blocks: 1 KiB per (32-row or 32-column tile, k-step); lane l reads bytes [16 l, 16 l + 16)
+  const int local_tile = (t - a.tile_off[lvl]) * 2;                 // first 32-row tile of this workgroup inside its level
+  const int level_tiles = (row_end - a.level_off[lvl] + 31) >> 5;
   const _Float16* ap[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    int row = row0 + 32 * m + r;
-    row = row < row_end ? row : row_end - 1;            // clamped read, masked store
-    ap[m] = X + (size_t)row * 512 + 8 * hi;
+    int lt = local_tile + m;
+    lt = lt < level_tiles ? lt : level_tiles - 1;                   // a level with an odd tile count: re-read the last one, masked store
+    ap[m] = X + ((size_t)(a.frag_tile_off[lvl] + lt) * 32 * 64 + lane) * 8;
   }
   const _Float16* bp[2];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) bp[n] = Wl + (size_t)(wave * 64 + 32 * n + r) * 512 + 8 * hi;
+  for (int n = 0; n < 2; ++n) bp[n] = Wl + ((size_t)(wave * 2 + n) * 32 * 64 + lane) * 8;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -351,15 +411,15 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-#pragma unroll 2
+#pragma unroll 4
   for (int s = 0; s < 32; ++s) {
     f16x8 af[2], bf[2][3];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f16x8*>(ap[m] + 16 * s);
+    for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f16x8*>(ap[m] + (size_t)s * 64 * 8);
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + 16 * s);
+      for (int p = 0; p < 3; ++p) bf[n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + (size_t)s * 64 * 8);
     // smallest pieces first: the low-order products enter the fp32 accumulator before the large ones
 #pragma unroll
     for (int p = 2; p >= 0; --p)
@@ -451,9 +511,12 @@ extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* p
   const int rows[3] = {(H >> 3) * (W >> 3), (H >> 4) * (W >> 4), (H >> 5) * (W >> 5)};
   a.level_off[0] = 0;
   a.tile_off[0] = 0;
+  int ft = 0;
   for (int l = 0; l < 3; ++l) {
     a.level_off[l + 1] = a.level_off[l] + rows[l];
     a.tile_off[l + 1] = a.tile_off[l] + (rows[l] + 63) / 64;
+    a.frag_tile_off[l] = ft;
+    ft += (rows[l] + 31) / 32;
   }
   a.weight = weight;
   a.mode = mode;
@@ -463,4 +526,12 @@ extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* p
   hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3]), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(pooled_f16), ws, sinv, bias, feats, a);
   return eod_launch_status();
+}
+
+extern "C" size_t eod_memory_pooled_halves(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  const int rows[3] = {(H >> 3) * (W >> 3), (H >> 4) * (W >> 4), (H >> 5) * (W >> 5)};
+  size_t tiles = 0;
+  for (int l = 0; l < 3; ++l) tiles += (size_t)((rows[l] + 31) / 32);
+  return tiles * 32 * 512;
 }

@@ -395,12 +395,13 @@ def memory_normalize_dirty_f16(mem: torch.Tensor, obs: torch.Tensor, dirty: torc
 
 
 def pooled_rows(H: int, W: int) -> int:
-    return (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32)
+    """Rows of the pooled buffer: every level padded to whole 32-row operand tiles (include/eod_hip.h eod_memory_gather_pool)."""
+    return int(_lib.load().eod_memory_pooled_halves(H, W)) // 512
 
 
 def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None,
                        err: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """a8 gather + cascaded pooling -> fp16 [h8*w8 + h16*w16 + h32*w32, 512] (stride-8 rows, then 16, then 32)."""
+    """a8 gather + cascaded pooling -> fp16 pooled rows of the three levels in MFMA operand-fragment order (see the header)."""
     N, D = mem_f16.shape
     if out is None:
         out = torch.empty((pooled_rows(H, W), D), dtype=torch.float16, device=mem_f16.device)

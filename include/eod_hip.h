@@ -202,8 +202,11 @@ int eod_memory_normalize_dirty_f16(const float* mem, const float* obs, int32_t* 
                                    eod_stream_t stream);
 /* device-side error word (OR of flags); kernels that index with caller data clamp and set it instead of faulting */
 #define EOD_FLAG_BAD_CELL_INDEX 1   /* a proj_indices entry outside [0, n_cells) was clamped */
-/* a8 gather + cascaded average pooling (timm.py:147-168): pooled_f16 = fp16 [h8*w8 + h16*w16 + h32*w32, 512] row list
- * (stride-8 rows, then stride-16, then stride-32; the values timm.py:168 casts to fp16).  err_flags: int32 [1] or NULL. */
+/* a8 gather + cascaded average pooling (timm.py:147-168): the values timm.py:168 casts to fp16, for the stride-8, -16 and -32
+ * levels, stored in the operand-fragment order eod_memory_project_fuse reads: [level][32-row tile][k-step s<32][hi<2][r<32][8]
+ * halves = element (row 32*tile + r, channel 16 s + 8 hi + j); each level starts on a tile boundary, so the buffer holds
+ * eod_memory_pooled_halves(H, W) halves.  err_flags: int32 [1] or NULL. */
+size_t eod_memory_pooled_halves(int H, int W);
 int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells,
                            uint16_t* pooled_f16, int32_t* err_flags, eod_stream_t stream);
 /* a8 projection + fusion (timm.py:174-189): for the three levels P_l = (pooled_l . W_l^T + b_l) * weight (+ P_l if mode 0

@@ -96,6 +96,44 @@ def pmc_traffic():
         return None
 
 
+def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
+    """The HBM-bound class: memory read = a4 (obs-normalise + fp16 cast) + a8 (gather, cascaded pooling, three 1x1
+    projections, x weight, fusion into P3..P5), on the frame's real data, each kernel bracketed by HIP events on the stream it is
+    launched on, one stream, `reps` repetitions.  Algorithmic bytes are the reference algorithm's (full-map normalise, U = N):
+        4 P + N (512*4 + 4) + 2*256*4 * sum_l h_l w_l + 3*512*256*4
+    The build moves far fewer (dirty rows only, distinct rows per tile once); `achieved` = algorithmic bytes / measured time."""
+    from embodied_object_detection_amd import ops
+    f = frames[idx]
+    model.inference_frame(frames[idx - 1], refresh_memory_snapshot=True, materialize=False)   # leaves this frame's dirty rows behind
+    torch.cuda.synchronize()
+    snap = model._dirty.clone()
+    n_dirty = int(snap.sum().item())
+    proj = f["proj_indices"]
+    shapes, off, feats, views, pooled = model.backbone._plan(H, W, 0)
+    names = ("normalize_dirty_f16_kernel", "gather_pool_kernel", "project_fuse_kernel")
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for r in range(reps):
+        model._dirty.copy_(snap)
+        ev[r][0].record()
+        ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16)
+        ev[r][1].record()
+        ops.memory_gather_pool(model._mem_f16, proj, H, W, out=pooled, err=model._err)
+        ev[r][2].record()
+        model.backbone.merge(pooled, feats, H, W, model.backbone.map_feature_weight, "sum")
+        ev[r][3].record()
+    torch.cuda.synchronize()
+    us = [float(np.median([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(5, reps)])) * 1e3 for k in range(3)]
+    rows = sum(h * w for (h, w) in shapes[:3])
+    alg = 4 * H * W + n_cells * (512 * 4 + 4) + 2 * 256 * 4 * rows + 3 * 512 * 256 * 4
+    tot = sum(us)
+    ach = alg / (tot * 1e-6) / 1e9
+    return {"bound": "hbm", "class": "memory read + fusion (a4 + a8)", "kernels": dict(zip(names, [round(u, 2) for u in us])),
+            "avg_us_total": round(tot, 2), "algorithmic_bytes": alg, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBPS, 4), "dirty_rows_this_frame": n_dirty, "memory_cells": n_cells,
+            "note": "event-bracketed on one stream after the timed region (median of %d launches); algorithmic bytes = the reference "
+                    "algorithm's per frame (SURVEY 8d, U = N); rocprofv3 per-kernel averages of the same run are under profiles/" % (reps - 5)}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -369,6 +407,14 @@ def main():
                                   "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
             variants["bf16x3_split_mfma"] = v
 
+    roofline_hbm = None
+    if rank == 0:
+        try:
+            roofline_hbm = hbm_class_probe(model, frames, args.warmup + 2, H, W, seq.n_cells)
+            log(f"hbm class: {roofline_hbm['kernels']} -> {roofline_hbm['achieved']} GB/s ({roofline_hbm['frac']})")
+        except Exception as e:      # never lose the headline to the probe
+            log(f"hbm probe failed: {e!r}")
+
     # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
     rec = RecordBuffer(max_rows=4 * 108)
     for j, i in enumerate(range(args.warmup, n_frames - 1)):
@@ -444,6 +490,7 @@ def main():
                         "pred_masks bool [D,H,W])}] per frame (train_mp3d.py:186, custom_rcnn.py:537-546); inputs resident in HBM",
             "boundary_host_inputs": boundary_host,
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "frame_roofline": frame_roofline(H, W, float(np.mean(pc)), float(np.mean(dc)), elapsed / args.steps, headline_math),
             "variants": variants,
             "eval_allreduce_ms": round(t_ar * 1e3, 3),

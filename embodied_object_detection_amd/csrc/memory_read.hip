@@ -31,16 +31,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* __restrict__ mem, const float* __restrict__ obs,
                                                                    int* __restrict__ dirty, __half* __restrict__ out, int n_cells) {
   const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6;
   const int n_groups = (n_cells + 63) >> 6;
-  for (int g = blockIdx.x * wpb + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * wpb) {
+  // The 4 waves of a workgroup share one 64-cell group and split its dirty rows (bit index mod 4): dirty cells come in runs
+  // (neighbouring map cells), so a run is spread over 4 waves x 4 rows in flight instead of serialising in one wave.
+  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int c = (g << 6) + lane;
     int f = 0;
-    if (c < n_cells) {
-      f = dirty[c];
-      if (f) dirty[c] = 0;
-    }
-    u64 bal = __ballot(f != 0);
+    if (c < n_cells) f = dirty[c];
+    __syncthreads();                       // every wave has read the flags before wave 0 clears them
+    if (wave == 0 && f) dirty[c] = 0;
+    u64 bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
     while (bal) {
       // up to 4 dirty rows per step: their loads are independent and in flight together
       int cells[4];
@@ -429,22 +430,28 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
         for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf[n][p], acc[m][n], 0, 0, 0);
   }
 
-  // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi
+  // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi.  All residual loads of a 32x32 tile are issued before
+  // its stores: written as load-modify-store per element, the compiler must keep every load behind the previous store (the
+  // addresses may alias) and the epilogue becomes 64 serial round trips (60 us measured).
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = wave * 64 + 32 * n + r;
     const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      const int rbase = row0 + 32 * m + 4 * hi;
+      float old[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = row0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hi;
-        if (row < row_end) {
-          float* o = P + (size_t)row * 256 + col;
-          // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
-          const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][n][i], si), b), a.weight);
-          *o = a.mode == 0 ? __fadd_rn(v, *o) : v;
-        }
+        const int row = rbase + (i & 3) + 8 * (i >> 2);
+        old[i] = (a.mode == 0 && row < row_end) ? P[(size_t)row * 256 + col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rbase + (i & 3) + 8 * (i >> 2);
+        // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
+        const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][n][i], si), b), a.weight);
+        if (row < row_end) P[(size_t)row * 256 + col] = a.mode == 0 ? __fadd_rn(v, old[i]) : v;
       }
     }
   }
@@ -457,8 +464,8 @@ extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs
   if (!mem || !obs || !dirty || !out_f16) return EOD_ERR_NULL;
   if (n_cells <= 0 || D != 512) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem) || !eod_aligned16(out_f16)) return EOD_ERR_ALIGN;
-  int blocks = ((n_cells + 63) / 64 + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (n_cells + 63) / 64;
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(normalize_dirty_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mem, obs, dirty,
                      reinterpret_cast<__half*>(out_f16), n_cells);
   return eod_launch_status();

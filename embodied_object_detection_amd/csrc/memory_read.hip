@@ -412,22 +412,35 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-#pragma unroll 4
-  for (int s = 0; s < 32; ++s) {
-    f16x8 af[2], bf[2][3];
+  // Software pipeline, written out: the 8 fragment loads of k-step s + 2 are issued before the 12 MFMAs of k-step s (three
+  // register sets).  Left to the compiler the loop became load -> s_waitcnt vmcnt(0) -> MFMA with ONE load in flight: 50 us.
+  f16x8 af[3][2], bf[3][2][3];
+  auto load_step = [&](int buf, int s) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f16x8*>(ap[m] + (size_t)s * 64 * 8);
+    for (int m = 0; m < 2; ++m) af[buf][m] = *reinterpret_cast<const f16x8*>(ap[m] + (size_t)s * 64 * 8);
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + (size_t)s * 64 * 8);
+      for (int p = 0; p < 3; ++p) bf[buf][n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + (size_t)s * 64 * 8);
+  };
+  auto mma_step = [&](int buf) {
     // smallest pieces first: the low-order products enter the fp32 accumulator before the large ones
 #pragma unroll
     for (int p = 2; p >= 0; --p)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf[n][p], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][m], bf[buf][n][p], acc[m][n], 0, 0, 0);
+  };
+  load_step(0, 0);
+  load_step(1, 1);
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    if (s + 2 < 32) load_step((s + 2) % 3, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(s % 3);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi.  All residual loads of a 32x32 tile are issued before
@@ -443,8 +456,9 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
       float old[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = rbase + (i & 3) + 8 * (i >> 2);
-        old[i] = (a.mode == 0 && row < row_end) ? P[(size_t)row * 256 + col] : 0.f;
+        int row = rbase + (i & 3) + 8 * (i >> 2);
+        row = row < row_end ? row : row_end - 1;            // clamped address instead of a divergent branch per element
+        old[i] = P[(size_t)row * 256 + col];
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {

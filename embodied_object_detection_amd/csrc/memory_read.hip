@@ -8,8 +8,9 @@
 //  * the fp16 table is kept INCREMENTALLY: the write path marks the cells whose accumulator row or observation count changed
 //    (`dirty`), and only those rows are re-normalised.  The reference clones and divides the whole map every frame (O(N):
 //    123 MB at 40 000 cells, 805 MB at 262 144) for a few thousand changed rows.
-//  * the gather fetches every DISTINCT cell of a 32x32 pixel tile once into LDS (an LDS hash de-duplicates the 1 024 indices;
-//    round 1 issued one 1 KiB row read per pixel: 420 MB of L2 traffic for <= 60 MB compulsory) and pools out of LDS.  A 4x4
+//  * the gather fetches every DISTINCT cell of a 16x16 pixel quadrant once into LDS (wave-level ballot de-duplication, rows
+//    brought in by global -> LDS DMA; round 1 issued one 1 KiB row read per pixel: 420 MB of L2 traffic for <= 60 MB
+//    compulsory) and pools out of LDS with one v_fma_mix_f32 per element.  A 4x4
 //    block whose 16 pixels share one cell is the cell's value exactly (n*v is exact in f32 for n <= 16 and an 11-bit v), so
 //    the 16 adds are skipped; every other block is summed in torch's row-major order: results stay bit-identical.
 //  * the three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion are ONE launch on the f16 matrix cores: the pooled operand is
@@ -90,20 +91,7 @@ __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* _
 // ------------------------------------------------------------------------------------------------------
 // a8: gather + cascaded average pooling, one workgroup per 32x32 pixel tile
 // ------------------------------------------------------------------------------------------------------
-constexpr int GP_CAP = 64;      // distinct rows cached per tile (64 KiB of LDS); pixels beyond it read HBM/L2 directly
-constexpr int GP_HASH = 512;    // open-addressing table (power of two, >= 2 * typical distinct count)
-
-constexpr int GP_PROBES = 16;   // linear-probing bound; a pixel whose cell finds no entry within it reads the table directly
-
-struct GpShared {
-  int key[GP_HASH];             // cell index or -1
-  short slot_of[GP_HASH];       // hash entry -> row slot (or -1 when beyond GP_CAP)
-  __attribute__((aligned(8))) short pix[1024];   // per pixel: hash entry, then row slot; -1 = read the table directly
-  int ucell[GP_CAP];
-  int wave_cnt[4];
-  int n_unique;
-  float s16[4][512];
-};
+constexpr int GP_CAP = 16;      // distinct rows cached per 16x16 quadrant (16 KiB of LDS per wave); pixels beyond it read L2/HBM directly
 
 // acc += float(half): ONE v_fma_mix_f32 (f16 source operand, * 1.0, f32 accumulate; a single rounding, identical to convert + add).
 // The compiler's own choice for this pattern is v_cvt_f32_f16 x2 + v_pk_add_f32, 1.5 instructions per element on a VALU-bound loop.
@@ -143,85 +131,63 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  GpShared& S = *reinterpret_cast<GpShared*>(smem_raw);
-  uint4* rows = reinterpret_cast<uint4*>(smem_raw + ((sizeof(GpShared) + 15) & ~(size_t)15));   // [GP_CAP][64] x 16 B
-
+  // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
+  extern __shared__ __align__(1024) unsigned char smem_raw[];
+  typedef __attribute__((address_space(3))) void lds_void;
   const int tiles_x = W >> 5;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  const int qy = wave >> 1, qx = wave & 1;                 // the wave's 16x16 quadrant = one stride-16 cell
+  unsigned char* my_rows = smem_raw + (size_t)wave * GP_CAP * 1024;
+  const uint4* rows = reinterpret_cast<const uint4*>(my_rows);                          // [GP_CAP][64] x 16 B
+  float* s16 = reinterpret_cast<float*>(smem_raw + (size_t)4 * GP_CAP * 1024);          // [4][512]
 
-  for (int i = tid; i < GP_HASH; i += 256) S.key[i] = -1;
-  __syncthreads();
-  // phase 1: indices (clamped + flagged), inserted into the hash
-  bool bad = false;
-  for (int i = tid; i < 1024; i += 256) {
-    const int yy = i >> 5, xx = i & 31;
-    int cell = proj[(size_t)(ty * 32 + yy) * W + tx * 32 + xx];
-    if ((unsigned)cell >= (unsigned)n_cells) {
-      bad = true;
-      cell = cell < 0 ? 0 : n_cells - 1;
-    }
-    unsigned h = ((unsigned)cell * 2654435761u) >> 23;          // 9 bits
-    int entry = -1;
-    for (int probe = 0; probe < GP_PROBES; ++probe) {
-      const int old = atomicCAS(&S.key[h], -1, cell);
-      if (old == -1 || old == cell) {
-        entry = (int)h;
-        break;
-      }
-      h = (h + 1) & (GP_HASH - 1);
-    }
-    S.pix[i] = (short)entry;
-  }
-  if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
-  __syncthreads();
-  // phase 2: occupied entries -> slots (entry order; which cell gets which slot does not affect the results)
+  // phase 1: lane l holds the 4 pixels (y = l >> 2, x = 4 (l & 3) ..+3) of its quadrant: one 16-byte index load
+  int c[4];
   {
-    int c = 0;
+    const int y = ty * 32 + qy * 16 + (lane >> 2), x = tx * 32 + qx * 16 + 4 * (lane & 3);
+    const int4 v = *reinterpret_cast<const int4*>(proj + (size_t)y * W + x);
+    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    bool bad = false;
 #pragma unroll
-    for (int j = 0; j < GP_HASH / 256; ++j) c += S.key[tid * (GP_HASH / 256) + j] != -1;
-    int inc = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) S.wave_cnt[wave] = inc;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += S.wave_cnt[w];
-    int rank = base + inc - c;
-#pragma unroll
-    for (int j = 0; j < GP_HASH / 256; ++j) {
-      const int e = tid * (GP_HASH / 256) + j;
-      const int k = S.key[e];
-      if (k != -1) {
-        if (rank < GP_CAP) {
-          S.slot_of[e] = (short)rank;
-          S.ucell[rank] = k;
-        } else {
-          S.slot_of[e] = -1;
-        }
-        ++rank;
+    for (int j = 0; j < 4; ++j) {
+      if ((unsigned)c[j] >= (unsigned)n_cells) {
+        bad = true;
+        c[j] = c[j] < 0 ? 0 : n_cells - 1;
       }
     }
-    if (tid == 255) S.n_unique = rank < GP_CAP ? rank : GP_CAP;
+    if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
   }
-  __syncthreads();
-  // phase 3: per pixel slot; per 4x4 block the common slot; fetch the distinct rows (all loads independent)
-  for (int i = tid; i < 1024; i += 256) {
-    const int e = S.pix[i];
-    S.pix[i] = e >= 0 ? S.slot_of[e] : (short)-1;
+  // phase 2: de-duplicate inside the wave with ballots (no LDS atomics: an LDS hash over the tile cost 13 us of CAS contention,
+  // the pixels of a tile hit ~15 distinct cells).  Each round takes the first unassigned pixel's cell as key, starts the key
+  // row's global -> LDS DMA (1 KiB, `buffer_load ... lds`: no VGPR staging) and assigns its slot to every pixel with that cell.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(mem), 0, 0xFFFFFFFFu, 0x00020000);
+  unsigned todo = 0xFu;
+  unsigned slots = 0xFFFFFFFFu;          // 4 x 8 bit; 255 = not cached (read the table directly)
+  int n_rows = 0;
+#pragma unroll 1
+  while (n_rows < GP_CAP) {
+    const u64 bal = __ballot(todo != 0);
+    if (bal == 0) break;
+    const int leader = __ffsll((long long)bal) - 1;
+    const int j = __ffs((int)todo) - 1;
+    const int cand = j == 0 ? c[0] : (j == 1 ? c[1] : (j == 2 ? c[2] : c[3]));
+    const int key = __builtin_amdgcn_readlane(cand, leader);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(my_rows + n_rows * 1024), 16, (unsigned)key * 1024u + lane * 16u, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (((todo >> q) & 1u) && c[q] == key) {
+        slots = (slots & ~(0xFFu << (8 * q))) | ((unsigned)n_rows << (8 * q));
+        todo &= ~(1u << q);
+      }
+    }
+    ++n_rows;
   }
-  const int nu = S.n_unique;
-  for (int s = wave; s < nu; s += 4) rows[s * 64 + lane] = *reinterpret_cast<const uint4*>(mem + (size_t)S.ucell[s] * 512 + lane * 8);
-  __syncthreads();
-  // phase 4: pooling.  Wave q owns a 16x16 quadrant (one stride-16 cell), each lane 8 consecutive channels.
-  // Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in f32, /16; each avg_pool2d(2) sums 4 values row-major, /4,
-  // rounds to fp16 (timm.py:152,168).
-  const int qy = wave >> 1, qx = wave & 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA'd rows are in LDS (only this wave reads them)
+
+  // phase 3: pooling.  Each lane owns 8 consecutive channels.  Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in
+  // f32, /16; each avg_pool2d(2) sums 4 values row-major, /4, rounds to fp16 (timm.py:152,168).
   const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
   const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
   const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
@@ -239,33 +205,30 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       for (int by = 0; by < 2; ++by) {
 #pragma unroll 1
         for (int bx = 0; bx < 2; ++bx) {
-          const int py0 = qy * 16 + cy8 * 8 + by * 4, px0 = qx * 16 + cx8 * 8 + bx * 4;
-          // the block's 16 row slots: 4 x 8 bytes of LDS, wave-uniform -> scalar registers
+          // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
+          const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant
           int sl[16];
-          int lo = 0x7fff, hi = -0x8000;
+          int lo = 255, hi = 0;
 #pragma unroll
           for (int dy = 0; dy < 4; ++dy) {
-            const uint2 v = *reinterpret_cast<const uint2*>(&S.pix[(py0 + dy) * 32 + px0]);
-            const unsigned a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)v.x), a1 = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y);
-            sl[4 * dy + 0] = (int)(short)(a0 & 0xffffu);
-            sl[4 * dy + 1] = (int)(short)(a0 >> 16);
-            sl[4 * dy + 2] = (int)(short)(a1 & 0xffffu);
-            sl[4 * dy + 3] = (int)(short)(a1 >> 16);
-          }
+            const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)slots, (yq + dy) * 4 + xq4);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            lo = sl[i] < lo ? sl[i] : lo;
-            hi = sl[i] > hi ? sl[i] : hi;
+            for (int dx = 0; dx < 4; ++dx) {
+              const int v = (int)((pk >> (8 * dx)) & 0xFFu);
+              sl[4 * dy + dx] = v;
+              lo = v < lo ? v : lo;
+              hi = v > hi ? v : hi;
+            }
           }
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          if (lo == hi && lo >= 0) {
+          if (lo == hi && hi != 255) {
             // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
             add8(acc4, rows[lo * 64 + lane]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
-          } else if (lo >= 0) {
+          } else if (hi != 255) {
             // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
             uint4 raw[16];
 #pragma unroll
@@ -275,19 +238,17 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
           } else {
-            // rare: more distinct cells in the tile than the LDS cache holds
-#pragma unroll 1
+            // rare: more distinct cells in the quadrant than the LDS cache holds
+#pragma unroll
             for (int dy = 0; dy < 4; ++dy) {
               uint4 raw[4];
+              const int src_lane = (yq + dy) * 4 + xq4;
 #pragma unroll
               for (int dx = 0; dx < 4; ++dx) {
-                const int pi = (py0 + dy) * 32 + px0 + dx;
-                const int sidx = __builtin_amdgcn_readfirstlane((int)S.pix[pi]);
-                if (sidx >= 0) {
-                  raw[dx] = rows[sidx * 64 + lane];
+                if (sl[4 * dy + dx] != 255) {
+                  raw[dx] = rows[sl[4 * dy + dx] * 64 + lane];
                 } else {
-                  int cell = proj[(size_t)(ty * 32 + py0 + dy) * W + tx * 32 + px0 + dx];
-                  cell = cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell);
+                  const int cell = __builtin_amdgcn_readlane(c[dx], src_lane);
                   raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * 512 + lane * 8);
                 }
               }
@@ -316,7 +277,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     v16[q] = round_f16(acc16[q] * 0.25f);
-    S.s16[wave][lane * 8 + q] = v16[q];
+    s16[wave * 512 + lane * 8 + q] = v16[q];
   }
   {
     const int oy = ty * 2 + qy, ox = tx * 2 + qx;
@@ -329,7 +290,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int c = tid * 8 + q;
-      v32[q] = (((S.s16[0][c] + S.s16[1][c]) + S.s16[2][c]) + S.s16[3][c]) * 0.25f;
+      v32[q] = (((s16[c] + s16[512 + c]) + s16[1024 + c]) + s16[1536 + c]) * 0.25f;
     }
     const int row = ty * w32 + tx;
     *reinterpret_cast<uint4*>(pooled + frag_half_offset(t32 + (row >> 5), row & 31, tid)) = pack8(v32);
@@ -488,9 +449,9 @@ extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs
 extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, uint16_t* pooled_f16,
                                       int32_t* err_flags, eod_stream_t stream) {
   if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
-  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0) return EOD_ERR_BAD_DIMS;
-  if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16)) return EOD_ERR_ALIGN;
-  const size_t lds = ((sizeof(GpShared) + 15) & ~(size_t)15) + (size_t)GP_CAP * 1024;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
+  const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

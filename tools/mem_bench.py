@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Stand-alone timing of the memory-read kernels on different index patterns (event-bracketed, one stream)."""
+import sys, os
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from embodied_object_detection_amd import ops
+from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+
+dev = torch.device("cuda:0")
+for (H, W, mw, cell) in ((640, 640, 200, 0.2), (960, 960, 512, 0.08)):
+    N = mw * mw
+    seq = SyntheticSequence(0, H=H, W=W, n_frames=2, map_w=mw, map_h=mw, cell=cell)
+    real = torch.from_numpy(seq.frame(1)["proj_indices"][..., 0]).to(dev)
+    pats = {"synthetic": real, "constant": torch.full((H, W), 7, dtype=torch.int32, device=dev),
+            "columns": (torch.arange(W, device=dev, dtype=torch.int32)[None, :] % N).expand(H, W).contiguous(),
+            "distinct": (torch.arange(H * W, device=dev, dtype=torch.int32) % N).reshape(H, W).contiguous()}
+    m16 = (torch.randn((N, 512), device=dev) * 10).half()
+    out = torch.empty((ops.pooled_rows(H, W), 512), dtype=torch.float16, device=dev)
+    for name, proj in pats.items():
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for a, b in ev:
+            a.record(); ops.memory_gather_pool(m16, proj, H, W, out=out); b.record()
+        torch.cuda.synchronize()
+        print(f"{H}x{W} gather_pool {name:10s} {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")

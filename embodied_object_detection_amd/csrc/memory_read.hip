@@ -14,9 +14,10 @@
 //    block whose 16 pixels share one cell is the cell's value exactly (n*v is exact in f32 for n <= 16 and an 11-bit v), so
 //    the 16 adds are skipped; every other block is summed in torch's row-major order: results stay bit-identical.
 //  * the three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion are ONE launch on the f16 matrix cores: the pooled operand is
-//    exactly fp16 (timm.py:168 casts it), each fp32 weight is split into three f16 pieces of a per-row power-of-two scaling
-//    (h + m + l reproduces the scaled weight to 2^-25 of the row maximum), every f16 x f16 product is exact in the fp32
-//    accumulator: fp32-class result at 16/3 of the fp32-MFMA rate.  Out-of-range cell indices are clamped and flagged.
+//    exactly fp16 (timm.py:168 casts it), each fp32 weight is split into TWO f16 pieces of a per-row power-of-two scaling
+//    (round-to-nearest residual: h + m carries 11 + 1 + 11 + 1 = 24 significant bits, i.e. |w - (h + m)| <= 2^-24 |w|, the size
+//    of one fp32 rounding), every f16 x f16 product is exact in the fp32 accumulator: fp32-class result at 16/2 of the
+//    fp32-MFMA rate.  Out-of-range cell indices are clamped and flagged.
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 // a8: three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion into P3..P5, one launch, f16 matrix cores
 // ------------------------------------------------------------------------------------------------------
 // weights: per level and output channel n, scaled by 2^S_n so that max_k |w| lands in [2^13, 2^14), then split
-//   w * 2^S = h + m + l  (h = f16(w'), m = f16(w' - h), l = f16(w' - h - m); the residuals are exact in f32)
+//   w * 2^S ~= h + m  (h = f16(w'), m = f16(w' - h); the residual w' - h is exact in f32, m rounds it to 11 more bits)
 // layout [level][piece][32-column tile][k-step s][lane = 32 hi + r][8 halves]: the B fragment B[k = 16 s + 8 hi + j][col 32 tile + r]
 // of a wave is ONE contiguous 1 KiB load, like the A fragments gather_pool writes.
 __global__ __launch_bounds__(64) void project_prepare_kernel(const float* __restrict__ w /*[256][512]*/, _Float16* __restrict__ out,
@@ -322,12 +323,9 @@ __global__ __launch_bounds__(64) void project_prepare_kernel(const float* __rest
     const _Float16 h = (_Float16)v;
     const float r1 = v - (float)h;
     const _Float16 m = (_Float16)r1;
-    const float r2 = r1 - (float)m;
-    const _Float16 l = (_Float16)r2;
     const size_t o = ((((size_t)(n >> 5) * 32 + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32 + (n & 31)) * 8 + (k & 7);
     out[(size_t)0 * piece_stride + o] = h;
     out[(size_t)1 * piece_stride + o] = m;
-    out[(size_t)2 * piece_stride + o] = l;
   }
   if (lane == 0) sinv[n] = ldexpf(1.0f, -S);
 }
@@ -340,16 +338,19 @@ struct ProjArgs {
   int mode;             // 0: P = (x.W + b) * weight + P   (sum)     1: P = (x.W + b) * weight   (mem_only)
 };
 
+// Workgroup = 64 rows x 128 columns, 4 waves; wave w owns columns [128 half + 32 w, +32) for both 32-row tiles: per k-step
+// 2 A + 2 B fragment loads (1 KiB each, contiguous) feed 4 MFMAs.  Small tiles on purpose: the op is 2.2 GFLOP, what matters
+// is how many bytes are in flight per CU (264 workgroups at 640x640, 2 per CU fit).
 __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Wsplit,
                                                             const float* __restrict__ sinv, const float* __restrict__ bias,
                                                             float* __restrict__ P, ProjArgs a) {
-  const int t = blockIdx.x;
+  const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int lvl = t >= a.tile_off[2] ? 2 : (t >= a.tile_off[1] ? 1 : 0);
   const int row0 = a.level_off[lvl] + (t - a.tile_off[lvl]) * 64;
   const int row_end = a.level_off[lvl + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 31, hi = lane >> 5;
-  const _Float16* Wl = Wsplit + (size_t)lvl * 3 * 256 * 512;
+  const _Float16* Wl = Wsplit + (size_t)lvl * 2 * 256 * 512;
 
   // fragment blocks: 1 KiB per (32-row or 32-column tile, k-step); lane l reads bytes [16 l, 16 l + 16)
   const int local_tile = (t - a.tile_off[lvl]) * 2;                 // first 32-row tile of this workgroup inside its level
@@ -361,73 +362,60 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
     lt = lt < level_tiles ? lt : level_tiles - 1;                   // a level with an odd tile count: re-read the last one, masked store
     ap[m] = X + ((size_t)(a.frag_tile_off[lvl] + lt) * 32 * 64 + lane) * 8;
   }
-  const _Float16* bp[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) bp[n] = Wl + ((size_t)(wave * 2 + n) * 32 * 64 + lane) * 8;
+  const int col_tile = half * 4 + wave;
+  const _Float16* bp = Wl + ((size_t)col_tile * 32 * 64 + lane) * 8;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
-  // Software pipeline, written out: the 8 fragment loads of k-step s + 2 are issued before the 12 MFMAs of k-step s (three
-  // register sets).  Left to the compiler the loop became load -> s_waitcnt vmcnt(0) -> MFMA with ONE load in flight: 50 us.
-  f16x8 af[3][2], bf[3][2][3];
+  // Software pipeline, written out: the 4 fragment loads of k-step s + 3 are issued before the 4 MFMAs of k-step s (four
+  // register sets).  Left to the compiler the loop became load -> s_waitcnt vmcnt(0) -> MFMA with ONE load in flight (50 us).
+  constexpr int DEPTH = 4;
+  f16x8 af[DEPTH][2], bf[DEPTH][2];
   auto load_step = [&](int buf, int s) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) af[buf][m] = *reinterpret_cast<const f16x8*>(ap[m] + (size_t)s * 64 * 8);
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bf[buf][n][p] = *reinterpret_cast<const f16x8*>(bp[n] + (size_t)p * 256 * 512 + (size_t)s * 64 * 8);
+    for (int p = 0; p < 2; ++p) bf[buf][p] = *reinterpret_cast<const f16x8*>(bp + (size_t)p * 256 * 512 + (size_t)s * 64 * 8);
   };
-  auto mma_step = [&](int buf) {
-    // smallest pieces first: the low-order products enter the fp32 accumulator before the large ones
 #pragma unroll
-    for (int p = 2; p >= 0; --p)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][m], bf[buf][n][p], acc[m][n], 0, 0, 0);
-  };
-  load_step(0, 0);
-  load_step(1, 1);
+  for (int s = 0; s < DEPTH - 1; ++s) load_step(s, s);
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-    if (s + 2 < 32) load_step((s + 2) % 3, s + 2);
+    if (s + DEPTH - 1 < 32) load_step((s + DEPTH - 1) % DEPTH, s + DEPTH - 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_step(s % 3);
+    // the small piece first: the low-order products enter the fp32 accumulator before the large ones
+#pragma unroll
+    for (int p = 1; p >= 0; --p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % DEPTH][m], bf[s % DEPTH][p], acc[m], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 
   // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi.  All residual loads of a 32x32 tile are issued before
   // its stores: written as load-modify-store per element, the compiler must keep every load behind the previous store (the
-  // addresses may alias) and the epilogue becomes 64 serial round trips (60 us measured).
+  // addresses may alias) and the epilogue becomes serial round trips.
+  const int col = col_tile * 32 + r;
+  const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int col = wave * 64 + 32 * n + r;
-    const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
+  for (int m = 0; m < 2; ++m) {
+    const int rbase = row0 + 32 * m + 4 * hi;
+    float old[16];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int rbase = row0 + 32 * m + 4 * hi;
-      float old[16];
+    for (int i = 0; i < 16; ++i) {
+      int row = rbase + (i & 3) + 8 * (i >> 2);
+      row = row < row_end ? row : row_end - 1;            // clamped address instead of a divergent branch per element
+      old[i] = P[(size_t)row * 256 + col];
+    }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int row = rbase + (i & 3) + 8 * (i >> 2);
-        row = row < row_end ? row : row_end - 1;            // clamped address instead of a divergent branch per element
-        old[i] = P[(size_t)row * 256 + col];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = rbase + (i & 3) + 8 * (i >> 2);
-        // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
-        const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][n][i], si), b), a.weight);
-        if (row < row_end) P[(size_t)row * 256 + col] = a.mode == 0 ? __fadd_rn(v, old[i]) : v;
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int row = rbase + (i & 3) + 8 * (i >> 2);
+      // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
+      const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][i], si), b), a.weight);
+      if (row < row_end) P[(size_t)row * 256 + col] = a.mode == 0 ? __fadd_rn(v, old[i]) : v;
     }
   }
 }
@@ -464,19 +452,19 @@ extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* pr
   return eod_launch_status();
 }
 
-extern "C" size_t eod_memory_project_weights_bytes(void) { return (size_t)3 * 3 * 256 * 512 * 2 + (size_t)2 * 3 * 256 * 4; }
+extern "C" size_t eod_memory_project_weights_bytes(void) { return (size_t)3 * 2 * 256 * 512 * 2 + (size_t)2 * 3 * 256 * 4; }
 
 extern "C" int eod_memory_project_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                           const float* b3, void* prepared, eod_stream_t stream) {
   if (!w1 || !w2 || !w3 || !b1 || !b2 || !b3 || !prepared) return EOD_ERR_NULL;
   if (!eod_aligned16(prepared)) return EOD_ERR_ALIGN;
   _Float16* ws = static_cast<_Float16*>(prepared);
-  float* sinv = reinterpret_cast<float*>(ws + (size_t)3 * 3 * 256 * 512);
+  float* sinv = reinterpret_cast<float*>(ws + (size_t)3 * 2 * 256 * 512);
   float* bias = sinv + 3 * 256;
   const float* w[3] = {w1, w2, w3};
   const float* b[3] = {b1, b2, b3};
   for (int l = 0; l < 3; ++l) {
-    hipLaunchKernelGGL(project_prepare_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream, w[l], ws + (size_t)l * 3 * 256 * 512,
+    hipLaunchKernelGGL(project_prepare_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream, w[l], ws + (size_t)l * 2 * 256 * 512,
                        sinv + l * 256, 256 * 512);
     if (hipMemcpyAsync(bias + l * 256, b[l], 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
       return EOD_ERR_LAUNCH;
@@ -503,9 +491,9 @@ extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* p
   a.weight = weight;
   a.mode = mode;
   const _Float16* ws = static_cast<const _Float16*>(prepared);
-  const float* sinv = reinterpret_cast<const float*>(ws + (size_t)3 * 3 * 256 * 512);
+  const float* sinv = reinterpret_cast<const float*>(ws + (size_t)3 * 2 * 256 * 512);
   const float* bias = sinv + 3 * 256;
-  hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3]), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3] * 2), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(pooled_f16), ws, sinv, bias, feats, a);
   return eod_launch_status();
 }

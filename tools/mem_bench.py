@@ -23,3 +23,25 @@ for (H, W, mw, cell) in ((640, 640, 200, 0.2), (960, 960, 512, 0.08)):
             a.record(); ops.memory_gather_pool(m16, proj, H, W, out=out); b.record()
         torch.cuda.synchronize()
         print(f"{H}x{W} gather_pool {name:10s} {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")
+
+# event-bracket overhead of a near-empty kernel, then normalise / project in isolation
+from embodied_object_detection_amd import _lib
+lib = _lib.load()
+x = torch.zeros((64,), dtype=torch.float32, device=dev)
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+for a, b in ev:
+    a.record(); lib.eod_fill_f32(x.data_ptr(), 0.0, 64, torch.cuda.current_stream().cuda_stream); b.record()
+torch.cuda.synchronize()
+print(f"empty kernel (fill 64 floats) event bracket {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")
+for (H, W) in ((640, 640), (960, 960)):
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn((256, 512, 1, 1), generator=g) * 0.01 for _ in range(3)]
+    bs = [torch.randn((256,), generator=g) * 0.01 for _ in range(3)]
+    proj = ops.MemoryProjector(ws, bs, dev)
+    pooled = (torch.randn((ops.pooled_rows(H, W), 512), device=dev)).half()
+    feats = torch.randn((ops.pooled_rows(H, W) + 200, 256), device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+    for a, b in ev:
+        a.record(); proj(pooled, feats, H, W, 5.0, "mem_only"); b.record()
+    torch.cuda.synchronize()
+    print(f"{H}x{W} project_fuse {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")

@@ -111,6 +111,7 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
 // (one whole deconv quadrant per workgroup: the fused mask-head tail, out_mode 2)
 void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s);
 void launch_conv_glds(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
+void launch_conv_halo(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);   // tile: 3 = 64x64, 2 = 128x64
 void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
 void launch_split_weights(const float* w, void* out, int Cout, int Kpad, hipStream_t s);
 

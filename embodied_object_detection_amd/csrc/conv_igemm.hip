@@ -66,6 +66,14 @@ inline int default_bk() {
   return v;
 }
 
+inline bool halo_default() {
+  static const bool v = [] {
+    const char* e = getenv("EOD_CONV_HALO");      // EOD_CONV_HALO=0: keep the classic kernel on the mask convs (A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 // Process-wide arithmetic mode of eod_conv2d (eod_set_conv_math / EOD_CONV_MATH): 0 fp32 MFMA, 1 bf16x3 split.
 std::atomic<int>& math_mode() {
   static std::atomic<int> v([] {
@@ -78,7 +86,7 @@ std::atomic<int>& math_mode() {
 struct Plan {
   int tile;  // 1=128x128 2=128x64 3=64x64
   int bk;    // K chunk staged per barrier pair: 32 or 64
-  int glds;  // 1: LDS-DMA kernel (BK = 32); 2: bf16x3 split kernel (BK = 32)
+  int glds;  // 1: LDS-DMA kernel (BK = 32); 2: bf16x3 split kernel (BK = 32); 3: halo-staged 3x3 kernel (conv_halo.hip)
   int bm, bn, tiles_m, tiles_n, splitk, cps, nchunks;
 };
 
@@ -108,6 +116,15 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     pick = 4;
     pl.glds = 0;
   }
+  // 3x3 / stride 1 / pad 1 on small images (the mask head's 14x14 ROI tiles): input halo staged once per channel chunk.
+  // Default in fp32 arithmetic once the 64x64 tiles fill the chip (no split-K form); force_tile 63 / 62 selects it in tests.
+  const bool halo_ok = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->tap4 && d->levels <= 0 && d->W + 1 <= 16 &&
+                       d->out_mode == 0 && !d->in_relu && d->force_splitk <= 1;
+  if (halo_ok && ((fbk == 6 && (ft == 3 || ft == 2)) ||
+                  (d->force_tile == 0 && pl.glds == 0 && halo_default() && (long)((M + 63) / 64) * ((d->Cout + 63) / 64) >= 256))) {
+    pl.glds = 3;
+    pick = (fbk == 6 && ft == 2) ? 1 : 2;
+  }
   pl.bk = (pl.glds || d->out_mode == 2) ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
   const int nchunks = d->Kpad / pl.bk;
   (void)nchunks32;
@@ -119,7 +136,7 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   pl.tiles_n = (d->Cout + pl.bn - 1) / pl.bn;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = 1;
-  if (d->out_mode == 2) {
+  if (d->out_mode == 2 || pl.glds == 3) {
     splitk = 1;
   } else if (d->force_splitk > 0) {
     splitk = d->force_splitk;
@@ -250,7 +267,8 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     if (!d->workspace || d->workspace_bytes < need) return EOD_ERR_CAPACITY;
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
-  if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
+  if (pl.glds == 3) launch_conv_halo(a, pl.tile, grid, s);
+  else if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
   else if (pl.glds == 1) launch_conv_glds(a, pl.tile, grid, s);
   else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s);
   if (pl.splitk > 1) {

@@ -3,8 +3,7 @@
 //   y[m][n] = act( (sum_k A[m][k] * Wt[n][k] + bias[n]) * out_scale + res[m][n] )
 //
 // A[m][k] is the im2col view of the NHWC input (m = (img, oy, ox), k = (ky, kx, c), c fastest), Wt is [Cout][Kpad].  The kernels
-// live in conv_fp32.hip (fp32 MFMA, default), conv_bf16x3.hip (opt-in split-bf16 arithmetic) and conv_glds.hip (LDS-DMA
-// staging experiment); this file picks one, sizes the grid and, for small problems, splits K into fp32 slabs that
+// live in conv_fp32.hip (fp32 MFMA, default) and conv_bf16x3.hip (opt-in split-bf16 arithmetic); this file picks one, sizes the grid and, for small problems, splits K into fp32 slabs that
 // conv_splitk_reduce_kernel sums in a fixed order before the fused epilogue (deterministic, no atomics).
 #include "conv_common.h"
 #include "../../include/eod_hip.h"
@@ -66,14 +65,6 @@ inline int default_bk() {
   return v;
 }
 
-inline bool halo_default() {
-  static const bool v = [] {
-    const char* e = getenv("EOD_CONV_HALO");      // EOD_CONV_HALO=0: keep the classic kernel on the mask convs (A/B measurements)
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
-
 // Process-wide arithmetic mode of eod_conv2d (eod_set_conv_math / EOD_CONV_MATH): 0 fp32 MFMA, 1 bf16x3 split.
 std::atomic<int>& math_mode() {
   static std::atomic<int> v([] {
@@ -86,7 +77,7 @@ std::atomic<int>& math_mode() {
 struct Plan {
   int tile;  // 1=128x128 2=128x64 3=64x64
   int bk;    // K chunk staged per barrier pair: 32 or 64
-  int glds;  // 1: LDS-DMA kernel (BK = 32); 2: bf16x3 split kernel (BK = 32); 3: halo-staged 3x3 kernel (conv_halo.hip)
+  int glds;  // 2: bf16x3 split kernel (BK = 32); 0: fp32 MFMA kernel
   int bm, bn, tiles_m, tiles_n, splitk, cps, nchunks;
 };
 
@@ -103,7 +94,7 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   else if (ft == 4 && fbk == 5 && !d->tap4 && !d->in_relu) pick = 3;
   else if (M >= 32768 && big_tile_env() >= 1 && big_tile_env() <= 3) pick = big_tile_env() - 1;   // experiment knob
   const bool bk64_ok = !d->tap4 && d->Cin % 64 == 0 && d->Kpad % 64 == 0;
-  pl.glds = (fbk == 4 && !d->tap4) ? 1 : ((fbk == 5 && !d->tap4 && !d->in_relu) ? 2 : 0);
+  pl.glds = (fbk == 5 && !d->tap4 && !d->in_relu) ? 2 : 0;
   if (d->force_tile == 0 && math_mode().load(std::memory_order_relaxed) == EOD_MATH_BF16X3 && !d->tap4 && !d->in_relu) {
     pl.glds = 2;
     const long t128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
@@ -116,15 +107,6 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     pick = 4;
     pl.glds = 0;
   }
-  // 3x3 / stride 1 / pad 1 on small images (the mask head's 14x14 ROI tiles): input halo staged once per channel chunk.
-  // Default in fp32 arithmetic once the 64x64 tiles fill the chip (no split-K form); force_tile 63 / 62 selects it in tests.
-  const bool halo_ok = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->tap4 && d->levels <= 0 && d->W + 1 <= 16 &&
-                       d->out_mode == 0 && !d->in_relu && d->force_splitk <= 1;
-  if (halo_ok && ((fbk == 6 && (ft == 3 || ft == 2)) ||
-                  (d->force_tile == 0 && pl.glds == 0 && halo_default() && (long)((M + 63) / 64) * ((d->Cout + 63) / 64) >= 256))) {
-    pl.glds = 3;
-    pick = (fbk == 6 && ft == 2) ? 1 : 2;
-  }
   pl.bk = (pl.glds || d->out_mode == 2) ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
   const int nchunks = d->Kpad / pl.bk;
   (void)nchunks32;
@@ -136,7 +118,7 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   pl.tiles_n = (d->Cout + pl.bn - 1) / pl.bn;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = 1;
-  if (d->out_mode == 2 || pl.glds == 3) {
+  if (d->out_mode == 2) {
     splitk = 1;
   } else if (d->force_splitk > 0) {
     splitk = d->force_splitk;
@@ -267,9 +249,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     if (!d->workspace || d->workspace_bytes < need) return EOD_ERR_CAPACITY;
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
-  if (pl.glds == 3) launch_conv_halo(a, pl.tile, grid, s);
-  else if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
-  else if (pl.glds == 1) launch_conv_glds(a, pl.tile, grid, s);
+  if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
   else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s);
   if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;

@@ -60,7 +60,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2), (13, 1), (22, 2), (41, 1), (42, 1), (43, 1), (43, 3), (51, 1), (52, 1), (53, 1), (53, 3), (54, 1), (54, 2)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 1), (2, 1), (3, 1), (3, 3), (1, 2), (13, 1), (22, 2), (51, 1), (52, 1), (53, 1), (53, 3), (54, 1), (54, 2)])
 def test_conv_matches_f_conv2d(dev, case, tile, splitk):
     from embodied_object_detection_amd import ops
     N, H, W, Cin, Cout, k, stride, pad = case
@@ -71,36 +71,6 @@ def test_conv_matches_f_conv2d(dev, case, tile, splitk):
     conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
     y = conv(nhwc(x).to(dev), N, H, W, force_tile=tile, force_splitk=splitk)
     close(nchw(y), ref)
-
-
-@pytest.mark.parametrize("tile", [63, 62])
-@pytest.mark.parametrize("case", [(9, 14, 14, 256, 256), (5, 7, 9, 64, 96), (3, 15, 15, 96, 64), (1, 4, 3, 32, 32)])
-def test_conv_halo_kernel_matches_f_conv2d(dev, case, tile):
-    """conv_halo.hip (3x3 / s1 / p1 on small images, input halo staged once per channel chunk): every image of the batch against
-    F.conv2d -- the slab of a tile holds rows of the neighbouring images, which the per-lane tap mask must keep out -- with a
-    device-side row count (only `count` images are valid; the rest of the buffer is NaN and must neither be read into a stored
-    result nor written)."""
-    from embodied_object_detection_amd import ops
-    N, H, W, Cin, Cout = case
-    x = rnd(N, Cin, H, W, seed=71)
-    w = rnd(Cout, Cin, 3, 3, seed=72, scale=(1.0 / (Cin * 9)) ** 0.5)
-    b = rnd(Cout, seed=73)
-    conv = ops.Conv(w, b, stride=1, pad=1, device=dev)
-    ref = F.relu(F.conv2d(x, w, b, padding=1))
-    y = conv(nhwc(x).to(dev), N, H, W, relu=True, force_tile=tile, force_splitk=1)
-    close(nchw(y), ref)
-    # dynamic count: cap N + 3 images, NaN beyond the count
-    cap = N + 3
-    xd = torch.full((cap, H, W, Cin), float("nan"), device=dev)
-    xd[:N] = nhwc(x).to(dev)
-    out = torch.full((cap, H, W, Cout), -7.0, device=dev)
-    cnt = torch.tensor([N], dtype=torch.int32, device=dev)
-    conv(xd, cap, H, W, relu=True, m_count=cnt, m_unit=H * W, out=out, force_tile=tile, force_splitk=1)
-    close(nchw(out[:N]), ref)
-    assert bool((out[N:] == -7.0).all()), "rows beyond the device-side count must not be written"
-    # and the classic kernel agrees to fp32 summation-order noise (K is walked in a different order)
-    y0 = conv(nhwc(x).to(dev), N, H, W, relu=True, force_tile=13, force_splitk=1)
-    close(y, y0, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("case", [(8, 14, 14, 256, 256, 3, 1), (1, 20, 20, 2048, 256, 1, 0), (64, 1, 1, 12544, 128, 1, 0)])
@@ -749,7 +719,7 @@ def test_semmap_labels_match_oracle(dev):
     assert (got == -1).sum().item() > 0 and (got >= 0).sum().item() > 0
 
 
-@pytest.mark.parametrize("cout,splitk,tile", [(256, 0, 0), (5, 0, 0), (64, 3, 0), (256, 1, 43), (64, 2, 42), (256, 1, 53), (64, 2, 52), (256, 1, 54)])
+@pytest.mark.parametrize("cout,splitk,tile", [(256, 0, 0), (5, 0, 0), (64, 3, 0), (256, 1, 53), (64, 2, 52), (256, 1, 54)])
 def test_conv_pyramid_mode_matches_per_level_conv(dev, cout, splitk, tile):
     """One launch over the 5 FPN levels with shared weights == five per-level 'same' convolutions."""
     from embodied_object_detection_amd import ops

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p) {
 
   const int cchunks = p.Cin >> 5;
   const int nsteps = cchunks * 9;
-  f32x4 ar[AP], br[BR];
+  f32x4 ar[AP], br[2][BR];     // weights are fetched TWO steps ahead (two register sets): ~2 x 1 024 MFMA cycles to cover the L2 latency
 
   auto load_slab = [&](int cc) {
 #pragma unroll
@@ -115,24 +115,27 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(As + buf * (SLAB + 1) * LS + (lr + 32 * i) * LS + 4 * lq) = ar[i];
   };
-  auto load_w = [&](int cc, int tap) {
-    const int k0 = tap * p.Cin + cc * 32;
+  auto load_w = [&](int set, int step) {
+    const int c = step / 9, tp = step - 9 * c;
+    const int k0 = tp * p.Cin + c * 32;
 #pragma unroll
-    for (int j = 0; j < BR; ++j) br[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], k0 * 4, 0));
+    for (int j = 0; j < BR; ++j) br[set][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], k0 * 4, 0));
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int set, int buf) {
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + buf * BN * LS + (lr + 32 * j) * LS + 4 * lq) = br[j];
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + buf * BN * LS + (lr + 32 * j) * LS + 4 * lq) = br[set][j];
   };
 
-  // prologue: slab 0 and weight chunk (0, tap 0)
+  // prologue: slab 0 and weight chunk of step 0 into LDS, weight chunk of step 1 into registers
   load_slab(0);
   load_w(0, 0);
   store_slab(0);
-  store_w(0);
+  store_w(0, 0);
+  if (nsteps > 1) load_w(1, 1);
   __syncthreads();
 
   int cc = 0, tap = 0;
+#pragma unroll 2
   for (int step = 0; step < nsteps; ++step) {
     // next step's coordinates
     int ntap = tap + 1, ncc = cc;
@@ -141,9 +144,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p) {
       ++ncc;
     }
     const bool has_next = step + 1 < nsteps;
-    const bool next_slab = has_next && tap == 0 && cc + 1 < cchunks;   // the slab of c-chunk cc+1 is fetched during tap 0 of cc ...
-    if (has_next) load_w(ncc, ntap);
-    if (next_slab) load_slab(cc + 1);
+    // the slab of c-chunk cc+1 is fetched during tap 0 of cc and written to the other slab buffer after tap 2 (that buffer was last
+    // read during c-chunk cc-1)
+    const bool slab_load = tap == 0 && cc + 1 < cchunks;
+    const bool slab_store = tap == 2 && cc + 1 < cchunks;
+    if (step + 2 < nsteps) load_w(step & 1, step + 2);      // register set (step & 1) was stored to LDS at the end of step - 1
+    if (slab_load) load_slab(cc + 1);
 
     // ---- MFMAs of this step out of slab buffer cc & 1 and weight buffer step & 1 ----
     const float* a_buf = As + (cc & 1) * (SLAB + 1) * LS + frag_k;
@@ -174,9 +180,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p) {
             else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
     }
-    // ---- ... and written to the OTHER slab buffer (last read during c-chunk cc-1, i.e. before the previous barrier) ----
-    if (has_next) store_w((step + 1) & 1);
-    if (next_slab) store_slab((cc + 1) & 1);
+    if (has_next) store_w((step + 1) & 1, (step + 1) & 1);   // the chunk of step + 1 was loaded during step - 1 into set (step + 1) & 1
+    if (slab_store) store_slab((cc + 1) & 1);
     __syncthreads();
     tap = ntap;
     cc = ncc;

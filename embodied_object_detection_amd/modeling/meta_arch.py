@@ -94,6 +94,16 @@ class CustomRCNNRecurrent:
         self._prefetched = None      # (image object of the frame, padded H, W)
         self._pyramid = 0            # which of the two FPN buffer sets the current frame uses
         self.overlap_memory_write = True    # also the memory selection + write-back, beside the detection mask pass
+        # Cross-frame pipelining inside `forward([episode])`: nothing of frame t+1 depends on frame t's DETECTION masks (the
+        # memory write needs the proposal masks only), so the detection mask pass + post-processing + paste of frame t run on
+        # their own low-priority stream underneath frame t+1's memory read, tower, proposal decoding and box cascade (short
+        # latency-bound chains that leave most of the chip idle).  Three pyramid sets and two detection-list sets make the
+        # overlap hazard free; results are bitwise those of the in-order schedule.
+        self.pipeline_detection_pass = True
+        self._det_stream = None
+        self._ev_det = [None, None]          # per result set: detection pass + paste finished
+        self._pyr_reader = {}                # pyramid set -> event of the last detection pass that read it
+        self._frame_no = 0
 
         num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         if state_dict is None:
@@ -198,7 +208,7 @@ class CustomRCNNRecurrent:
                 count=torch.zeros((1,), dtype=torch.int32, device=dev),
                 masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev),
                 count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
-                ready=torch.cuda.Event()) for _ in range(2)]
+                ready=torch.cuda.Event(), err_ready=torch.cuda.Event()) for _ in range(2)]
             self._post_slot = 0
         self._post = self._posts[self._post_slot]
 
@@ -218,7 +228,9 @@ class CustomRCNNRecurrent:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
                 nxt = input_seq[i + 1] if i + 1 < len(input_seq) else None
-                self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt)
+                last = nxt is None and input_seq is batched_inputs[-1]
+                self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
+                                     trailing_detection_pass=not last)
                 ticket = self._post_ticket()
                 if pending is not None:
                     batch_output.append({"instances": self._materialize(pending)})
@@ -232,9 +244,22 @@ class CustomRCNNRecurrent:
     def _post_ticket(self):
         """Async read-back of the frame's detection count into pinned host memory + an event; flips the result set."""
         P = self._post
-        P["count_host"].copy_(P["count"], non_blocking=True)
+        cur = torch.cuda.current_stream(self.device)
         P["err_host"].copy_(self._err, non_blocking=True)
-        P["ready"].record(torch.cuda.current_stream(self.device))
+        k = self._post_slot
+        if self.overlap_branches and self.pipeline_detection_pass and self._det_stream is not None and self._ev_det[k] is not None:
+            # the detection pass of this frame may still be running on its own stream: the count is copied there, and the ticket's
+            # event covers both streams
+            ds = self._det_stream
+            ds.wait_event(self._ev_det[k])
+            P["err_ready"].record(cur)
+            ds.wait_event(P["err_ready"])
+            with torch.cuda.stream(ds):
+                P["count_host"].copy_(P["count"], non_blocking=True)
+                P["ready"].record(ds)
+        else:
+            P["count_host"].copy_(P["count"], non_blocking=True)
+            P["ready"].record(cur)
         self._post_slot ^= 1
         return P
 
@@ -267,17 +292,22 @@ class CustomRCNNRecurrent:
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
         ts.wait_event(after)
+        nxt = (self._pyramid + 1) % 3
+        if nxt in self._pyr_reader:
+            ts.wait_event(self._pyr_reader[nxt])      # a trailing detection pass may still read that set
         with torch.cuda.stream(ts):
             image = self._device_image(frame)
             x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
-            self.backbone.top_down(self.backbone.bottom_up.forward(x4, Hp, Wp), Hp, Wp, self._pyramid ^ 1)
+            self.backbone.top_down(self.backbone.bottom_up.forward(x4, Hp, Wp), Hp, Wp, nxt)
             self._ev_trunk.record(ts)
         self._prefetched = (frame["image"], Hp, Wp)
 
     def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
-                        next_frame: Optional[dict] = None):
+                        next_frame: Optional[dict] = None, trailing_detection_pass: bool = False):
         """One frame: `inference` (custom_rcnn.py:548-582) + `update_implicit_memory` (681-760).  `next_frame` (optional) is the
-        frame the caller will pass next: its memory-independent bottom-up pass is started early."""
+        frame the caller will pass next: its memory-independent bottom-up pass is started early.  `trailing_detection_pass`
+        (set by `forward` for every frame but the last of a call): do not join the detection-pass stream at the end of the frame;
+        the caller reads the results through `_post_ticket` / `_materialize` only."""
         H, W = int(frame["image"].shape[-2]), int(frame["image"].shape[-1])
         if H % 32 or W % 32:
             raise ValueError("H and W must be multiples of 32 (proj_indices is not padded: SURVEY §8 notation)")
@@ -299,8 +329,11 @@ class CustomRCNNRecurrent:
             # whatever was started ahead (used or not) must be finished before this frame touches either pyramid set
             torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
         hit = pre is not None and pre[0] is frame["image"]
-        if hit:
-            self._pyramid ^= 1          # the look-ahead wrote P3..P5 (memory-independent half) into the other buffer set
+        # every frame moves to the next of three pyramid sets (the look-ahead wrote P3..P5 of a hit into exactly that one); a
+        # trailing detection pass of the frame that last used the set must be over before a miss recomputes into it
+        self._pyramid = (self._pyramid + 1) % 3
+        if not hit and self._pyramid in self._pyr_reader:
+            torch.cuda.current_stream(self.device).wait_event(self._pyr_reader[self._pyramid])
         look_ahead = next_frame is not None and self.prefetch_trunk and self.overlap_branches
         if look_ahead and self.lookahead_at_start:
             # it may start NOW, beside this frame's memory fusion, tower and proposal decoding (a short latency-bound chain
@@ -336,8 +369,11 @@ class CustomRCNNRecurrent:
                 self._ev_pm.record(main)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
-                det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward_box(
-                    views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+                k = self._post_slot
+                if self._ev_det[k] is not None:
+                    self._side_stream.wait_event(self._ev_det[k])     # the detection list set k is still read by frame t-2's pass
+                det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k)
+                det_boxes, det_scores, det_classes, det_rows, det_count = det
                 self._ev_box.record(self._side_stream)
                 if lazy:
                     # select the memory instances first, then run the mask head only on those proposals (same results: the
@@ -345,8 +381,12 @@ class CustomRCNNRecurrent:
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
                     ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
                     self._ev_sel.record(self._side_stream)
-            main.wait_event(self._ev_box)
-            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            pipelined = self.pipeline_detection_pass
+            if pipelined:
+                self._enqueue_detection_pass(views, shapes, det, (H, W), frame)
+            else:
+                main.wait_event(self._ev_box)
+                self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
             if lazy:
                 main.wait_event(self._ev_sel)
                 prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
@@ -364,6 +404,7 @@ class CustomRCNNRecurrent:
                     self._ev_mem.record(self._side_stream)
                 mem_done = True
         else:
+            pipelined = False
             det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
                 views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
             if self.lazy_proposal_masks and update_mem:
@@ -377,14 +418,9 @@ class CustomRCNNRecurrent:
                 prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
 
         # detector_postprocess (custom_rcnn.py:579-580)
-        out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
-        if (out_h, out_w) != (H, W):
-            raise NotImplementedError("output size != input size is not used on this path (train_mp3d.py:487-490)")
         P = self._post
-        ops.detector_postprocess(det_boxes, det_scores, det_classes, det_count, self.roi_heads.topk, out_w / W, out_h / H,
-                                 float(out_w), float(out_h), P["boxes"], P["scores"], P["classes"], P["src"], P["count"])
-        ops.paste_masks(self.roi_heads.det_masks, P["boxes"], P["src"], P["count"], self.roi_heads.topk, out_h, out_w,
-                        self.mask_threshold, P["masks"])
+        if not pipelined:
+            self._postprocess_and_paste(det_boxes, det_scores, det_classes, det_count, (H, W), frame, P)
 
         # memory update (custom_rcnn.py:515)
         if mem_done:
@@ -392,11 +428,49 @@ class CustomRCNNRecurrent:
         elif update_mem:
             self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
         self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
+        if pipelined and not trailing_detection_pass:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_det[self._post_slot])     # in-order callers see a finished frame
         if self.stats_log is not None:      # bench.py: device-side copies of the frame's counters, read after the timed region
-            self.stats_log.append((prop_count.clone(), P["count"].clone(), self._writer.k_out.clone(), self._uniq_count.clone()))
+            cnt = P["count"]
+            if pipelined and trailing_detection_pass:
+                with torch.cuda.stream(self._det_stream):
+                    cnt = P["count"].clone()
+            self.stats_log.append((prop_count.clone(), cnt.clone(), self._writer.k_out.clone(), self._uniq_count.clone()))
         if not materialize:
             return None
         return {"instances": self._materialize(self._post_ticket())}
+
+    def _postprocess_and_paste(self, det_boxes, det_scores, det_classes, det_count, image_hw, frame, P):
+        H, W = image_hw
+        out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
+        if (out_h, out_w) != (H, W):
+            raise NotImplementedError("output size != input size is not used on this path (train_mp3d.py:487-490)")
+        ops.detector_postprocess(det_boxes, det_scores, det_classes, det_count, self.roi_heads.topk, out_w / W, out_h / H,
+                                 float(out_w), float(out_h), P["boxes"], P["scores"], P["classes"], P["src"], P["count"])
+        ops.paste_masks(self.roi_heads.det_masks, P["boxes"], P["src"], P["count"], self.roi_heads.topk, out_h, out_w,
+                        self.mask_threshold, P["masks"])
+
+    def _enqueue_detection_pass(self, views, shapes, det, image_hw, frame):
+        """`forward_with_given_boxes` (detic_roi_heads.py:257) + `detector_postprocess` + paste (custom_rcnn.py:579-580) of this
+        frame on the detection stream (lowest priority: its GEMMs fill whatever the latency-bound chains of the frame -- and of
+        the next frame -- leave idle)."""
+        if self._det_stream is None:
+            least = 0
+            try:
+                least = int(torch.cuda.Stream.priority_range()[0])
+            except Exception:
+                pass
+            self._det_stream = torch.cuda.Stream(device=self.device, priority=least)
+            self._ev_det = [torch.cuda.Event(), torch.cuda.Event()]
+        ds = self._det_stream
+        det_boxes, det_scores, det_classes, det_rows, det_count = det
+        k = self._post_slot
+        ds.wait_event(self._ev_box)
+        with torch.cuda.stream(ds):
+            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            self._postprocess_and_paste(det_boxes, det_scores, det_classes, det_count, image_hw, frame, self._post)
+            self._ev_det[k].record(ds)
+        self._pyr_reader[self._pyramid] = self._ev_det[k]
 
     def select_memory_instances(self, prop_boxes, prop_scores, prop_count, image_hw):
         """`inference_with_proposals` up to the NMS (custom_rcnn.py:825-875): CLIP re-score of the proposals, threshold

@@ -88,11 +88,14 @@ class DeticCascadeROIHeads:
         # deconv + ReLU + predictor + sigmoid in ONE launch (the [rois,28,28,256] activation never goes to memory); False keeps
         # the two-launch form (used by the tests as the cross-check)
         self.fuse_mask_tail = True
-        self.selector = ops.DetectionSelector(R, self.C1, self.topk, device)
+        # two detection-list sets: the detection mask pass of frame t may still read set t % 2 while the cascade of frame t+1 writes
+        # the other one (meta_arch.py, pipeline_detection_pass)
+        self.selectors = [ops.DetectionSelector(R, self.C1, self.topk, device) for _ in range(2)]
+        self.selector = self.selectors[0]
 
     # ---- cascade box heads ------------------------------------------------------------------------
     def forward_box(self, views: List[torch.Tensor], shapes, prop_boxes: torch.Tensor, prop_scores: torch.Tensor, count: torch.Tensor,
-                    image_hw: Tuple[int, int]):
+                    image_hw: Tuple[int, int], sel: int = 0):
         h3, w3 = shapes[0]
         H, W = image_hw
         R = self.R
@@ -112,7 +115,7 @@ class DeticCascadeROIHeads:
             ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
             boxes = self.boxes[k + 1]
         ops.cascade_scores(self.prob, prop_scores, count, R, self.C1, 1.0 / self.num_stages)
-        return self.selector(boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
+        return self.selectors[sel](boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
 
     # ---- mask head ----------------------------------------------------------------------------------
     def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor,
@@ -156,5 +159,5 @@ class DeticCascadeROIHeads:
         `rows` / `rows_count`: lazy variant -- only the proposals the memory update will read (custom_rcnn.py:875-880) get a
         mask; every other proposal's mask is dead in the reference (never read after `inference_with_proposals`)."""
         if rows is not None:
-            return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows)
+            return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows, bufs=bufs)
         return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks, bufs=bufs)

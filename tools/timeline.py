@@ -9,8 +9,8 @@ rows = c.execute("select kernel_id, queue_id, stream_id, start, end from rocpd_k
 def nm(k):
     n = names.get(k, str(k)).replace('(anonymous namespace)::', '').replace('eodconv::', '')
     return n.split('(')[0][-48:]
-norm = [i for i, r in enumerate(rows) if 'normalize_f16' in nm(r[0])]
-i0, i1 = norm[-5], norm[-4]
+norm = [i for i, r in enumerate(rows) if 'normalize_dirty' in nm(r[0])]
+i0, i1 = norm[25], norm[26]
 t0, t1 = rows[i0][3], rows[i1][3]
 print('frame span ms', (t1 - t0) / 1e6)
 fr = [r for r in rows if t0 <= r[3] < t1]

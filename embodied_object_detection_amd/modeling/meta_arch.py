@@ -29,13 +29,15 @@ from ..structures import Boxes, Instances
 # few hardware queues, and two of a model's streams landing on the same queue would silently serialise them (measured: 127 vs
 # 104 frames/s for otherwise identical runs when each model created its own).  Models of one process run from one host thread,
 # so sharing the streams only adds the ordering that already exists.
-_SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+_SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, ...]] = {}
 
 
-def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, torch.cuda.Stream]:
+def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
+    """(side, look-ahead, main chain): three high-priority streams.  The device offers two priority levels (0 and -1); the
+    detection pass that trails under the next frame runs at 0, everything latency-bound at -1."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _SCHED_STREAMS:
-        _SCHED_STREAMS[idx] = (torch.cuda.Stream(device=device, priority=-1), torch.cuda.Stream(device=device, priority=-1))
+        _SCHED_STREAMS[idx] = tuple(torch.cuda.Stream(device=device, priority=-1) for _ in range(3))
     return _SCHED_STREAMS[idx]
 
 
@@ -101,6 +103,7 @@ class CustomRCNNRecurrent:
         # overlap hazard free; results are bitwise those of the in-order schedule.
         self.pipeline_detection_pass = True
         self._det_stream = None
+        self._ev_call = None
         self._ev_det = [None, None]          # per result set: detection pass + paste finished
         self._pyr_reader = {}                # pyramid set -> event of the last detection pass that read it
         self._frame_no = 0
@@ -217,6 +220,25 @@ class CustomRCNNRecurrent:
         """Sequential pass over sequences and frames; the memory persists across calls (custom_rcnn.py:435-546)."""
         if self.training:
             raise NotImplementedError("training forward is out of scope for the hot path (SURVEY §8f rank 4)")
+        if self.overlap_branches and self.pipeline_detection_pass:
+            # The frame's own chain (memory read -> tower -> proposals -> proposal masks -> memory write) moves to a HIGH priority
+            # stream for the duration of the call: the previous frame's detection pass trails at normal priority, and at equal
+            # priority the short chain would queue behind the GEMMs' thousands of workgroups.  The caller's stream is joined on
+            # both sides, so the call keeps its in-order meaning.
+            caller = torch.cuda.current_stream(self.device)
+            ms = _sched_streams(self.device)[2]
+            if self._ev_call is None:
+                self._ev_call = (torch.cuda.Event(), torch.cuda.Event())
+            self._ev_call[0].record(caller)
+            ms.wait_event(self._ev_call[0])
+            with torch.cuda.stream(ms):
+                out = self._forward_frames(batched_inputs)
+                self._ev_call[1].record(ms)
+            caller.wait_event(self._ev_call[1])
+            return out
+        return self._forward_frames(batched_inputs)
+
+    def _forward_frames(self, batched_inputs: List[List[dict]]):
         batch_output = []
         pending = None            # ticket of the previous frame: its Instances are built after this frame has been enqueued
         for input_seq in batched_inputs:

@@ -33,11 +33,11 @@ _SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, ...]] = {}
 
 
 def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
-    """(side, look-ahead, main chain): three high-priority streams.  The device offers two priority levels (0 and -1); the
+    """(side, look-ahead, main chain, memory selection + write): four high-priority streams.  The device offers two priority levels (0 and -1); the
     detection pass that trails under the next frame runs at 0, everything latency-bound at -1."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _SCHED_STREAMS:
-        _SCHED_STREAMS[idx] = tuple(torch.cuda.Stream(device=device, priority=-1) for _ in range(3))
+        _SCHED_STREAMS[idx] = tuple(torch.cuda.Stream(device=device, priority=-1) for _ in range(4))
     return _SCHED_STREAMS[idx]
 
 
@@ -84,7 +84,7 @@ class CustomRCNNRecurrent:
         # `overlap_branches = False` restores one stream.
         self.overlap_branches = True
         self._side_stream = None
-        self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = self._ev_sel = None
+        self._ev_props = self._ev_pm = self._ev_box = self._ev_mem = self._ev_sel = self._ev_s0 = None
         # Look-ahead: the ResNet trunk does not read the memory, so the NEXT frame's bottom-up pass and FPN top-down convs (known from the
         # inner frame list of `forward`, or passed as `next_frame`) are enqueued on a third stream while this frame's mask passes
         # run; they write the other of two pyramid buffer sets.
@@ -378,7 +378,7 @@ class CustomRCNNRecurrent:
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = _sched_streams(self.device)[0]     # high priority: the small launches go first
-                self._ev_props, self._ev_pm, self._ev_box, self._ev_mem, self._ev_sel = (torch.cuda.Event() for _ in range(5))
+                self._ev_props, self._ev_pm, self._ev_box, self._ev_mem, self._ev_sel, self._ev_s0 = (torch.cuda.Event() for _ in range(6))
             self._ev_props.record(main)
             if look_ahead and not self.lookahead_at_start:
                 self._enqueue_trunk(next_frame, self._ev_props)
@@ -394,15 +394,21 @@ class CustomRCNNRecurrent:
                 k = self._post_slot
                 if self._ev_det[k] is not None:
                     self._side_stream.wait_event(self._ev_det[k])     # the detection list set k is still read by frame t-2's pass
-                det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k)
+                det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k,
+                                                 stage0_event=self._ev_s0 if lazy else None)
                 det_boxes, det_scores, det_classes, det_rows, det_count = det
                 self._ev_box.record(self._side_stream)
-                if lazy:
-                    # select the memory instances first, then run the mask head only on those proposals (same results: the
-                    # other proposals' masks are never read, custom_rcnn.py:875-880)
+            mem_stream = self._side_stream
+            if lazy:
+                # The memory selection needs only stage 0 of the cascade (its CLIP-space features, custom_rcnn.py:825-875): it
+                # runs on its own stream beside stages 1-2 and the detection selection; the mask head then runs only on the
+                # proposals it keeps (same results: the other proposals' masks are never read, custom_rcnn.py:875-880).
+                mem_stream = _sched_streams(self.device)[3]
+                mem_stream.wait_event(self._ev_s0)
+                with torch.cuda.stream(mem_stream):
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
                     ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
-                    self._ev_sel.record(self._side_stream)
+                    self._ev_sel.record(mem_stream)
             pipelined = self.pipeline_detection_pass
             if pipelined:
                 self._enqueue_detection_pass(views, shapes, det, (H, W), frame)
@@ -418,12 +424,12 @@ class CustomRCNNRecurrent:
             if update_mem and self.overlap_memory_write:
                 # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
                 # stream beside the detection mask pass; the main stream joins at the end of the frame
-                with torch.cuda.stream(self._side_stream):
+                with torch.cuda.stream(mem_stream):
                     if not lazy:
                         mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-                    self._side_stream.wait_event(self._ev_pm)
+                    mem_stream.wait_event(self._ev_pm)
                     self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
-                    self._ev_mem.record(self._side_stream)
+                    self._ev_mem.record(mem_stream)
                 mem_done = True
         else:
             pipelined = False

@@ -95,7 +95,9 @@ class DeticCascadeROIHeads:
 
     # ---- cascade box heads ------------------------------------------------------------------------
     def forward_box(self, views: List[torch.Tensor], shapes, prop_boxes: torch.Tensor, prop_scores: torch.Tensor, count: torch.Tensor,
-                    image_hw: Tuple[int, int], sel: int = 0):
+                    image_hw: Tuple[int, int], sel: int = 0, stage0_event=None):
+        """`stage0_event` (optional torch.cuda.Event): recorded once stage 0 has produced `feat0` / `featn0` -- all that the memory
+        selection (custom_rcnn.py:825-875) needs from the cascade."""
         h3, w3 = shapes[0]
         H, W = image_hw
         R = self.R
@@ -107,6 +109,8 @@ class DeticCascadeROIHeads:
             feat = self.feat0 if k == 0 else self.feat
             st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
             ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp)
+            if k == 0 and stage0_event is not None:
+                stage0_event.record(torch.cuda.current_stream(self.device))
             st["bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.hb)
             st["bb2"](self.hb, R, 1, 1, m_count=count, m_unit=1, out=self.deltas)
             last = k == self.num_stages - 1

@@ -30,6 +30,10 @@ from ..structures import Boxes, Instances
 # 104 frames/s for otherwise identical runs when each model created its own).  Models of one process run from one host thread,
 # so sharing the streams only adds the ordering that already exists.
 _SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, ...]] = {}
+# Result sets (post-processed detections + pasted masks, detection lists): `forward` hands frame t's Instances out after frame
+# t+2 has been enqueued, so that the host never waits for a detection pass that still trails on the GPU (the host needs ~3.7 ms
+# to enqueue a frame, about as long as the GPU needs to run one).
+RESULT_SETS = 3
 
 
 def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
@@ -104,7 +108,7 @@ class CustomRCNNRecurrent:
         self.pipeline_detection_pass = True
         self._det_stream = None
         self._ev_call = None
-        self._ev_det = [None, None]          # per result set: detection pass + paste finished
+        self._ev_det = [None] * RESULT_SETS   # per result set: detection pass + paste finished
         self._pyr_reader = {}                # pyramid set -> event of the last detection pass that read it
         self._frame_no = 0
 
@@ -200,7 +204,7 @@ class CustomRCNNRecurrent:
             self._writer = ops.MemoryWriter(H, W, n_cells, 100, self.proposal_generator.cap, self.device, mask_thresh=0.5)
             self._writer_key = key
         if self._posts is None or self._posts[0]["hw"] != (H, W):
-            # two result sets: frame t's `Instances` are sliced out of set t % 2 only after frame t+1 has been enqueued
+            # RESULT_SETS result sets: frame t's `Instances` are sliced out of set t % 3 only after frame t+2 has been enqueued
             # (`forward`), so the host's read-back of the detection count never leaves the GPU idle
             D = self.roi_heads.topk
             dev = self.device
@@ -211,7 +215,7 @@ class CustomRCNNRecurrent:
                 count=torch.zeros((1,), dtype=torch.int32, device=dev),
                 masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev),
                 count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
-                ready=torch.cuda.Event(), err_ready=torch.cuda.Event()) for _ in range(2)]
+                ready=torch.cuda.Event(), err_ready=torch.cuda.Event()) for _ in range(RESULT_SETS)]
             self._post_slot = 0
         self._post = self._posts[self._post_slot]
 
@@ -240,7 +244,7 @@ class CustomRCNNRecurrent:
 
     def _forward_frames(self, batched_inputs: List[List[dict]]):
         batch_output = []
-        pending = None            # ticket of the previous frame: its Instances are built after this frame has been enqueued
+        pending = []              # tickets of the last frames: Instances are built RESULT_SETS - 1 frames behind the enqueue
         for input_seq in batched_inputs:
             for i, frame in enumerate(input_seq):
                 n_cells = int(input_seq[0]["memory"].shape[0])
@@ -253,14 +257,13 @@ class CustomRCNNRecurrent:
                 last = nxt is None and input_seq is batched_inputs[-1]
                 self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
                                      trailing_detection_pass=not last)
-                ticket = self._post_ticket()
-                if pending is not None:
-                    batch_output.append({"instances": self._materialize(pending)})
-                pending = ticket
+                pending.append(self._post_ticket())
+                if len(pending) == RESULT_SETS:
+                    batch_output.append({"instances": self._materialize(pending.pop(0))})
                 if self.save_semmap and i == 0:
                     self.save_memory_snapshot(frame["sequence_name"])          # custom_rcnn.py:518-530
-        if pending is not None:
-            batch_output.append({"instances": self._materialize(pending)})
+        for ticket in pending:
+            batch_output.append({"instances": self._materialize(ticket)})
         return batch_output
 
     def _post_ticket(self):
@@ -282,7 +285,7 @@ class CustomRCNNRecurrent:
         else:
             P["count_host"].copy_(P["count"], non_blocking=True)
             P["ready"].record(cur)
-        self._post_slot ^= 1
+        self._post_slot = (self._post_slot + 1) % RESULT_SETS
         return P
 
     def _device_image(self, frame) -> torch.Tensor:
@@ -489,7 +492,7 @@ class CustomRCNNRecurrent:
             except Exception:
                 pass
             self._det_stream = torch.cuda.Stream(device=self.device, priority=least)
-            self._ev_det = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_det = [torch.cuda.Event() for _ in range(RESULT_SETS)]
         ds = self._det_stream
         det_boxes, det_scores, det_classes, det_rows, det_count = det
         k = self._post_slot

@@ -88,9 +88,9 @@ class DeticCascadeROIHeads:
         # deconv + ReLU + predictor + sigmoid in ONE launch (the [rois,28,28,256] activation never goes to memory); False keeps
         # the two-launch form (used by the tests as the cross-check)
         self.fuse_mask_tail = True
-        # two detection-list sets: the detection mask pass of frame t may still read set t % 2 while the cascade of frame t+1 writes
-        # the other one (meta_arch.py, pipeline_detection_pass)
-        self.selectors = [ops.DetectionSelector(R, self.C1, self.topk, device) for _ in range(2)]
+        # three detection-list sets: the detection mask pass of frame t may still read set t % 3 while the cascades of the next
+        # frames write the others (meta_arch.py, pipeline_detection_pass / RESULT_SETS)
+        self.selectors = [ops.DetectionSelector(R, self.C1, self.topk, device) for _ in range(3)]
         self.selector = self.selectors[0]
 
     # ---- cascade box heads ------------------------------------------------------------------------

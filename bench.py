@@ -295,7 +295,13 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        log(f'{what}: {el:.3f} s for {args.steps} frames ({args.steps * world / el:.1f} frames/s), host side {host / args.steps * 1e3:.2f} ms/frame')
+        hp = model.host_profile
+        fr = max(hp["frames"], 1)
+        log(f'{what}: {el:.3f} s for {args.steps} frames ({args.steps * world / el:.1f} frames/s), host side {host / args.steps * 1e3:.2f} ms/frame'
+            f' [forward(): enqueue {hp["enqueue_s"] / fr * 1e3:.2f}, materialise {hp["materialize_s"] / fr * 1e3:.2f} of which waiting '
+            f'{hp["wait_s"] / fr * 1e3:.2f} ms/frame]')
+        for k_ in hp:
+            hp[k_] = 0
         return el
 
     def as_variant(el, note, **extra):

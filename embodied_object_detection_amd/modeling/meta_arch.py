@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import time as _time
+
 import numpy as np
 import torch
 
@@ -154,6 +156,8 @@ class CustomRCNNRecurrent:
         self._post_slot = 0
         self.last_stats: Dict[str, torch.Tensor] = {}
         self.stats_log = None
+        self.trace = None
+        self.host_profile = {"frames": 0, "enqueue_s": 0.0, "materialize_s": 0.0, "wait_s": 0.0}   # host seconds spent in forward()
 
     # detectron2 nn.Module surface used by the drivers
     def eval(self):
@@ -255,11 +259,17 @@ class CustomRCNNRecurrent:
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
                 nxt = input_seq[i + 1] if i + 1 < len(input_seq) else None
                 last = nxt is None and input_seq is batched_inputs[-1]
+                t0 = _time.perf_counter()
                 self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
                                      trailing_detection_pass=not last)
                 pending.append(self._post_ticket())
+                t1 = _time.perf_counter()
                 if len(pending) == RESULT_SETS:
                     batch_output.append({"instances": self._materialize(pending.pop(0))})
+                hp = self.host_profile
+                hp["frames"] += 1
+                hp["enqueue_s"] += t1 - t0
+                hp["materialize_s"] += _time.perf_counter() - t1
                 if self.save_semmap and i == 0:
                     self.save_memory_snapshot(frame["sequence_name"])          # custom_rcnn.py:518-530
         for ticket in pending:
@@ -321,10 +331,12 @@ class CustomRCNNRecurrent:
         if nxt in self._pyr_reader:
             ts.wait_event(self._pyr_reader[nxt])      # a trailing detection pass may still read that set
         with torch.cuda.stream(ts):
+            self._mark("trunk_lookahead_begin", ts)
             image = self._device_image(frame)
             x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
             self.backbone.top_down(self.backbone.bottom_up.forward(x4, Hp, Wp), Hp, Wp, nxt)
             self._ev_trunk.record(ts)
+            self._mark("trunk_lookahead", ts)
         self._prefetched = (frame["image"], Hp, Wp)
 
     def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
@@ -341,6 +353,8 @@ class CustomRCNNRecurrent:
             raise ValueError(f"proj_indices shape {tuple(proj.shape)} != image {(H, W)}")
         n_cells = self.implicit_memory.shape[0]
         self._ensure_frame_buffers(H, W, n_cells)
+        self._frame_no += 1
+        self._mark("start")
 
         # a4 + fp16 cast (create_implicit_memory + preprocess_spatial_memory)
         mem_f16 = None
@@ -383,6 +397,7 @@ class CustomRCNNRecurrent:
                 self._side_stream = _sched_streams(self.device)[0]     # high priority: the small launches go first
                 self._ev_props, self._ev_pm, self._ev_box, self._ev_mem, self._ev_sel, self._ev_s0 = (torch.cuda.Event() for _ in range(6))
             self._ev_props.record(main)
+            self._mark("proposals", main)
             if look_ahead and not self.lookahead_at_start:
                 self._enqueue_trunk(next_frame, self._ev_props)
             lazy = self.lazy_proposal_masks and update_mem
@@ -401,6 +416,7 @@ class CustomRCNNRecurrent:
                                                  stage0_event=self._ev_s0 if lazy else None)
                 det_boxes, det_scores, det_classes, det_rows, det_count = det
                 self._ev_box.record(self._side_stream)
+                self._mark("cascade+det_select", self._side_stream)
             mem_stream = self._side_stream
             if lazy:
                 # The memory selection needs only stage 0 of the cascade (its CLIP-space features, custom_rcnn.py:825-875): it
@@ -412,6 +428,7 @@ class CustomRCNNRecurrent:
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
                     ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
                     self._ev_sel.record(mem_stream)
+                    self._mark("mem_select", mem_stream)
             pipelined = self.pipeline_detection_pass
             if pipelined:
                 self._enqueue_detection_pass(views, shapes, det, (H, W), frame)
@@ -424,6 +441,7 @@ class CustomRCNNRecurrent:
                                                                 rows_count=self._uniq_count,
                                                                 bufs=self.roi_heads.proposal_pass_buffers())
                 self._ev_pm.record(main)
+                self._mark("prop_masks", main)
             if update_mem and self.overlap_memory_write:
                 # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
                 # stream beside the detection mask pass; the main stream joins at the end of the frame
@@ -433,6 +451,7 @@ class CustomRCNNRecurrent:
                     mem_stream.wait_event(self._ev_pm)
                     self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
                     self._ev_mem.record(mem_stream)
+                    self._mark("mem_write", mem_stream)
                 mem_done = True
         else:
             pipelined = False
@@ -471,6 +490,15 @@ class CustomRCNNRecurrent:
             return None
         return {"instances": self._materialize(self._post_ticket())}
 
+    def _mark(self, name: str, stream=None):
+        """Diagnostics (`model.trace = []`): a timing event on `stream` (default: current) at a named point of the frame's schedule;
+        tools/frame_schedule.py turns the list into a per-frame timeline without a profiler in the way."""
+        if self.trace is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        self.trace.append((self._frame_no, name, ev))
+
     def _postprocess_and_paste(self, det_boxes, det_scores, det_classes, det_count, image_hw, frame, P):
         H, W = image_hw
         out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
@@ -498,9 +526,11 @@ class CustomRCNNRecurrent:
         k = self._post_slot
         ds.wait_event(self._ev_box)
         with torch.cuda.stream(ds):
+            self._mark("det_pass_begin", ds)
             self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
             self._postprocess_and_paste(det_boxes, det_scores, det_classes, det_count, image_hw, frame, self._post)
             self._ev_det[k].record(ds)
+            self._mark("det_pass", ds)
         self._pyr_reader[self._pyramid] = self._ev_det[k]
 
     def select_memory_instances(self, prop_boxes, prop_scores, prop_count, image_hw):
@@ -527,7 +557,9 @@ class CustomRCNNRecurrent:
     def _materialize(self, P) -> Instances:
         """Slice a result set by its detection count (the frame's only host wait: on the event recorded after the count's
         async copy).  The paste kernel writes 0/1 bytes, so the masks are handed out as a bool view's copy."""
+        t0 = _time.perf_counter()
         P["ready"].synchronize()
+        self.host_profile["wait_s"] += _time.perf_counter() - t0
         flags = int(P["err_host"][0])
         if flags:
             self._err.zero_()

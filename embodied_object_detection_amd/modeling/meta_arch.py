@@ -108,6 +108,7 @@ class CustomRCNNRecurrent:
         # latency-bound chains that leave most of the chip idle).  Three pyramid sets and two detection-list sets make the
         # overlap hazard free; results are bitwise those of the in-order schedule.
         self.pipeline_detection_pass = True
+        self.early_memory_selection = True   # memory selection on its own stream right after cascade stage 0 (False: after the cascade)
         self._det_stream = None
         self._ev_call = None
         self._ev_det = [None] * RESULT_SETS   # per result set: detection pass + paste finished
@@ -418,7 +419,13 @@ class CustomRCNNRecurrent:
                 self._ev_box.record(self._side_stream)
                 self._mark("cascade+det_select", self._side_stream)
             mem_stream = self._side_stream
-            if lazy:
+            if lazy and not self.early_memory_selection:
+                with torch.cuda.stream(self._side_stream):
+                    mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                    ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
+                    self._ev_sel.record(self._side_stream)
+                    self._mark("mem_select", self._side_stream)
+            elif lazy:
                 # The memory selection needs only stage 0 of the cascade (its CLIP-space features, custom_rcnn.py:825-875): it
                 # runs on its own stream beside stages 1-2 and the detection selection; the mask head then runs only on the
                 # proposals it keeps (same results: the other proposals' masks are never read, custom_rcnn.py:875-880).

@@ -47,29 +47,6 @@ def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
     return _SCHED_STREAMS[idx]
 
 
-def _masked_stream(device: torch.device, every: int) -> torch.cuda.Stream:
-    """Normal-priority stream whose kernels may not run on every `every`-th CU (1/every of the chip stays free for the other
-    streams).  Falls back to a plain stream when the HIP runtime refuses."""
-    if every and every > 1:
-        try:
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-            words = (n_cu + 31) // 32
-            mask = (ctypes.c_uint32 * words)()
-            for cu in range(n_cu):
-                if cu % every != every - 1:
-                    mask[cu // 32] |= 1 << (cu % 32)
-            handle = ctypes.c_void_p()
-            with torch.cuda.device(device):
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
-            if rc == 0 and handle.value:
-                return torch.cuda.ExternalStream(handle.value, device=device)
-        except Exception:
-            pass
-    return torch.cuda.Stream(device=device, priority=0)
-
-
 @META_ARCH_REGISTRY.register()
 class CustomRCNNRecurrent:
     def __init__(self, cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -131,11 +108,13 @@ class CustomRCNNRecurrent:
         # latency-bound chains that leave most of the chip idle).  Three pyramid sets and two detection-list sets make the
         # overlap hazard free; results are bitwise those of the in-order schedule.
         self.pipeline_detection_pass = True
-        self.early_memory_selection = True   # memory selection on its own stream right after cascade stage 0 (False: after the cascade)
-        # The detection stream may not use every `det_stream_reserved_cus`-th compute unit (hipExtStreamCreateWithCUMask): the
-        # latency-bound chains of the (next) frame then always find free CUs instead of queueing behind the GEMMs' workgroups
-        # -- the device has only two stream priority levels, and priority acts at workgroup dispatch only.  0 = no reservation.
-        self.det_stream_reserved_cus = 8
+        # Memory selection right after cascade stage 0 on its own stream (it needs only the stage-0 features) instead of after the
+        # cascade.  Measured (tools/frame_schedule.py, same box): True lets the proposal-mask pass and the memory write finish
+        # early, the next frame then starts while the detection pass still runs and its latency-bound chain is slowed 3x by the
+        # resident GEMM workgroups (5.66 ms/frame); False keeps the detection pass inside its frame (5.52 ms/frame).  A CU mask
+        # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
+        # the mask (an fp32 matmul on a half-masked stream takes the same time).
+        self.early_memory_selection = False
         self._det_stream = None
         self._ev_call = None
         self._ev_det = [None] * RESULT_SETS   # per result set: detection pass + paste finished
@@ -548,7 +527,7 @@ class CustomRCNNRecurrent:
         frame on the detection stream (lowest priority: its GEMMs fill whatever the latency-bound chains of the frame -- and of
         the next frame -- leave idle)."""
         if self._det_stream is None:
-            self._det_stream = _masked_stream(self.device, self.det_stream_reserved_cus)
+            self._det_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._ev_det = [torch.cuda.Event() for _ in range(RESULT_SETS)]
         ds = self._det_stream
         det_boxes, det_scores, det_classes, det_rows, det_count = det

@@ -374,6 +374,7 @@ def test_on_disk_episodes_drive_the_model(setup, tmp_path):
     frames, sd = setup["frames"], setup["sd"]
     H, W, n_cells = setup["H"], setup["W"], setup["n_cells"]
     root = str(tmp_path / "ds")
+    decoded = {}
     for d in ("memory_data", "sensor_data", "JPEGImages"):
         os.makedirs(os.path.join(root, d))
     for ep, chunk in enumerate((frames[:2], frames[2:])):              # one scene, two episodes of two frames
@@ -384,8 +385,9 @@ def test_on_disk_episodes_drive_the_model(setup, tmp_path):
             f.write("proj_indices", np.stack([fr["proj_indices"] for fr in chunk]).astype(np.int32))
         recs = []
         for i, fr in enumerate(chunk):
-            fn = f"scene_x_{ep}_{i}.png"                               # lossless, so the decoded pixels equal the synthetic frame
-            Image.fromarray(fr["image"].permute(1, 2, 0).numpy()).save(os.path.join(root, "JPEGImages", fn))
+            fn = f"scene_x_{ep}_{i}.jpg"                               # a real JPEG, as in the reference's JPEGImages/ (lossy)
+            Image.fromarray(fr["image"].permute(1, 2, 0).numpy()).save(os.path.join(root, "JPEGImages", fn), quality=90)
+            decoded[fn] = torch.from_numpy(np.asarray(Image.open(os.path.join(root, "JPEGImages", fn)).convert("RGB")).copy()).permute(2, 0, 1).contiguous()
             recs.append(str({"file_name": fn, "image": "x", "gt_boxes": [[4, 4, 20, 30]], "gt_classes": [3]}))
         with h5io.H5File(os.path.join(root, "sensor_data", name), "w") as f:
             f.write("segmentation_data", np.zeros((len(chunk), H, W), dtype=np.uint8))
@@ -397,8 +399,11 @@ def test_on_disk_episodes_drive_the_model(setup, tmp_path):
                               scene_episode_offset=ds.episode_offsets())
     assert res["frames"] == 4 and [s[0] for s in seen] == [0, 1]
     assert [f["memory_reset"] for s in seen for f in s[1]] == [True, False, False, False]
+    # hand-fed reference: the same frames with the pixels an independent decode of the JPEG files gives
     ref_model = build_model(_cfg(), sd)
-    ref = [ref_model([[f]])[0]["instances"] for f in frames]
+    names = [f"scene_x_{ep}_{i}.jpg" for ep in range(2) for i in range(2)]
+    assert any(not torch.equal(decoded[n], f["image"]) for n, f in zip(names, frames)), "JPEG is lossy: the disk pixels differ from the source"
+    ref = [ref_model([[dict(f, image=decoded[n])]])[0]["instances"] for n, f in zip(names, frames)]
     got = [o["instances"] for s in seen for o in s[2]]
     for a, b in zip(ref, got):
         assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)

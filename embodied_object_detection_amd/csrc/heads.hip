@@ -13,46 +13,51 @@ __device__ __forceinline__ int dyn_rows(const int* count, int cap) {
   return c < cap ? c : cap;
 }
 
-// one wave per row.  feat [R,D] (D = 512 -> 8 per lane).  The normalised row goes through LDS; then lane (c, seg) = (lane / 3,
-// lane % 3) forms class c's dot product over a third of the channels: 63 lanes busy, zs read 84 contiguous bytes per k across the
-// class lanes, no serial chain of 21 wave reductions (that form took 80 / 37 us on the cascade's critical path).
+// one wave per row, 4 rows per workgroup.  feat [R,D] (D = 512 -> 8 per lane).  The class matrix zs [D,C1] is staged once per
+// workgroup in LDS, transposed to [c][k], so that every class costs two conflict-free ds_read_b128 per lane instead of eight
+// strided global loads behind a dependent chain (80 / 37 us -> a few us on the cascade's critical path).  Same arithmetic and
+// summation order as before: per lane 8 products in channel order, then the wave butterfly.
+constexpr int ZS_MAX_C = 24;
 __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
                                                            const int* __restrict__ count, int R_cap, int D, int C1, float temp) {
-  __shared__ float xs[4][512];
+  __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
   const int R = dyn_rows(count, R_cap);
+  if ((int)(blockIdx.x * 4) >= R) return;    // whole workgroup beyond the count
+  for (int i = threadIdx.x; i < D * C1; i += blockDim.x) {
+    const int k = i / C1, c = i - k * C1;    // coalesced read of zs[k][c]
+    zt[c * 512 + k] = zs[i];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  const int row = blockIdx.x * (blockDim.x >> 6) + w;
-  if (row >= R) return;                      // wave-uniform; no block-wide barrier below
-  const int per = D / 64;  // 8
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
   float x[8];
   float ss = 0.f;
-  for (int q = 0; q < per; ++q) {
-    x[q] = feat[(size_t)row * D + lane * per + q];
-    ss += x[q] * x[q];
+  {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8 + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
   }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ss += x[q] * x[q];
   ss = wave_reduce_sum(ss);
   const float denom = fmaxf(sqrtf(ss), 1e-12f);
-  for (int q = 0; q < per; ++q) {
-    x[q] = temp * (x[q] / denom);
-    if (featn_out) featn_out[(size_t)row * D + lane * per + q] = x[q];
-    xs[w][lane * per + q] = x[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = temp * (x[q] / denom);
+  if (featn_out) {
+    *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8 + 4) = f32x4{x[4], x[5], x[6], x[7]};
   }
-  __builtin_amdgcn_wave_barrier();           // the row is written and read by this wave only; LDS operations of a wave are in order
-  const int cl = lane / 3, seg = lane - 3 * cl;
-  for (int c0 = 0; c0 < C1; c0 += 21) {      // 21 classes per pass (one pass for the 20 + background columns of this path)
-    const int c = c0 + cl;
-    const bool on = cl < 21 && c < C1;
+  for (int c = 0; c < C1; ++c) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
     float s = 0.f;
-    if (on) {
-      const int k0 = seg * 171, k1 = seg == 2 ? D : k0 + 171;
-      for (int k = k0; k < k1; ++k) s += xs[w][k] * zs[(size_t)k * C1 + c];
-    }
-    // the three segments of a class sit in adjacent lanes
-    const float s1 = __shfl_down(s, 1, 64), s2 = __shfl_down(s, 2, 64);
-    if (on && seg == 0) {
-      const float p = eod_sigmoid_precise((s + s1) + s2);
+    s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
+    s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
+    s = wave_reduce_sum(s);
+    if (lane == 0) {
+      const float p = eod_sigmoid_precise(s);
       float* o = prob_acc + (size_t)row * C1 + c;
       *o = accumulate ? (*o + p) : p;
     }
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_acc, int accumulate, float* feat_norm_out,
                                const int32_t* count, int R_cap, int D, int C1, float temp, eod_stream_t stream) {
   if (!feat || !zs || !prob_acc) return EOD_ERR_NULL;
-  if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  if (D != 512 || C1 < 2 || C1 > ZS_MAX_C || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(feat) || (feat_norm_out && !eod_aligned16(feat_norm_out))) return EOD_ERR_ALIGN;
   hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
                      feat_norm_out, count, R_cap, D, C1, temp);
   return eod_launch_status();

@@ -116,7 +116,9 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   pl.bn = cfg[pick][1];
   pl.tiles_m = (M + pl.bm - 1) / pl.bm;
   pl.tiles_n = (d->Cout + pl.bn - 1) / pl.bn;
-  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  // split-K is decided on `plan_rows` when given (a batch planned like one image: identical K walk, bitwise equal results)
+  const int Mp = (d->plan_rows > 0 && d->plan_rows < M) ? d->plan_rows : M;
+  const long tiles = (long)((Mp + pl.bm - 1) / pl.bm) * pl.tiles_n;
   int splitk = 1;
   if (d->out_mode == 2) {
     splitk = 1;
@@ -126,7 +128,7 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     // Deep-K, few-row GEMMs (the box head's fc1: 320 x 12544 -> 1024, 80 tiles, 392 chunks) are a serial chain of ~1.5 us chunk
     // round trips per workgroup: 7 workgroups per CU instead of 2 shorten the chain 3.5x (105 -> ~35 us on the cascade's critical
     // path) for 4x the slab traffic of a 10 us reduce.
-    const int target = (nchunks >= 128 && M <= 512) ? 1792 : 512;
+    const int target = (nchunks >= 128 && Mp <= 512) ? 1792 : 512;
     int want = (int)((target + tiles - 1) / tiles);
     int maxs = nchunks / 4;
     splitk = want < maxs ? want : maxs;

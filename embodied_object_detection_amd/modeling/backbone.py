@@ -45,11 +45,16 @@ class ResNet50Trunk:
                     ds = ops.Conv(wd, bd, stride=stride, device=device, name=f"{p}.downsample")
                 self.blocks.append((li, c1, c2, c3, ds))
 
-    def forward(self, x4: torch.Tensor, H: int, W: int):
-        """x4: [1,H,W,4] normalised image -> {'layer3','layer4','layer5'}: (tensor, h, w)."""
-        x = self.stem(x4, 1, H, W, relu=True)
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1):
+        """x4: [N,H,W,4] normalised image(s) -> {'layer3','layer4','layer5'}: (tensor, h, w).  N > 1: every layer is ONE launch
+        over the batch, planned like a single image (`plan_rows`), so each image's result is bitwise that of an N = 1 call."""
+        def pr(conv, hh, ww):
+            oh, ow = conv.out_hw(hh, ww)
+            return oh * ow if N > 1 else 0
+
+        x = self.stem(x4, N, H, W, relu=True, plan_rows=pr(self.stem, H, W))
         h, w = self.stem.out_hw(H, W)
-        x, h, w = ops.maxpool3x3s2(x, 1, h, w, 64)
+        x, h, w = ops.maxpool3x3s2(x, N, h, w, 64)
         feats = {}
         cur_layer = 1
         for (li, c1, c2, c3, ds) in self.blocks:
@@ -58,11 +63,11 @@ class ResNet50Trunk:
                 cur_layer = li
             sc = x
             if ds is not None:
-                sc = ds(x, 1, h, w)
-            o = c1(x, 1, h, w, relu=True)
-            o = c2(o, 1, h, w, relu=True)
+                sc = ds(x, N, h, w, plan_rows=pr(ds, h, w))
+            o = c1(x, N, h, w, relu=True, plan_rows=pr(c1, h, w))
+            o = c2(o, N, h, w, relu=True, plan_rows=pr(c2, h, w))
             h2, w2 = c2.out_hw(h, w)
-            x = c3(o, 1, h2, w2, res=sc, res_mode=1, relu=True)
+            x = c3(o, N, h2, w2, res=sc, res_mode=1, relu=True, plan_rows=pr(c3, h2, w2))
             h, w = h2, w2
         feats[f"layer{cur_layer + 1}"] = (x, h, w)
         return feats
@@ -124,6 +129,18 @@ class CustomRecurrentFPN:
         self.output[4](lat4, 1, h4, w4, out=views[1])
         lat3 = self.lateral[3](c3, 1, h3, w3, res=lat4, res_mode=2)
         self.output[3](lat3, 1, h3, w3, out=views[0])
+
+    def top_down_batched(self, c: dict, H: int, W: int, N: int):
+        """`top_down` for N images in one launch per layer -> level-major tensors (P3 [N,h3,w3,256], P4, P5); planned like one
+        image.  The caller copies each image's slices into that scene's own pyramid set (modeling/batched.py)."""
+        (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
+        lat5 = self.lateral[5](c5, N, h5, w5, plan_rows=h5 * w5)
+        p5 = self.output[5](lat5, N, h5, w5, plan_rows=h5 * w5)
+        lat4 = self.lateral[4](c4, N, h4, w4, res=lat5, res_mode=2, plan_rows=h4 * w4)
+        p4 = self.output[4](lat4, N, h4, w4, plan_rows=h4 * w4)
+        lat3 = self.lateral[3](c3, N, h3, w3, res=lat4, res_mode=2, plan_rows=h3 * w3)
+        p3 = self.output[3](lat3, N, h3, w3, plan_rows=h3 * w3)
+        return [p3, p4, p5]
 
     def fuse_memory_and_top(self, H: int, W: int, memory_f16: Optional[torch.Tensor], proj: Optional[torch.Tensor], which: int = 0,
                             err: Optional[torch.Tensor] = None):

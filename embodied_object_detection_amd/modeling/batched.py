@@ -1,0 +1,132 @@
+"""B independent sequences in lock-step on one GPU (BASELINE.json configs[4]: 4 sequences at 960x960, 512x512 memory grid).
+
+Only independent sequences may be batched: inside a sequence frame t+1 reads the memory frame t wrote
+(`Detic/detic/modeling/meta_arch/custom_rcnn.py:485-515`, `Detic/SMNet/loader.py:289-293`), so consecutive frames of one scene are
+never put in a batch.
+
+What is batched: the memory-independent half of the frame -- `preprocess_image`, the ResNet-50 trunk and the FPN top-down convs
+(`backbone/timm.py:277-299,118-136`, ~75 launches, two thirds of a frame's launches) run ONCE per step for all B images (N = B
+through `eod_conv2d`, planned like one image so that every image's result is bitwise the single-image result).  The scenes then
+continue on their own streams with their own memory state: memory read + fusion, proposals, cascade, mask passes, memory write
+(`CustomRCNNRecurrent.inference_frame` takes the batched trunk output exactly as it takes its own look-ahead).  The weights exist
+once; every scene has its own activation buffers and memory.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+from .meta_arch import CustomRCNNRecurrent
+
+
+def _share_weights(dst: CustomRCNNRecurrent, src: CustomRCNNRecurrent):
+    """Point every conv / linear layer of `dst` at `src`'s device weights (the layer objects stay separate: each keeps its own
+    launch descriptor)."""
+    def convs(m: CustomRCNNRecurrent):
+        out = [m.backbone.bottom_up.stem]
+        for (_li, c1, c2, c3, ds) in m.backbone.bottom_up.blocks:
+            out += [c1, c2, c3] + ([ds] if ds is not None else [])
+        for l in (3, 4, 5):
+            out += [m.backbone.lateral[l], m.backbone.output[l]]
+        out += [m.backbone.p6, m.backbone.p7]
+        out += [t[0] for t in m.proposal_generator.tower] + [m.proposal_generator.out_conv]
+        for st in m.roi_heads.stages:
+            out += [st["fc1"], st["fc2"], st["cls"], st["bb0"], st["bb2"]]
+        out += list(m.roi_heads.mask_convs) + [m.roi_heads.deconv]
+        return out
+
+    for a, b in zip(convs(dst), convs(src)):
+        a.w, a.bias, a.w_split = b.w, b.bias, b.w_split
+    dst.backbone.merge.prepared = src.backbone.merge.prepared
+    for a, b in zip(dst.proposal_generator.tower, src.proposal_generator.tower):
+        pass   # GroupNorm gamma / beta are tiny; left per scene
+    for sa, sb in zip(dst.roi_heads.stages, src.roi_heads.stages):
+        sa["zs"] = sb["zs"]
+    dst.roi_heads.pred_w = src.roi_heads.pred_w
+    dst.zs_weight = src.zs_weight
+
+
+class BatchedSequences:
+    """`BatchedSequences(cfg, B)(episodes)`: `episodes` = list of B frame lists of equal length (one per sequence); returns a list of
+    B output lists, each what `CustomRCNNRecurrent.forward([episode_b])` returns."""
+
+    def __init__(self, cfg, batch: int, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        if batch < 1:
+            raise ValueError("batch must be >= 1")
+        self.scenes: List[CustomRCNNRecurrent] = [CustomRCNNRecurrent(cfg, state_dict) for _ in range(batch)]
+        for m in self.scenes[1:]:
+            _share_weights(m, self.scenes[0])
+        torch.cuda.empty_cache()                 # the duplicate weight uploads of scenes 1.. are released
+        self.device = self.scenes[0].device
+        self.streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(batch)]
+        self._ev_in = torch.cuda.Event()
+        self._ev_trunk = torch.cuda.Event()
+        self._ev_done = [torch.cuda.Event() for _ in range(batch)]
+        for m in self.scenes:
+            # the scenes overlap each other: inside a scene one stream, in-order detection pass
+            m.overlap_branches = False
+            m.prefetch_trunk = False
+
+    def __call__(self, episodes: List[List[dict]]):
+        return self.forward(episodes)
+
+    def _batched_trunk(self, frames: List[dict]):
+        """One N = B pass of preprocess + ResNet-50 + FPN top-down; every scene's P3..P5 are copied into the pyramid set its next
+        frame reads, and the scene is told that its trunk has been computed ahead."""
+        m0 = self.scenes[0]
+        B = len(frames)
+        H, W = int(frames[0]["image"].shape[-2]), int(frames[0]["image"].shape[-1])
+        xs = []
+        for m, f in zip(self.scenes, frames):
+            x4, Hp, Wp = ops.preprocess_image(m._device_image(f), m.pixel_mean, m.pixel_std)
+            xs.append(x4)
+        x = torch.cat(xs, dim=0)                 # [B,Hp,Wp,4] (a device copy; no arithmetic)
+        c = m0.backbone.bottom_up.forward(x, Hp, Wp, N=B)
+        p345 = m0.backbone.top_down_batched(c, Hp, Wp, B)
+        for b, (m, f) in enumerate(zip(self.scenes, frames)):
+            nxt = (m._pyramid + 1) % 3
+            shapes, off, feats, views, pooled = m.backbone._plan(Hp, Wp, nxt)
+            for l in range(3):
+                views[l].copy_(p345[l][b:b + 1])
+            m._prefetched = (f["image"], Hp, Wp)
+        return Hp, Wp
+
+    def forward(self, episodes: List[List[dict]]):
+        B = len(self.scenes)
+        if len(episodes) != B or len({len(e) for e in episodes}) != 1:
+            raise ValueError(f"need {B} episodes of equal length")
+        T = len(episodes[0])
+        outs: List[List[dict]] = [[] for _ in range(B)]
+        pending: List[List] = [[] for _ in range(B)]
+        cur = torch.cuda.current_stream(self.device)
+        for t in range(T):
+            frames = [episodes[b][t] for b in range(B)]
+            # the batched trunk runs on the caller's stream once every scene has finished with the pyramid set it overwrites
+            for b in range(B):
+                cur.wait_event(self._ev_done[b])
+            self._batched_trunk(frames)
+            self._ev_trunk.record(cur)
+            for b, (m, f) in enumerate(zip(self.scenes, frames)):
+                s = self.streams[b]
+                s.wait_event(self._ev_trunk)
+                with torch.cuda.stream(s):
+                    if f["memory_reset"]:
+                        m.reset_memory(int(episodes[b][0]["memory"].shape[0]))
+                    if m.implicit_memory is None:
+                        raise RuntimeError("first frame of a scene must carry memory_reset=True")
+                    refresh = m.test_type in ("default", "episodic") or (m.test_type == "longterm" and t == 0)
+                    m._ev_trunk = self._ev_trunk          # what `inference_frame` waits on before it takes a trunk computed ahead
+                    m.inference_frame(f, refresh_memory_snapshot=refresh, materialize=False)
+                    pending[b].append(m._post_ticket())
+                    self._ev_done[b].record(s)
+                    if len(pending[b]) == 3:
+                        outs[b].append({"instances": m._materialize(pending[b].pop(0))})
+        for b, m in enumerate(self.scenes):
+            with torch.cuda.stream(self.streams[b]):
+                for ticket in pending[b]:
+                    outs[b].append({"instances": m._materialize(ticket)})
+            cur.wait_event(self._ev_done[b])
+        torch.cuda.current_stream(self.device).synchronize()
+        return outs

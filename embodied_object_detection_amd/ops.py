@@ -135,7 +135,8 @@ class Conv:
                  relu: bool = False, in_relu: bool = False, out_scale: float = 1.0, m_count: Optional[torch.Tensor] = None,
                  m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0,
                  levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
-                 fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True) -> torch.Tensor:
+                 fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True,
+                 plan_rows: int = 0) -> torch.Tensor:
         """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
         `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
         in one launch, `out` = [units, 2H, 2W] probabilities (out_mode 2 of include/eod_hip.h)."""
@@ -163,6 +164,7 @@ class Conv:
         else:
             d.fuse_w, d.fuse_b, d.out_units = None, 0.0, None
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
+        d.plan_rows = plan_rows
         if levels is not None:
             off, shapes = levels
             d.levels = len(shapes)

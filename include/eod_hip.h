@@ -60,7 +60,7 @@ typedef struct EodConvDesc {
                         predictor (see fuse_w below) */
   int32_t tap4;      /* 1: Cin == 4 (stem, RGB padded to 4): one float4 per tap */
   int32_t force_tile; /* 0 auto, else tile + 10 * variant: tile 1=128x128 2=128x64 3=64x64; variant 0 default, 1 BK=32, 2 BK=64,
-                         4 LDS-DMA staging (experimental), 5 bf16x3 split math (benchmarks/tests) */
+                         5 bf16x3 split math (benchmarks/tests) */
   int32_t force_splitk; /* 0 auto */
   float out_scale;
   /* pyramid mode (levels > 0): x / y are [level_off[levels], C] row lists, level l is a level_h[l] x level_w[l] image;
@@ -80,6 +80,10 @@ typedef struct EodConvDesc {
   /* optional: the same weights pre-split for the bf16x3 kernels (eod_conv_split_weights_bf16x3), Cout * Kpad * 6 bytes; used by
    * the 256x128 bf16x3 kernel instead of splitting w on the fly; ignored by every other kernel */
   const void* w_split;
+  /* 0, or the number of output rows the tile / split-K plan is made for instead of this call's: a batch of N images planned
+   * like ONE image walks K exactly as the single-image call does (same split-K slabs, same summation order), so its results
+   * are bitwise those of N separate calls (modeling/batched.py). */
+  int32_t plan_rows;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);

@@ -65,9 +65,10 @@ class BatchedSequences:
         self._ev_trunk = torch.cuda.Event()
         self._ev_done = [torch.cuda.Event() for _ in range(batch)]
         for m in self.scenes:
-            # the scenes overlap each other: inside a scene one stream, in-order detection pass
-            m.overlap_branches = False
+            # the trunk comes from the batched pass; inside a scene the box cascade / memory write still run beside the mask passes
+            # (`intra_scene_overlap`), the scenes overlap each other on their own streams
             m.prefetch_trunk = False
+        self.intra_scene_overlap = True
 
     def __call__(self, episodes: List[List[dict]]):
         return self.forward(episodes)
@@ -118,6 +119,7 @@ class BatchedSequences:
                         raise RuntimeError("first frame of a scene must carry memory_reset=True")
                     refresh = m.test_type in ("default", "episodic") or (m.test_type == "longterm" and t == 0)
                     m._ev_trunk = self._ev_trunk          # what `inference_frame` waits on before it takes a trunk computed ahead
+                    m.overlap_branches = self.intra_scene_overlap
                     m.inference_frame(f, refresh_memory_snapshot=refresh, materialize=False)
                     pending[b].append(m._post_ticket())
                     self._ev_done[b].record(s)

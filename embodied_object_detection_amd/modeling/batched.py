@@ -68,7 +68,7 @@ class BatchedSequences:
             # the trunk comes from the batched pass; inside a scene the box cascade / memory write still run beside the mask passes
             # (`intra_scene_overlap`), the scenes overlap each other on their own streams
             m.prefetch_trunk = False
-        self.intra_scene_overlap = True
+        self.intra_scene_overlap = False     # measured at 960x960, B = 4: 121.6 frames/s in order vs 89.5 with the shared side streams
 
     def __call__(self, episodes: List[List[dict]]):
         return self.forward(episodes)

@@ -92,9 +92,9 @@ def available_cores() -> int:
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate passes: profiles/r01_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
+    WRITE_SIZE, separate passes: profiles/r02_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")) as fh:
             return round(float(json.load(fh)["traffic_bytes_per_launch"]), 1)
     except (OSError, KeyError, ValueError):
         return None
@@ -505,7 +505,11 @@ def main():
                     "achieved": round(sum(flops) / (tot_ms * 1e-3) / 1e12, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(sum(flops) / (tot_ms * 1e-3) / 1e12 / peak, 4), "traffic": None if b3 else pmc_traffic(),
                     "launches": len(durs), "avg_launch_ms": round(tot_ms / len(durs), 4),
-                    "algorithmic_flop_per_launch": round(sum(flops) / len(flops), 1)}
+                    "algorithmic_flop_per_launch": round(sum(flops) / len(flops), 1),
+                    "note": "events on the launch stream around every mask-conv launch of the timed region (detection pass on ~300 "
+                            "ROIs and proposal-mask pass on ~45): in the default schedule these launches run concurrently with each "
+                            "other and with the look-ahead trunk, so a launch's duration includes sharing the chip; "
+                            "exclusive_launches is the kernel with the chip to itself"}
         if ev_excl:
             d2 = [s_.elapsed_time(e_) for (s_, e_, _c) in ev_excl]
             f2 = [2.0 * (int(c.item()) if c is not None else 0) * 196 * 256 * 2304 for (_s, _e, c) in ev_excl]
@@ -540,10 +544,11 @@ def main():
                        "proposal_masks_per_frame_mean": round(float(np.mean(uq)), 1) if lazy else round(float(np.mean(pc)), 1),
                        "image": f"{H}x{W}", "memory_cells": map_w * map_h, "weights": "random-init (synthetic_state_dict seed 0)",
                        "memory_cls_score_thresh": args.memory_thresh,
-                       "schedule": ("3 HIP streams per scene: main (FPN + memory fusion, proposals, both mask passes), side (box "
-                                    "cascade, memory selection + write-back), look-ahead (the next frame's memory-independent "
-                                    "ResNet trunk, inside an episode); frame t's Instances are sliced out after frame t+1 has been "
-                                    "enqueued; every step does one frame's full work, results bitwise equal to one stream"
+                       "schedule": ("five HIP streams per scene inside model([episode]): main chain (memory read + fusion, tower, proposal "
+                                    "decoding, proposal masks), side (box cascade, detection and memory selection, memory write), "
+                                    "look-ahead (the next frame's memory-independent ResNet trunk), detection (detection mask pass + "
+                                    "post-process + paste, may trail under the next frame), caller; Instances are sliced out two frames "
+                                    "behind the enqueue; every step does one frame's full work, results bitwise equal to one stream"
                                     if model.overlap_branches else "one HIP stream"),
                        "proposals_per_frame_mean": round(float(np.mean(pc)), 1), "detections_per_frame_mean": round(float(np.mean(dc)), 1),
                        "memory_instances_per_frame_mean": round(float(np.mean(mk)), 1)},

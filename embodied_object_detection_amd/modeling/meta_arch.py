@@ -494,11 +494,12 @@ class CustomRCNNRecurrent:
         if pipelined and not trailing_detection_pass:
             torch.cuda.current_stream(self.device).wait_event(self._ev_det[self._post_slot])     # in-order callers see a finished frame
         if self.stats_log is not None:      # bench.py: device-side copies of the frame's counters, read after the timed region
-            cnt = P["count"]
             if pipelined and trailing_detection_pass:
-                with torch.cuda.stream(self._det_stream):
+                with torch.cuda.stream(self._det_stream):      # the count is written by the trailing detection pass: copy it there
                     cnt = P["count"].clone()
-            self.stats_log.append((prop_count.clone(), cnt.clone(), self._writer.k_out.clone(), self._uniq_count.clone()))
+            else:
+                cnt = P["count"].clone()
+            self.stats_log.append((prop_count.clone(), cnt, self._writer.k_out.clone(), self._uniq_count.clone()))
         if not materialize:
             return None
         return {"instances": self._materialize(self._post_ticket())}

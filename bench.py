@@ -131,7 +131,15 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     alg = 4 * H * W + n_cells * (512 * 4 + 4) + 2 * 256 * 4 * rows + 3 * 512 * 256 * 4
     tot = sum(us)
     ach = alg / (tot * 1e-6) / 1e9
+    traffic = None
+    try:
+        if (H, W, n_cells) == (640, 640, 40000):        # the committed PMC passes were taken on this configuration
+            with open(os.path.join(ROOT, "profiles", "r02_hbm_class_traffic.json")) as fh:
+                traffic = round(float(json.load(fh)["traffic_bytes_total_x2_reads"]), 1)
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "hbm", "class": "memory read + fusion (a4 + a8)", "kernels": dict(zip(names, [round(u, 2) for u in us])),
+            "traffic": traffic,
             "avg_us_total": round(tot, 2), "algorithmic_bytes": alg, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBPS, 4), "dirty_rows_this_frame": n_dirty, "memory_cells": n_cells,
             "note": "event-bracketed on one stream after the timed region (median of %d launches); algorithmic bytes = the reference "

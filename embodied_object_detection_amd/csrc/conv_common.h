@@ -14,7 +14,6 @@ struct ConvArgs {
   const float* res;
   float* y;
   float* partial;
-  int* tile_counters;       // fp32 kernel, split-K: arrival counter per output tile (zero between launches); NULL = separate reduce kernel
   const int* m_count;
   int m_unit;
   const float* fuse_w;      // out_mode 2: predictor weights / bias / unit scatter

@@ -282,49 +282,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
   }
   store_wave_tiles<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
-  if (p.splitk > 1 && p.tile_counters) {
-    // Split-K combine by the LAST workgroup to arrive at this output tile (instead of a separate reduce launch per layer: 52
-    // launches per frame, 15 of them on the cascade's critical path).  Every thread publishes its slab stores (release fence,
-    // device scope), one thread takes a ticket; the workgroup holding the last ticket re-reads all slabs (acquire fence) in slab
-    // order -- the sum does not depend on the arrival order -- applies the fused epilogue and re-arms the counter.
-    __shared__ int last_flag;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      const int ticket = atomicAdd(p.tile_counters + t, 1);
-      last_flag = ticket == p.splitk - 1;
-      if (last_flag) p.tile_counters[t] = 0;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
-    const size_t slab = (size_t)p.M * p.Cout;
-    if ((p.Cout & 3) == 0) {
-      constexpr int C4 = BN / 4;
-      for (int idx = tid; idx < BM * C4; idx += 256) {
-        const int row = idx / C4, c4 = idx - row * C4;
-        const int m = m0 + row, n = n0 + 4 * c4;
-        if (m >= M || n >= p.Cout) continue;
-        const float* src = p.partial + (size_t)m * p.Cout + n;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int zz = 0; zz < p.splitk; ++zz) v += *reinterpret_cast<const f32x4*>(src + zz * slab);
-        epilogue_store(p, v.x, m, n);
-        epilogue_store(p, v.y, m, n + 1);
-        epilogue_store(p, v.z, m, n + 2);
-        epilogue_store(p, v.w, m, n + 3);
-      }
-    } else {
-      for (int idx = tid; idx < BM * BN; idx += 256) {
-        const int row = idx / BN, c = idx - row * BN;
-        const int m = m0 + row, n = n0 + c;
-        if (m >= M || n >= p.Cout) continue;
-        const float* src = p.partial + (size_t)m * p.Cout + n;
-        float v = 0.f;
-        for (int zz = 0; zz < p.splitk; ++zz) v += src[zz * slab];
-        epilogue_store(p, v, m, n);
-      }
-    }
-  }
 }
 
 }  // namespace

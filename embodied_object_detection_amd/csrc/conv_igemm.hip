@@ -65,14 +65,6 @@ inline int default_bk() {
   return v;
 }
 
-inline bool fused_reduce_enabled() {
-  static const bool v = [] {
-    const char* e = getenv("EOD_CONV_FUSED_REDUCE");      // 0: separate split-K reduce launches (A/B measurements)
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
-
 // Process-wide arithmetic mode of eod_conv2d (eod_set_conv_math / EOD_CONV_MATH): 0 fp32 MFMA, 1 bf16x3 split.
 std::atomic<int>& math_mode() {
   static std::atomic<int> v([] {
@@ -220,7 +212,7 @@ extern "C" size_t eod_conv2d_workspace_bytes(const EodConvDesc* d) {
   const int nchunks = d->Kpad / 32;
   const Plan pl = make_plan(d, M, nchunks);
   if (pl.splitk <= 1) return 0;
-  return EOD_CONV_COUNTER_BYTES + (size_t)pl.splitk * M * d->Cout * sizeof(float);
+  return (size_t)pl.splitk * M * d->Cout * sizeof(float);
 }
 
 extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
@@ -229,8 +221,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvArgs a{};
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
-  a.partial = d->workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + EOD_CONV_COUNTER_BYTES) : nullptr;
-  a.tile_counters = nullptr;
+  a.partial = d->workspace;
   a.m_count = d->m_count; a.m_unit = d->m_unit;
   a.fuse_w = d->fuse_w; a.out_units = d->out_units; a.fuse_b = d->fuse_b;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
@@ -260,17 +251,13 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.nchunks = pl.nchunks;
   a.splitk = pl.splitk; a.cps = pl.cps; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   if (pl.splitk > 1) {
-    const size_t need = EOD_CONV_COUNTER_BYTES + (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
+    const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
     if (!d->workspace || d->workspace_bytes < need) return EOD_ERR_CAPACITY;
-    // fp32 kernel: the last workgroup of every tile combines the slabs itself (counters = first EOD_CONV_COUNTER_BYTES of the
-    // workspace, zero before the first use, left zero).  The out_mode-2 kernel never splits; the bf16x3 kernels keep the reduce launch.
-    if (pl.glds == 0 && (long)pl.tiles_m * pl.tiles_n * (long)sizeof(int) <= (long)EOD_CONV_COUNTER_BYTES && fused_reduce_enabled())
-      a.tile_counters = reinterpret_cast<int*>(d->workspace);
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
   if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
   else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s);
-  if (pl.splitk > 1 && !a.tile_counters) {
+  if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;
     const bool vec = a.Cout % 4 == 0;
     int blocks = (int)((total / (vec ? 4 : 1) + 255) / 256);

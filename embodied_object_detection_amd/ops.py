@@ -47,8 +47,7 @@ class Workspace:
         key = (device.index if isinstance(device, torch.device) else str(device), _stream())
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            # zero-filled: the first 4 KB hold the split-K arrival counters of eod_conv2d, which every launch leaves at zero
-            buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self.bufs[key] = buf
         return buf
 

@@ -48,8 +48,7 @@ typedef struct EodConvDesc {
   const float* bias;   /* [Cout] or NULL ([Cout/4] for out_mode 1) */
   const float* res;    /* residual or NULL */
   float* y;            /* [N,OH,OW,Cout] (out_mode 0) / [N,2OH,2OW,Cout/4] (out_mode 1) */
-  float* workspace;    /* split-K: EOD_CONV_COUNTER_BYTES of per-tile arrival counters (must be ZERO before the first call that uses
-                          the buffer; every call leaves them zero) followed by the fp32 slabs; >= eod_conv2d_workspace_bytes() */
+  float* workspace;    /* split-K slabs, >= workspace_bytes */
   size_t workspace_bytes;
   const int32_t* m_count; /* optional device int: number of valid units (each m_unit output rows) */
   int32_t m_unit;
@@ -86,7 +85,6 @@ typedef struct EodConvDesc {
    * are bitwise those of N separate calls (modeling/batched.py). */
   int32_t plan_rows;
 } EodConvDesc;
-#define EOD_CONV_COUNTER_BYTES 4096
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
 /* Arithmetic of eod_conv2d when force_tile == 0 (process-wide, read at every call; initial value from the environment variable

@@ -33,7 +33,7 @@ class EodConvDesc(C.Structure):
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
         ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
-        ("plan_rows", C.c_int32), ("lds_pad", C.c_int32),
+        ("plan_rows", C.c_int32),
     ]
 
 

@@ -287,26 +287,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 }  // namespace
 
 template <int BM, int BN>
-static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s, unsigned pad) {
+static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s) {
   if (tap4)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), 0, s, a);
   else if (a.nlv > 0 && bk == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), 0, s, a);
   else if (a.nlv > 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), 0, s, a);
   else if (bk == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), 0, s, a);
 }
 
-// `lds_pad`: dynamic LDS the kernels never touch; it only lowers how many workgroups fit on a CU (EodConvDesc.lds_pad)
-void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, unsigned lds_pad) {
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s) {
   switch (tile) {
-    case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), lds_pad, s, a); break;
-    case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s, lds_pad); break;
-    case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s, lds_pad); break;
-    default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s, lds_pad); break;
+    case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), 0, s, a); break;
+    case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s); break;
+    case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s); break;
+    default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s); break;
   }
 }
 

@@ -115,7 +115,6 @@ class CustomRCNNRecurrent:
         # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
         # the mask (an fp32 matmul on a half-masked stream takes the same time).
         self.early_memory_selection = False
-        self.det_pass_lds_pad = 0            # see EodConvDesc.lds_pad: occupancy cap of the detection pass's GEMMs (experiment)
         self._det_stream = None
         self._ev_call = None
         self._ev_det = [None] * RESULT_SETS   # per result set: detection pass + paste finished
@@ -537,11 +536,7 @@ class CustomRCNNRecurrent:
         ds.wait_event(self._ev_box)
         with torch.cuda.stream(ds):
             self._mark("det_pass_begin", ds)
-            for conv in self.roi_heads.mask_convs + [self.roi_heads.deconv]:
-                conv.lds_pad = self.det_pass_lds_pad
             self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
-            for conv in self.roi_heads.mask_convs + [self.roi_heads.deconv]:
-                conv.lds_pad = 0
             self._postprocess_and_paste(det_boxes, det_scores, det_classes, det_count, image_hw, frame, self._post)
             self._ev_det[k].record(ds)
             self._mark("det_pass", ds)

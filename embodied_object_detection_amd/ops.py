@@ -127,7 +127,6 @@ class Conv:
         self._lib = _lib.load()
         self.w_split = None     # bf16x3 pieces of the weights, made on first use in that arithmetic mode
         self.event_log = None   # bench.py: list that receives (start_event, end_event, m_count) per launch
-        self.lds_pad = 0        # extra LDS per workgroup of this layer's launches (occupancy cap, include/eod_hip.h)
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -166,7 +165,6 @@ class Conv:
             d.fuse_w, d.fuse_b, d.out_units = None, 0.0, None
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
         d.plan_rows = plan_rows
-        d.lds_pad = self.lds_pad
         if levels is not None:
             off, shapes = levels
             d.levels = len(shapes)

@@ -84,9 +84,6 @@ typedef struct EodConvDesc {
    * like ONE image walks K exactly as the single-image call does (same split-K slabs, same summation order), so its results
    * are bitwise those of N separate calls (modeling/batched.py). */
   int32_t plan_rows;
-  /* extra LDS bytes reserved per workgroup (fp32 kernel): caps how many workgroups of this launch are resident per CU, so that a
-   * long low-priority GEMM leaves wave slots and LDS to latency-bound kernels of other streams (0 = none) */
-  int32_t lds_pad;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);

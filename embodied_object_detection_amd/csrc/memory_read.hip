@@ -222,9 +222,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       float acc8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
-#pragma unroll 1
+      // the four 4x4 blocks of a stride-8 cell are unrolled: their slot look-ups and LDS reads overlap
+#pragma unroll
       for (int by = 0; by < 2; ++by) {
-#pragma unroll 1
+#pragma unroll
         for (int bx = 0; bx < 2; ++bx) {
           // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
           const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant

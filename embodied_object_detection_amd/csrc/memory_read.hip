@@ -102,19 +102,6 @@ __device__ __forceinline__ void mix_lo(float& acc, unsigned pk) {
 __device__ __forceinline__ void mix_hi(float& acc, unsigned pk) {
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk));
 }
-// acc += float(half) * n  (n a small integer count as f32: the product is exact, one rounding in the add)
-__device__ __forceinline__ void mixn_lo(float& acc, unsigned pk, float n) {
-  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk), "v"(n));
-}
-__device__ __forceinline__ void mixn_hi(float& acc, unsigned pk, float n) {
-  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk), "v"(n));
-}
-__device__ __forceinline__ void addn8(float (&acc)[8], const uint4& raw, float n) {
-  mixn_lo(acc[0], raw.x, n); mixn_hi(acc[1], raw.x, n);
-  mixn_lo(acc[2], raw.y, n); mixn_hi(acc[3], raw.y, n);
-  mixn_lo(acc[4], raw.z, n); mixn_hi(acc[5], raw.z, n);
-  mixn_lo(acc[6], raw.w, n); mixn_hi(acc[7], raw.w, n);
-}
 __device__ __forceinline__ void add8(float (&acc)[8], const uint4& raw) {
   mix_lo(acc[0], raw.x); mix_hi(acc[1], raw.x);
   mix_lo(acc[2], raw.y); mix_hi(acc[3], raw.y);
@@ -143,15 +130,8 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
   return ((((size_t)tile32 * 32 + (c8 >> 1)) * 2 + (c8 & 1)) * 32 + r) * 8;
 }
 
-// TORCH_ORDER: the 16 pixels of a 4x4 block are added one by one in torch's row-major order (bit-identical to
-// F.avg_pool2d on every input).  Default (false): a block is summed as sum_over_distinct_cells count * row, ascending slot order --
-// the same 16 numbers, at most 3-4 roundings instead of 15; identical to the sequential sum whenever that sum is exact, i.e.
-// whenever the exponents inside the block (per channel) span <= 9 bits (11-bit values, 4 bits of count, 24-bit accumulator);
-// beyond that the two orders can differ by one f32 ulp before the fp16 rounding.  It removes ~5/6 of the kernel's VALU work.
-template <bool TORCH_ORDER>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
-  static_assert(GP_CAP <= 16, "slot ids must fit a nibble");
   // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
   extern __shared__ __align__(1024) unsigned char smem_raw[];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -222,10 +202,9 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       float acc8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
-      // the four 4x4 blocks of a stride-8 cell are unrolled: their slot look-ups and LDS reads overlap
-#pragma unroll
+#pragma unroll 1
       for (int by = 0; by < 2; ++by) {
-#pragma unroll
+#pragma unroll 1
         for (int bx = 0; bx < 2; ++bx) {
           // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
           const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant
@@ -250,20 +229,6 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
             add8(acc4, rows[lo * 64 + lane]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
-          } else if (hi != 255 && !TORCH_ORDER) {
-            // all rows are in LDS: count the block's pixels per slot (16 nibble counters in one 64-bit scalar; a count of 16 is the
-            // uniform case above), then one multiply-add per distinct slot and element
-            u64 cnt = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cnt += 1ull << (4 * sl[i]);
-            while (cnt) {
-              const int sidx = __builtin_ctzll(cnt) >> 2;
-              const float n = (float)(int)((cnt >> (4 * sidx)) & 15ull);
-              cnt &= ~(15ull << (4 * sidx));
-              addn8(acc4, rows[sidx * 64 + lane], n);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
           } else if (hi != 255) {
             // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
             uint4 raw[16];
@@ -406,9 +371,9 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
-  // Software pipeline, written out: the 4 fragment loads of k-step s + 7 are issued before the 4 MFMAs of k-step s (eight
+  // Software pipeline, written out: the 4 fragment loads of k-step s + 3 are issued before the 4 MFMAs of k-step s (four
   // register sets).  Left to the compiler the loop became load -> s_waitcnt vmcnt(0) -> MFMA with ONE load in flight (50 us).
-  constexpr int DEPTH = 8;
+  constexpr int DEPTH = 4;
   f16x8 af[DEPTH][2], bf[DEPTH][2];
   auto load_step = [&](int buf, int s) {
 #pragma unroll
@@ -470,27 +435,20 @@ extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs
 }
 
 extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, uint16_t* pooled_f16,
-                                      int32_t* err_flags, int torch_order, eod_stream_t stream) {
+                                      int32_t* err_flags, eod_stream_t stream) {
   if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
   if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
   const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
       return EOD_ERR_LAUNCH;
     attr_set = true;
   }
-  const dim3 grid((H >> 5) * (W >> 5));
-  if (torch_order)
-    hipLaunchKernelGGL(gather_pool_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
-                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
-  else
-    hipLaunchKernelGGL(gather_pool_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
-                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+  hipLaunchKernelGGL(gather_pool_kernel, dim3((H >> 5) * (W >> 5)), dim3(256), lds, (hipStream_t)stream,
+                     reinterpret_cast<const __half*>(mem_f16), proj, H, W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
   return eod_launch_status();
 }
 

@@ -4,7 +4,7 @@ wrong results by design).  Build the variants first (CPU container): python tool
 import ctypes as C, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE)); sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "embodied_object_detection_amd", "csrc")
-SRC = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_fp32.hip", "conv_glds.hip", "conv_bf16x3.hip")]
+SRC = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_fp32.hip", "conv_bf16x3.hip")]
 variants = {"full": [], "no_global": ["-DABL_NOGLOBAL"], "no_split": ["-DABL_NOSPLIT"], "no_ldswrite": ["-DABL_NOLDSW"],
             "no_global_split": ["-DABL_NOGLOBAL", "-DABL_NOSPLIT"], "no_global_split_ldsw": ["-DABL_NOGLOBAL", "-DABL_NOSPLIT", "-DABL_NOLDSW"]}
 if len(sys.argv) > 1 and sys.argv[1] == "build":

@@ -37,8 +37,8 @@ def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "mask"):
-    bench("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1, tiles=(3, 23, 43, 42, 41, 23, 43, 42, 41))
-    bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 43, 42, 41))
+    bench("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1, tiles=(3, 23, 13, 22, 21))
+    bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 13, 22, 21))
     bench("deconv 256 rois", 256, 14, 14, 256, 256, 2, 1, 0, deconv=True, tiles=(3, 2, 23, 22, 21))
 if which in ("all", "resnet"):
     bench("l1 conv2 3x3 64 160x160", 1, 160, 160, 64, 64, 3, 1, 1)

@@ -22,6 +22,11 @@
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 
+// diagnostics hook (tools/experiments/gp_timing.hip defines it to record s_memtime per phase); nothing in the product build
+#ifndef GP_STAMP
+#define GP_STAMP(k)
+#endif
+
 namespace {
 
 typedef unsigned long long u64;
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   const uint4* rows = reinterpret_cast<const uint4*>(my_rows);                          // [GP_CAP][64] x 16 B
   float* s16 = reinterpret_cast<float*>(smem_raw + (size_t)4 * GP_CAP * 1024);          // [4][512]
 
+  GP_STAMP(0);
   // phase 1: lane l holds the 4 pixels (y = l >> 2, x = 4 (l & 3) ..+3) of its quadrant: one 16-byte index load
   int c[4];
   {
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   // the pixels of a tile hit ~15 distinct cells).  Each round takes the first unassigned pixel's cell as key, starts the key
   // row's global -> LDS DMA (1 KiB, `buffer_load ... lds`: no VGPR staging) and assigns its slot to every pixel with that cell.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(mem), 0, 0xFFFFFFFFu, 0x00020000);
+  GP_STAMP(1);
   unsigned todo = 0xFu;
   unsigned slots = 0xFFFFFFFFu;          // 4 x 8 bit; 255 = not cached (read the table directly)
   int n_rows = 0;
@@ -185,7 +192,9 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     }
     ++n_rows;
   }
+  GP_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA'd rows are in LDS (only this wave reads them)
+  GP_STAMP(3);
 
   // phase 3: pooling.  Each lane owns 8 consecutive channels.  Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in
   // f32, /16; each avg_pool2d(2) sums 4 values row-major, /4, rounds to fp16 (timm.py:152,168).
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       }
     }
   }
+  GP_STAMP(4);
   float v16[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     const int row = ty * w32 + tx;
     *reinterpret_cast<uint4*>(pooled + frag_half_offset(t32 + (row >> 5), row & 31, tid)) = pack8(v32);
   }
+  GP_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------------

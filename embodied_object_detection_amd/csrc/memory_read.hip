@@ -201,6 +201,25 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
   const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
   const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
+  // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code by lane b = 4 * block_row + block_col: the common
+  // slot if its 16 pixels share a cached row, -1 if they are all cached but differ, -2 if some pixel reads the table directly.  The
+  // block loop then needs one readlane per uniform block instead of unpacking 16 slots with ~100 scalar instructions (in-kernel
+  // stamps: that bookkeeping, not the adds, was 800 cycles per block).
+  int binfo;
+  {
+    const int b = lane & 15, brow = b >> 2, bcol = b & 3;
+    unsigned r[4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) r[dy] = (unsigned)__shfl((int)slots, (4 * brow + dy) * 4 + bcol, 64);
+    const unsigned first = r[0] & 0xFFu;
+    const bool uniform = r[0] == first * 0x01010101u && r[1] == r[0] && r[2] == r[0] && r[3] == r[0];
+    bool direct = false;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) direct |= ((r[dy] >> (8 * dx)) & 0xFFu) == 0xFFu;
+    binfo = direct ? -2 : (uniform ? (int)first : -1);
+  }
   float acc16[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
@@ -215,30 +234,27 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       for (int by = 0; by < 2; ++by) {
 #pragma unroll 1
         for (int bx = 0; bx < 2; ++bx) {
-          // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
           const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant
+          const int info = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);
+          float acc4[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
+          if (info >= 0) {
+            // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
+            add8(acc4, rows[info * 64 + lane]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
+            continue;
+          }
+          // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
           int sl[16];
-          int lo = 255, hi = 0;
 #pragma unroll
           for (int dy = 0; dy < 4; ++dy) {
             const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)slots, (yq + dy) * 4 + xq4);
 #pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-              const int v = (int)((pk >> (8 * dx)) & 0xFFu);
-              sl[4 * dy + dx] = v;
-              lo = v < lo ? v : lo;
-              hi = v > hi ? v : hi;
-            }
+            for (int dx = 0; dx < 4; ++dx) sl[4 * dy + dx] = (int)((pk >> (8 * dx)) & 0xFFu);
           }
-          float acc4[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          if (lo == hi && hi != 255) {
-            // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
-            add8(acc4, rows[lo * 64 + lane]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
-          } else if (hi != 255) {
+          if (info == -1) {
             // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
             uint4 raw[16];
 #pragma unroll

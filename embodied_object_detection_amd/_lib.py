@@ -106,7 +106,7 @@ SIGNATURES = {
     "eod_memory_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_normalize_dirty_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_gather_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_void_p]),
+                                         C.c_int, C.c_void_p]),
     "eod_memory_pooled_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "eod_memory_project_weights_bytes": (C.c_size_t, []),
     "eod_memory_project_prepare": (C.c_int, [C.c_void_p] * 8),

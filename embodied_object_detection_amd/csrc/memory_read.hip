@@ -107,6 +107,19 @@ __device__ __forceinline__ void mix_lo(float& acc, unsigned pk) {
 __device__ __forceinline__ void mix_hi(float& acc, unsigned pk) {
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk));
 }
+// acc += float(half) * n  (n a small integer count as f32: the product is exact, one rounding in the add)
+__device__ __forceinline__ void mixn_lo(float& acc, unsigned pk, float n) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk), "v"(n));
+}
+__device__ __forceinline__ void mixn_hi(float& acc, unsigned pk, float n) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk), "v"(n));
+}
+__device__ __forceinline__ void addn8(float (&acc)[8], const uint4& raw, float n) {
+  mixn_lo(acc[0], raw.x, n); mixn_hi(acc[1], raw.x, n);
+  mixn_lo(acc[2], raw.y, n); mixn_hi(acc[3], raw.y, n);
+  mixn_lo(acc[4], raw.z, n); mixn_hi(acc[5], raw.z, n);
+  mixn_lo(acc[6], raw.w, n); mixn_hi(acc[7], raw.w, n);
+}
 __device__ __forceinline__ void add8(float (&acc)[8], const uint4& raw) {
   mix_lo(acc[0], raw.x); mix_hi(acc[1], raw.x);
   mix_lo(acc[2], raw.y); mix_hi(acc[3], raw.y);
@@ -135,8 +148,16 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
   return ((((size_t)tile32 * 32 + (c8 >> 1)) * 2 + (c8 & 1)) * 32 + r) * 8;
 }
 
+// TORCH_ORDER: every 4x4 block is summed pixel by pixel in torch's row-major order (bit-identical to F.avg_pool2d on every
+// input).  Default (false): a block with <= 4 distinct cells is summed as sum count x row in first-appearance order -- the same 16
+// numbers, <= 4 roundings instead of 15, identical to the sequential sum whenever that sum is exact (exponents inside the block
+// span <= 9 bits per channel: 11-bit values + 4 bits of count in a 24-bit accumulator).  The kernel is instruction-issue bound
+// (in-kernel stamps: ~8 cycles per instruction and wave, two waves per SIMD): the per-block (cell, count) lists are built once per
+// wave in vector code, 16 blocks in parallel, and a block then costs ~12 instructions per distinct cell instead of ~180.
+template <bool TORCH_ORDER>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
+  static_assert(GP_CAP <= 16, "slot ids must fit a nibble");
   // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
   extern __shared__ __align__(1024) unsigned char smem_raw[];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -205,7 +226,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   // slot if its 16 pixels share a cached row, -1 if they are all cached but differ, -2 if some pixel reads the table directly.  The
   // block loop then needs one readlane per uniform block instead of unpacking 16 slots with ~100 scalar instructions (in-kernel
   // stamps: that bookkeeping, not the adds, was 800 cycles per block).
+  //   >= 0: common slot | -1: mixed, pixel by pixel | -2: some pixel reads the table directly | -(10 + n): n <= 4 distinct slots,
+  //   listed in `blist` as bytes (slot | count << 4) in first-appearance order
   int binfo;
+  unsigned blist = 0;
   {
     const int b = lane & 15, brow = b >> 2, bcol = b & 3;
     unsigned r[4];
@@ -214,11 +238,30 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     const unsigned first = r[0] & 0xFFu;
     const bool uniform = r[0] == first * 0x01010101u && r[1] == r[0] && r[2] == r[0] && r[3] == r[0];
     bool direct = false;
+    unsigned us0 = 255, us1 = 255, us2 = 255, us3 = 255, uc0 = 0, uc1 = 0, uc2 = 0, uc3 = 0;
+    int nu = 0;
+    bool overflow = false;
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
+    for (int dy = 0; dy < 4; ++dy) {
 #pragma unroll
-      for (int dx = 0; dx < 4; ++dx) direct |= ((r[dy] >> (8 * dx)) & 0xFFu) == 0xFFu;
-    binfo = direct ? -2 : (uniform ? (int)first : -1);
+      for (int dx = 0; dx < 4; ++dx) {
+        const unsigned v = (r[dy] >> (8 * dx)) & 0xFFu;
+        direct |= v == 0xFFu;
+        const bool m0 = nu > 0 && us0 == v, m1 = nu > 1 && us1 == v, m2 = nu > 2 && us2 == v, m3 = nu > 3 && us3 == v;
+        uc0 += m0; uc1 += m1; uc2 += m2; uc3 += m3;
+        const bool fresh = !(m0 | m1 | m2 | m3);
+        if (fresh) {
+          if (nu == 0) { us0 = v; uc0 = 1; }
+          else if (nu == 1) { us1 = v; uc1 = 1; }
+          else if (nu == 2) { us2 = v; uc2 = 1; }
+          else if (nu == 3) { us3 = v; uc3 = 1; }
+          else overflow = true;
+          nu = nu < 4 ? nu + 1 : nu;
+        }
+      }
+    }
+    blist = (us0 & 15u) | (uc0 << 4) | ((us1 & 15u) | (uc1 << 4)) << 8 | ((us2 & 15u) | (uc2 << 4)) << 16 | ((us3 & 15u) | (uc3 << 4)) << 24;
+    binfo = direct ? -2 : (uniform ? (int)first : ((overflow || TORCH_ORDER) ? -1 : -(10 + nu)));
   }
   float acc16[8];
 #pragma unroll
@@ -244,6 +287,18 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
             add8(acc4, rows[info * 64 + lane]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
+            continue;
+          }
+          if (info <= -10) {
+            // <= 4 distinct cached rows: count x row per distinct row (counts <= 15 here: 16 is the uniform case)
+            const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
+            const int nu = -info - 10;
+            for (int k = 0; k < nu; ++k) {
+              const unsigned e = (bl >> (8 * k)) & 0xFFu;
+              addn8(acc4, rows[(e & 15u) * 64 + lane], (float)(int)(e >> 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
             continue;
           }
           // the block's 16 slots sit in 4 lanes (one per pixel row): wave-uniform after readlane
@@ -462,20 +517,27 @@ extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs
 }
 
 extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, uint16_t* pooled_f16,
-                                      int32_t* err_flags, eod_stream_t stream) {
+                                      int32_t* err_flags, int torch_order, eod_stream_t stream) {
   if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
   if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
   const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
       return EOD_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gather_pool_kernel, dim3((H >> 5) * (W >> 5)), dim3(256), lds, (hipStream_t)stream,
-                     reinterpret_cast<const __half*>(mem_f16), proj, H, W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+  const dim3 grid((H >> 5) * (W >> 5));
+  if (torch_order)
+    hipLaunchKernelGGL(gather_pool_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+  else
+    hipLaunchKernelGGL(gather_pool_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
   return eod_launch_status();
 }
 

@@ -95,6 +95,8 @@ class CustomRecurrentFPN:
         self.merge = ops.MemoryProjector([sd[f"backbone.map_merge_projection{i}.weight"] for i in (1, 2, 3)],
                                          [sd[f"backbone.map_merge_projection{i}.bias"] for i in (1, 2, 3)], device)
         self._plans = {}
+        # False: 4x4 pooling blocks are summed per distinct cell (count x row); True: pixel by pixel in torch's order (see the header)
+        self.pool_in_torch_order = False
 
     def level_shapes(self, H: int, W: int) -> List[Tuple[int, int]]:
         hw = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
@@ -151,7 +153,7 @@ class CustomRecurrentFPN:
             if memory_f16 is None or proj is None:
                 raise ValueError("implicit_memory needs the fp16 memory table and proj_indices")
             # P3..P5 are the first rows of the pyramid's row list, in the order the pooled rows are written
-            ops.memory_gather_pool(memory_f16, proj, H, W, out=pooled, err=err)
+            ops.memory_gather_pool(memory_f16, proj, H, W, out=pooled, err=err, torch_order=self.pool_in_torch_order)
             self.merge(pooled, feats, H, W, self.map_feature_weight, self.feat_fusion)
         self.p6(views[2], 1, h5, w5, out=views[3])
         self.p7(views[3], 1, shapes[3][0], shapes[3][1], in_relu=True, out=views[4])

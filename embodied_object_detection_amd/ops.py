@@ -402,12 +402,13 @@ def pooled_rows(H: int, W: int) -> int:
 
 
 def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None,
-                       err: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       err: Optional[torch.Tensor] = None, torch_order: bool = False) -> torch.Tensor:
     """a8 gather + cascaded pooling -> fp16 pooled rows of the three levels in MFMA operand-fragment order (see the header)."""
     N, D = mem_f16.shape
     if out is None:
         out = torch.empty((pooled_rows(H, W), D), dtype=torch.float16, device=mem_f16.device)
-    check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, out.data_ptr(), _ptr(err), _stream()),
+    check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, out.data_ptr(), _ptr(err), int(torch_order),
+                                             _stream()),
           "eod_memory_gather_pool")
     return out
 

@@ -547,15 +547,26 @@ def test_memory_read_matches_oracle(dev, pattern):
     assert torch.equal(m16.cpu(), ref_norm), "obs-normalised fp16 memory must be bit-exact"
     ref = _pooled_rows(M.memory_read_pooled(ref_norm, proj))
     err = torch.zeros((1,), dtype=torch.int32, device=dev)
-    raw = ops.memory_gather_pool(m16, proj.int().to(dev), H, W, err=err).cpu()
-    assert raw.shape == (ops.pooled_rows(H, W), 512)
-    out = _fragments_to_rows(raw, H, W).float()
-    assert out.shape == ref.shape
-    same = (out == ref).float().mean().item()
-    print(f"[memory read / {pattern}] identical fp16 values: {same:.6f}")
-    assert same > 0.9995, f"fp16 pooled values differ on {1 - same:.2e} of elements"
-    close(out, ref, rtol=1e-3, atol=1e-3)
+    for torch_order in (True, False):
+        raw = ops.memory_gather_pool(m16, proj.int().to(dev), H, W, err=err, torch_order=torch_order).cpu()
+        assert raw.shape == (ops.pooled_rows(H, W), 512)
+        out = _fragments_to_rows(raw, H, W).float()
+        assert out.shape == ref.shape
+        same = (out == ref).float().mean().item()
+        print(f"[memory read / {pattern} / torch_order={torch_order}] identical fp16 values: {same:.6f}")
+        if torch_order:
+            assert same == 1.0, "pixel-by-pixel pooling order must be bit-identical to F.avg_pool2d"
+        else:
+            # per-cell block sums: same numbers, fewer roundings; this input spreads 2^20 inside the windows on purpose
+            assert same > 0.9995, f"fp16 pooled values differ on {1 - same:.2e} of elements"
+        close(out, ref, rtol=1e-3, atol=1e-3)
     assert int(err.item()) == 0
+    # with <= 9 bits of exponent spread inside a window the sequential sum is exact, so both orders give the same bits
+    tame = (torch.rand((N, 512), generator=g) * 3 + 1) * torch.where(torch.rand((N, 512), generator=g) < 0.5, -1.0, 1.0)
+    t16 = tame.half().to(dev)
+    a = ops.memory_gather_pool(t16, proj.int().to(dev), H, W, torch_order=True).cpu()
+    b = ops.memory_gather_pool(t16, proj.int().to(dev), H, W, torch_order=False).cpu()
+    assert torch.equal(_fragments_to_rows(a, H, W), _fragments_to_rows(b, H, W))
 
 
 def test_memory_read_flags_out_of_range_indices(dev):

@@ -31,7 +31,7 @@ int main() {
       for (int x = 0; x < W; ++x)
         proj[y * W + x] = pat == 0 ? 7 : (pat == 1 ? (x * 5) % N : ((y / 8) * 200 + x / 8) % N);
     hipMemcpy(dproj, proj.data(), proj.size() * 4, hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 3; ++rep) eod_memory_gather_pool(mem, dproj, H, W, 512, N, pooled, nullptr, nullptr);
+    for (int rep = 0; rep < 3; ++rep) eod_memory_gather_pool(mem, dproj, H, W, 512, N, pooled, nullptr, 0, nullptr);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)blocks * 4 * 6);
     hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);

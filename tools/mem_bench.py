@@ -18,11 +18,12 @@ for (H, W, mw, cell) in ((640, 640, 200, 0.2), (960, 960, 512, 0.08)):
     m16 = (torch.randn((N, 512), device=dev) * 10).half()
     out = torch.empty((ops.pooled_rows(H, W), 512), dtype=torch.float16, device=dev)
     for name, proj in pats.items():
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-        for a, b in ev:
-            a.record(); ops.memory_gather_pool(m16, proj, H, W, out=out); b.record()
-        torch.cuda.synchronize()
-        print(f"{H}x{W} gather_pool {name:10s} {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")
+        for order in (False, True):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+            for a, b in ev:
+                a.record(); ops.memory_gather_pool(m16, proj, H, W, out=out, torch_order=order); b.record()
+            torch.cuda.synchronize()
+            print(f"{H}x{W} gather_pool {name:10s} torch_order={int(order)} {np.median([a.elapsed_time(b) for a, b in ev[5:]]) * 1e3:8.1f} us")
 
 # event-bracket overhead of a near-empty kernel, then normalise / project in isolation
 from embodied_object_detection_amd import _lib

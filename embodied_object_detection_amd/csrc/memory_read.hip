@@ -222,12 +222,11 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
   const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
   const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
-  // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code by lane b = 4 * block_row + block_col: the common
-  // slot if its 16 pixels share a cached row, -1 if they are all cached but differ, -2 if some pixel reads the table directly.  The
-  // block loop then needs one readlane per uniform block instead of unpacking 16 slots with ~100 scalar instructions (in-kernel
-  // stamps: that bookkeeping, not the adds, was 800 cycles per block).
-  //   >= 0: common slot | -1: mixed, pixel by pixel | -2: some pixel reads the table directly | -(10 + n): n <= 4 distinct slots,
-  //   listed in `blist` as bytes (slot | count << 4) in first-appearance order
+  // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code by lane b = 4 * block_row + block_col (in-kernel
+  // stamps: unpacking 16 slots per block with ~100 scalar instructions, not the adds, was 800 cycles per block):
+  //   -(10 + n): n <= 4 distinct cached rows, listed in `blist` as bytes (slot | (count - 1) << 4) in first-appearance order (a
+  //   block of one row is the list {(row, 16)}: 16 v is exact and (16 v) / 16 = v) | -1: pixel by pixel | -2: some pixel reads the
+  //   table directly
   int binfo;
   unsigned blist = 0;
   {
@@ -260,8 +259,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
         }
       }
     }
-    blist = (us0 & 15u) | (uc0 << 4) | ((us1 & 15u) | (uc1 << 4)) << 8 | ((us2 & 15u) | (uc2 << 4)) << 16 | ((us3 & 15u) | (uc3 << 4)) << 24;
-    binfo = direct ? -2 : (uniform ? (int)first : ((overflow || TORCH_ORDER) ? -1 : -(10 + nu)));
+    blist = (us0 & 15u) | ((uc0 - 1u) & 15u) << 4 | ((us1 & 15u) | ((uc1 - 1u) & 15u) << 4) << 8 |
+            ((us2 & 15u) | ((uc2 - 1u) & 15u) << 4) << 16 | ((us3 & 15u) | ((uc3 - 1u) & 15u) << 4) << 24;
+    binfo = direct ? -2 : ((overflow || (TORCH_ORDER && !uniform)) ? -1 : -(10 + nu));
+    (void)first;
   }
   float acc16[8];
 #pragma unroll
@@ -273,30 +274,47 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       float acc8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
-#pragma unroll 1
-      for (int by = 0; by < 2; ++by) {
-#pragma unroll 1
-        for (int bx = 0; bx < 2; ++bx) {
-          const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant
-          const int info = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);
+      // descriptors of the cell's four 4x4 blocks
+      int info[4];
+      unsigned bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = (cy8 * 2 + (j >> 1)) * 4 + cx8 * 2 + (j & 1);
+        info[j] = __builtin_amdgcn_readlane(binfo, b);
+        bl[j] = (unsigned)__builtin_amdgcn_readlane((int)blist, b);
+      }
+      if (info[0] <= -10 && info[1] <= -10 && info[2] <= -10 && info[3] <= -10) {
+        // common case: every block is a short list.  All (<= 16) row reads are issued first, then the multiply-adds, block by block
+        uint4 raw[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < -info[j] - 10) raw[j][k] = rows[((bl[j] >> (8 * k)) & 15u) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          if (info >= 0) {
-            // 16 copies of one fp16 row: the running sums n*v (n <= 16) are exact in f32, and (16 v) / 16 = v
-            add8(acc4, rows[info * 64 + lane]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q];
-            continue;
-          }
-          if (info <= -10) {
-            // <= 4 distinct cached rows: count x row per distinct row (counts <= 15 here: 16 is the uniform case)
-            const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
-            const int nu = -info - 10;
-            for (int k = 0; k < nu; ++k) {
-              const unsigned e = (bl >> (8 * k)) & 0xFFu;
-              addn8(acc4, rows[(e & 15u) * 64 + lane], (float)(int)(e >> 4));
-            }
+          for (int k = 0; k < 4; ++k)
+            if (k < -info[j] - 10) addn8(acc4, raw[j][k], (float)(int)(((bl[j] >> (8 * k + 4)) & 15u) + 1u));
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+          const int by = j >> 1, bx = j & 1;
+          const int yq = cy8 * 8 + by * 4, xq4 = cx8 * 2 + bx;          // first row / 4-pixel column group inside the quadrant
+          float acc4[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
+          const int inf = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);
+          if (inf <= -10) {
+            const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
+            for (int k = 0; k < -inf - 10; ++k)
+              addn8(acc4, rows[((bw >> (8 * k)) & 15u) * 64 + lane], (float)(int)(((bw >> (8 * k + 4)) & 15u) + 1u));
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
             continue;
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) sl[4 * dy + dx] = (int)((pk >> (8 * dx)) & 0xFFu);
           }
-          if (info == -1) {
+          if (inf == -1) {
             // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
             uint4 raw[16];
 #pragma unroll

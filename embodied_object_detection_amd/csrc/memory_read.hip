@@ -21,6 +21,7 @@
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 // diagnostics hook (tools/experiments/gp_timing.hip defines it to record s_memtime per phase); nothing in the product build
 #ifndef GP_STAMP
@@ -224,9 +225,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
   // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code by lane b = 4 * block_row + block_col (in-kernel
   // stamps: unpacking 16 slots per block with ~100 scalar instructions, not the adds, was 800 cycles per block):
-  //   -(10 + n): n <= 4 distinct cached rows, listed in `blist` as bytes (slot | (count - 1) << 4) in first-appearance order (a
-  //   block of one row is the list {(row, 16)}: 16 v is exact and (16 v) / 16 = v) | -1: pixel by pixel | -2: some pixel reads the
-  //   table directly
+  //   binfo = counts of up to 4 distinct cached rows (5 bits each, first-appearance order, 0 for unused entries) | kind << 20 | n << 22
+  //           kind 0: the block is that list (a block of one row is {(row, 16)}: 16 v is exact and (16 v) / 16 = v)
+  //           kind 1: pixel by pixel (more than 4 distinct rows, or TORCH_ORDER)   kind 2: some pixel reads the table directly
+  //   blist = the rows' slots (4 bits each; unused entries repeat entry 0, their count 0 adds an exact zero)
   int binfo;
   unsigned blist = 0;
   {
@@ -259,10 +261,12 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
         }
       }
     }
-    blist = (us0 & 15u) | ((uc0 - 1u) & 15u) << 4 | ((us1 & 15u) | ((uc1 - 1u) & 15u) << 4) << 8 |
-            ((us2 & 15u) | ((uc2 - 1u) & 15u) << 4) << 16 | ((us3 & 15u) | ((uc3 - 1u) & 15u) << 4) << 24;
-    binfo = direct ? -2 : ((overflow || (TORCH_ORDER && !uniform)) ? -1 : -(10 + nu));
-    (void)first;
+    us1 = nu > 1 ? us1 : us0;
+    us2 = nu > 2 ? us2 : us0;
+    us3 = nu > 3 ? us3 : us0;
+    blist = (us0 & 15u) | (us1 & 15u) << 4 | (us2 & 15u) << 8 | (us3 & 15u) << 12;
+    const unsigned kind = direct ? 2u : ((overflow || (TORCH_ORDER && !uniform)) ? 1u : 0u);
+    binfo = (int)(uc0 | uc1 << 5 | uc2 << 10 | uc3 << 15 | kind << 20 | (unsigned)nu << 22);
   }
   float acc16[8];
 #pragma unroll
@@ -283,25 +287,34 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
         info[j] = __builtin_amdgcn_readlane(binfo, b);
         bl[j] = (unsigned)__builtin_amdgcn_readlane((int)blist, b);
       }
-      if (info[0] <= -10 && info[1] <= -10 && info[2] <= -10 && info[3] <= -10) {
-        // common case: every block is a short list.  All (<= 16) row reads are issued first, then the multiply-adds, block by block
-        uint4 raw[4][4];
+      const unsigned kinds = ((unsigned)(info[0] | info[1] | info[2] | info[3]) >> 20) & 3u;
+      int nmax = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nmax = max(nmax, (info[j] >> 22) & 7);
+      // common case: every block is a short list.  Branch-free inside: the (8 or 16) row reads are issued first, then the
+      // multiply-adds block by block; unused list entries re-read entry 0 with a count of 0 (an exact + 0).
+      auto listed = [&](auto vtag) {
+        constexpr int V = decltype(vtag)::value;
+        uint4 raw[4][V];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < -info[j] - 10) raw[j][k] = rows[((bl[j] >> (8 * k)) & 15u) * 64 + lane];
+          for (int k = 0; k < V; ++k) raw[j][k] = rows[((bl[j] >> (4 * k)) & 15u) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < -info[j] - 10) addn8(acc4, raw[j][k], (float)(int)(((bl[j] >> (8 * k + 4)) & 15u) + 1u));
+          for (int k = 0; k < V; ++k) addn8(acc4, raw[j][k], (float)(int)(((unsigned)info[j] >> (5 * k)) & 31u));
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
         }
+      };
+      if (kinds == 0 && nmax <= 2) {
+        listed(std::integral_constant<int, 2>{});
+      } else if (kinds == 0) {
+        listed(std::integral_constant<int, 4>{});
       } else {
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
@@ -310,11 +323,13 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          const int inf = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);
-          if (inf <= -10) {
+          const int inf = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);      // (j is a run-time index here)
+          const int kind = (inf >> 20) & 3;
+          if (kind == 0) {
             const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
-            for (int k = 0; k < -inf - 10; ++k)
-              addn8(acc4, rows[((bw >> (8 * k)) & 15u) * 64 + lane], (float)(int)(((bw >> (8 * k + 4)) & 15u) + 1u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              addn8(acc4, rows[((bw >> (4 * k)) & 15u) * 64 + lane], (float)(int)(((unsigned)inf >> (5 * k)) & 31u));
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
             continue;
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) sl[4 * dy + dx] = (int)((pk >> (8 * dx)) & 0xFFu);
           }
-          if (inf == -1) {
+          if (kind == 1) {
             // all 16 rows are in LDS: 16 independent reads, then the adds in row-major order
             uint4 raw[16];
 #pragma unroll

@@ -98,9 +98,7 @@ __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* _
 // ------------------------------------------------------------------------------------------------------
 // a8: gather + cascaded average pooling, one workgroup per 32x32 pixel tile
 // ------------------------------------------------------------------------------------------------------
-// distinct rows cached per 16x16 quadrant (1 KiB of LDS each, per wave); pixels beyond the capacity read L2/HBM directly.
-// 16 (72 KB per workgroup: two per CU) for frames of fewer than 512 tiles, 32 (136 KB: one per CU) for larger frames, where a
-// quadrant of a finer map holds more cells and the chip is filled either way.
+constexpr int GP_CAP = 16;      // distinct rows cached per 16x16 quadrant (16 KiB of LDS per wave); pixels beyond it read L2/HBM directly
 
 // acc += float(half): ONE v_fma_mix_f32 (f16 source operand, * 1.0, f32 accumulate; a single rounding, identical to convert + add).
 // The compiler's own choice for this pattern is v_cvt_f32_f16 x2 + v_pk_add_f32, 1.5 instructions per element on a VALU-bound loop.
@@ -157,10 +155,10 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 // span <= 9 bits per channel: 11-bit values + 4 bits of count in a 24-bit accumulator).  The kernel is instruction-issue bound
 // (in-kernel stamps: ~8 cycles per instruction and wave, two waves per SIMD): the per-block (cell, count) lists are built once per
 // wave in vector code, 16 blocks in parallel, and a block then costs ~12 instructions per distinct cell instead of ~180.
-template <bool TORCH_ORDER, int GP_CAP>
+template <bool TORCH_ORDER>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
-  static_assert(GP_CAP <= 32, "slot ids must fit 5 bits");
+  static_assert(GP_CAP <= 16, "slot ids must fit a nibble");
   // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
   extern __shared__ __align__(1024) unsigned char smem_raw[];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   //   binfo = counts of up to 4 distinct cached rows (5 bits each, first-appearance order, 0 for unused entries) | kind << 20 | n << 22
   //           kind 0: the block is that list (a block of one row is {(row, 16)}: 16 v is exact and (16 v) / 16 = v)
   //           kind 1: pixel by pixel (more than 4 distinct rows, or TORCH_ORDER)   kind 2: some pixel reads the table directly
-  //   blist = the rows' slots (5 bits each; unused entries repeat entry 0, their count 0 adds an exact zero)
+  //   blist = the rows' slots (4 bits each; unused entries repeat entry 0, their count 0 adds an exact zero)
   int binfo;
   unsigned blist = 0;
   {
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     us1 = nu > 1 ? us1 : us0;
     us2 = nu > 2 ? us2 : us0;
     us3 = nu > 3 ? us3 : us0;
-    blist = (us0 & 31u) | (us1 & 31u) << 5 | (us2 & 31u) << 10 | (us3 & 31u) << 15;
+    blist = (us0 & 15u) | (us1 & 15u) << 4 | (us2 & 15u) << 8 | (us3 & 15u) << 12;
     const unsigned kind = direct ? 2u : ((overflow || (TORCH_ORDER && !uniform)) ? 1u : 0u);
     binfo = (int)(uc0 | uc1 << 5 | uc2 << 10 | uc3 << 15 | kind << 20 | (unsigned)nu << 22);
   }
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int k = 0; k < V; ++k) raw[j][k] = rows[((bl[j] >> (5 * k)) & 31u) * 64 + lane];
+          for (int k = 0; k < V; ++k) raw[j][k] = rows[((bl[j] >> (4 * k)) & 15u) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float acc4[8];
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
             const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              addn8(acc4, rows[((bw >> (5 * k)) & 31u) * 64 + lane], (float)(int)(((unsigned)inf >> (5 * k)) & 31u));
+              addn8(acc4, rows[((bw >> (4 * k)) & 15u) * 64 + lane], (float)(int)(((unsigned)inf >> (5 * k)) & 31u));
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
             continue;
@@ -556,30 +554,23 @@ extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* pr
   if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
   if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
-  const int tiles = (H >> 5) * (W >> 5);
-  const int cap = tiles >= 512 ? 32 : 16;
-  const size_t lds = (size_t)4 * cap * 1024 + 4 * 512 * sizeof(float);
+  const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    const int big = 4 * 32 * 1024 + 4 * 512 * (int)sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
       return EOD_ERR_LAUNCH;
     attr_set = true;
   }
-  const dim3 grid(tiles);
-  const __half* m = reinterpret_cast<const __half*>(mem_f16);
-  __half* o = reinterpret_cast<__half*>(pooled_f16);
-  hipStream_t st = (hipStream_t)stream;
-  if (cap == 16) {
-    if (torch_order) hipLaunchKernelGGL((gather_pool_kernel<true, 16>), grid, dim3(256), lds, st, m, proj, H, W, n_cells, o, err_flags);
-    else hipLaunchKernelGGL((gather_pool_kernel<false, 16>), grid, dim3(256), lds, st, m, proj, H, W, n_cells, o, err_flags);
-  } else {
-    if (torch_order) hipLaunchKernelGGL((gather_pool_kernel<true, 32>), grid, dim3(256), lds, st, m, proj, H, W, n_cells, o, err_flags);
-    else hipLaunchKernelGGL((gather_pool_kernel<false, 32>), grid, dim3(256), lds, st, m, proj, H, W, n_cells, o, err_flags);
-  }
+  const dim3 grid((H >> 5) * (W >> 5));
+  if (torch_order)
+    hipLaunchKernelGGL(gather_pool_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+  else
+    hipLaunchKernelGGL(gather_pool_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
   return eod_launch_status();
 }
 

@@ -210,9 +210,9 @@ int eod_memory_normalize_dirty_f16(const float* mem, const float* obs, int32_t* 
  * levels, stored in the operand-fragment order eod_memory_project_fuse reads: [level][32-row tile][k-step s<32][hi<2][r<32][8]
  * halves = element (row 32*tile + r, channel 16 s + 8 hi + j); each level starts on a tile boundary, so the buffer holds
  * eod_memory_pooled_halves(H, W) halves.  err_flags: int32 [1] or NULL.  torch_order != 0: every 4x4 block is summed pixel by pixel
- * in row-major order (bit-identical to F.avg_pool2d on every input); 0: per block sum_{distinct cells} count * row -- the same 16
- * numbers with fewer roundings, identical whenever the sequential sum is exact (exponent spread <= 9 bits inside the block), ~6x
- * less arithmetic. */
+ * in row-major order (bit-identical to F.avg_pool2d on every input); 0: a block with <= 4 distinct cells is summed as
+ * sum count * row in first-appearance order -- the same 16 numbers with fewer roundings, identical to the sequential sum whenever
+ * that sum is exact (exponents inside the block span <= 9 bits per channel); fewer instructions on an issue-bound kernel. */
 size_t eod_memory_pooled_halves(int H, int W);
 int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells,
                            uint16_t* pooled_f16, int32_t* err_flags, int torch_order, eod_stream_t stream);

@@ -115,18 +115,36 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     proj = f["proj_indices"]
     shapes, off, feats, views, pooled = model.backbone._plan(H, W, 0)
     names = ("normalize_dirty_f16_kernel", "gather_pool_kernel", "project_fuse_kernel")
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-    for r in range(reps):
-        model._dirty.copy_(snap)
-        ev[r][0].record()
-        ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16)
-        ev[r][1].record()
-        ops.memory_gather_pool(model._mem_f16, proj, H, W, out=pooled, err=model._err)
-        ev[r][2].record()
-        model.backbone.merge(pooled, feats, H, W, model.backbone.map_feature_weight, "sum")
-        ev[r][3].record()
-    torch.cuda.synchronize()
-    us = [float(np.median([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(5, reps)])) * 1e3 for k in range(3)]
+    # Each kernel: `batch` back-to-back launches between ONE pair of events, `reps` times; duration = median / batch.  (A pair of
+    # events around a single 10-20 us launch adds ~5 us of bracket to it: profiles/r02_mem_bench_rocprof.txt.)  The normalise
+    # consumes its dirty flags, so every launch is preceded by the 160 KB copy that restores them and the copies alone are
+    # timed the same way and subtracted.
+    batch = 20
+
+    def timed(body, pre=None):
+        out = []
+        for _ in range(reps // 3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(2_000_000)          # ~1 ms of spinning first: the host has queued the whole batch before it starts
+            a.record()
+            for _i in range(batch):
+                if pre is not None:
+                    pre()
+                if body is not None:
+                    body()
+            b.record()
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b) * 1e3 / batch)
+        return float(np.median(out[2:]))
+
+    restore = lambda: model._dirty.copy_(snap)
+    t_restore = timed(None, restore)
+    us = [max(0.0, timed(lambda: ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16),
+                         restore) - t_restore),
+          timed(lambda: ops.memory_gather_pool(model._mem_f16, proj, H, W, out=pooled, err=model._err)),
+          timed(lambda: model.backbone.merge(pooled, feats, H, W, model.backbone.map_feature_weight, "sum"))]
+    restore()
+    ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16)
     rows = sum(h * w for (h, w) in shapes[:3])
     alg = 4 * H * W + n_cells * (512 * 4 + 4) + 2 * 256 * 4 * rows + 3 * 512 * 256 * 4
     tot = sum(us)
@@ -142,8 +160,9 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
             "traffic": traffic,
             "avg_us_total": round(tot, 2), "algorithmic_bytes": alg, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBPS, 4), "dirty_rows_this_frame": n_dirty, "memory_cells": n_cells,
-            "note": "event-bracketed on one stream after the timed region (median of %d launches); algorithmic bytes = the reference "
-                    "algorithm's per frame (SURVEY 8d, U = N); rocprofv3 per-kernel averages of the same run are under profiles/" % (reps - 5)}
+            "note": "HIP events around %d back-to-back launches of each kernel on one stream, after the timed region (median of %d "
+                    "batches, / %d); algorithmic bytes = the reference algorithm's per frame (SURVEY 8d, U = N); rocprofv3 "
+                    "per-kernel averages of the same run are under profiles/" % (batch, reps // 3 - 2, batch)}
 
 
 def log(msg):

@@ -115,6 +115,19 @@ __device__ __forceinline__ void mixn_lo(float& acc, unsigned pk, float n) {
 __device__ __forceinline__ void mixn_hi(float& acc, unsigned pk, float n) {
   asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pk), "v"(n));
 }
+// acc = float(half) * n  (no read of acc: saves the zero fill of a fresh accumulator)
+__device__ __forceinline__ void mixn0_lo(float& acc, unsigned pk, float n) {
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(pk), "v"(n));
+}
+__device__ __forceinline__ void mixn0_hi(float& acc, unsigned pk, float n) {
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(pk), "v"(n));
+}
+__device__ __forceinline__ void setn8(float (&acc)[8], const uint4& raw, float n) {
+  mixn0_lo(acc[0], raw.x, n); mixn0_hi(acc[1], raw.x, n);
+  mixn0_lo(acc[2], raw.y, n); mixn0_hi(acc[3], raw.y, n);
+  mixn0_lo(acc[4], raw.z, n); mixn0_hi(acc[5], raw.z, n);
+  mixn0_lo(acc[6], raw.w, n); mixn0_hi(acc[7], raw.w, n);
+}
 __device__ __forceinline__ void addn8(float (&acc)[8], const uint4& raw, float n) {
   mixn_lo(acc[0], raw.x, n); mixn_hi(acc[1], raw.x, n);
   mixn_lo(acc[2], raw.y, n); mixn_hi(acc[3], raw.y, n);
@@ -150,7 +163,7 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 }
 
 // TORCH_ORDER: every 4x4 block is summed pixel by pixel in torch's row-major order (bit-identical to F.avg_pool2d on every
-// input).  Default (false): a block with <= 4 distinct cells is summed as sum count x row in first-appearance order -- the same 16
+// input).  Default (false): a block with <= 4 distinct cells is summed as sum count x row in cache-slot order -- the same 16
 // numbers, <= 4 roundings instead of 15, identical to the sequential sum whenever that sum is exact (exponents inside the block
 // span <= 9 bits per channel: 11-bit values + 4 bits of count in a 24-bit accumulator).  The kernel is instruction-issue bound
 // (in-kernel stamps: ~8 cycles per instruction and wave, two waves per SIMD): the per-block (cell, count) lists are built once per
@@ -189,85 +202,82 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
   }
   // phase 2: de-duplicate inside the wave with ballots (no LDS atomics: an LDS hash over the tile cost 13 us of CAS contention,
-  // the pixels of a tile hit ~15 distinct cells).  Each round takes the first unassigned pixel's cell as key, starts the key
+  // the pixels of a tile hit ~15 distinct cells).  Each round takes a cell of the first lane with pixels left as key, starts the key
   // row's global -> LDS DMA (1 KiB, `buffer_load ... lds`: no VGPR staging) and assigns its slot to every pixel with that cell.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(mem), 0, 0xFFFFFFFFu, 0x00020000);
   GP_STAMP(1);
-  unsigned todo = 0xFu;
-  unsigned slots = 0xFFFFFFFFu;          // 4 x 8 bit; 255 = not cached (read the table directly)
+  int sl[4] = {255, 255, 255, 255};      // cache slot of each pixel; 255 = not cached (read the table directly)
   int n_rows = 0;
 #pragma unroll 1
   while (n_rows < GP_CAP) {
-    const u64 bal = __ballot(todo != 0);
+    // a pixel that has its slot holds -1: the largest remaining cell of the first lane with any left is the round's key
+    const int cand = max(max(c[0], c[1]), max(c[2], c[3]));
+    const u64 bal = __ballot(cand >= 0);
     if (bal == 0) break;
-    const int leader = __ffsll((long long)bal) - 1;
-    const int j = __ffs((int)todo) - 1;
-    const int cand = j == 0 ? c[0] : (j == 1 ? c[1] : (j == 2 ? c[2] : c[3]));
-    const int key = __builtin_amdgcn_readlane(cand, leader);
+    const int key = __builtin_amdgcn_readlane(cand, __ffsll((long long)bal) - 1);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(my_rows + n_rows * 1024), 16, (unsigned)key * 1024u + lane * 16u, 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (((todo >> q) & 1u) && c[q] == key) {
-        slots = (slots & ~(0xFFu << (8 * q))) | ((unsigned)n_rows << (8 * q));
-        todo &= ~(1u << q);
-      }
+      const bool hit = c[q] == key;
+      sl[q] = hit ? n_rows : sl[q];
+      c[q] = hit ? -1 : c[q];
     }
     ++n_rows;
   }
+  const unsigned slots = (unsigned)sl[0] | (unsigned)sl[1] << 8 | (unsigned)sl[2] << 16 | (unsigned)sl[3] << 24;
   GP_STAMP(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA'd rows are in LDS (only this wave reads them)
-  GP_STAMP(3);
 
   // phase 3: pooling.  Each lane owns 8 consecutive channels.  Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in
   // f32, /16; each avg_pool2d(2) sums 4 values row-major, /4, rounds to fp16 (timm.py:152,168).
   const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
   const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
   const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
-  // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code by lane b = 4 * block_row + block_col (in-kernel
-  // stamps: unpacking 16 slots per block with ~100 scalar instructions, not the adds, was 800 cycles per block):
-  //   binfo = counts of up to 4 distinct cached rows (5 bits each, first-appearance order, 0 for unused entries) | kind << 20 | n << 22
+  // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code, all 64 lanes at work (in-kernel stamps: unpacking
+  // 16 slots per block with ~100 scalar instructions, not the adds, was 800 cycles per block; a first vector version that walked
+  // the 16 pixels of a block in one lane was 1 200 instructions, this one is ~70):
+  //   binfo = counts of up to 4 distinct cached rows (5 bits each, ascending slot order, 0 for unused entries) | kind << 20 | n << 22
   //           kind 0: the block is that list (a block of one row is {(row, 16)}: 16 v is exact and (16 v) / 16 = v)
   //           kind 1: pixel by pixel (more than 4 distinct rows, or TORCH_ORDER)   kind 2: some pixel reads the table directly
   //   blist = the rows' slots (4 bits each; unused entries repeat entry 0, their count 0 adds an exact zero)
   int binfo;
-  unsigned blist = 0;
+  unsigned blist;
   {
-    const int b = lane & 15, brow = b >> 2, bcol = b & 3;
-    unsigned r[4];
+    // lane l holds pixel row (l >> 2) & 3 of block (row l >> 4, column l & 3): the four lanes of a block are l, l + 4, l + 8, l + 12
+    // inside one 16-lane row, so two row rotations combine them (all four lanes end up with the block's descriptor).
+    auto ror = [](unsigned v, auto ctrl) {
+      return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, false);
+    };
+    using ror4 = std::integral_constant<int, 0x124>;      // row_ror:4
+    using ror8 = std::integral_constant<int, 0x128>;      // row_ror:8
+    unsigned m = 0;                                        // bit s: slot s occurs in the block; bit 31: a pixel without a slot
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) r[dy] = (unsigned)__shfl((int)slots, (4 * brow + dy) * 4 + bcol, 64);
-    const unsigned first = r[0] & 0xFFu;
-    const bool uniform = r[0] == first * 0x01010101u && r[1] == r[0] && r[2] == r[0] && r[3] == r[0];
-    bool direct = false;
-    unsigned us0 = 255, us1 = 255, us2 = 255, us3 = 255, uc0 = 0, uc1 = 0, uc2 = 0, uc3 = 0;
-    int nu = 0;
-    bool overflow = false;
+    for (int q = 0; q < 4; ++q) m |= 1u << (sl[q] & 31);
+    m |= ror(m, ror4{});
+    m |= ror(m, ror8{});
+    const bool direct = (m >> 31) != 0;
+    const unsigned mm = m & 0xFFFFu;
+    const int nu = __popc(mm);
+    // the list is the block's slots in ascending order; a pixel's list position is the number of smaller slots present
+    unsigned cnt = 0;
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-#pragma unroll
-      for (int dx = 0; dx < 4; ++dx) {
-        const unsigned v = (r[dy] >> (8 * dx)) & 0xFFu;
-        direct |= v == 0xFFu;
-        const bool m0 = nu > 0 && us0 == v, m1 = nu > 1 && us1 == v, m2 = nu > 2 && us2 == v, m3 = nu > 3 && us3 == v;
-        uc0 += m0; uc1 += m1; uc2 += m2; uc3 += m3;
-        const bool fresh = !(m0 | m1 | m2 | m3);
-        if (fresh) {
-          if (nu == 0) { us0 = v; uc0 = 1; }
-          else if (nu == 1) { us1 = v; uc1 = 1; }
-          else if (nu == 2) { us2 = v; uc2 = 1; }
-          else if (nu == 3) { us3 = v; uc3 = 1; }
-          else overflow = true;
-          nu = nu < 4 ? nu + 1 : nu;
-        }
-      }
+    for (int q = 0; q < 4; ++q) {
+      const unsigned below = mm & ((1u << (sl[q] & 31)) - 1u);
+      cnt += 1u << (5 * (__popc(below) & 3));             // (positions >= 4 only occur in blocks that are not summed as a list)
     }
-    us1 = nu > 1 ? us1 : us0;
-    us2 = nu > 2 ? us2 : us0;
-    us3 = nu > 3 ? us3 : us0;
-    blist = (us0 & 15u) | (us1 & 15u) << 4 | (us2 & 15u) << 8 | (us3 & 15u) << 12;
+    cnt += ror(cnt, ror4{});
+    cnt += ror(cnt, ror8{});
+    const unsigned m1 = mm & (mm - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+    const unsigned us0 = (unsigned)(__ffs((int)mm) - 1) & 15u;
+    const unsigned us1 = m1 ? (unsigned)(__ffs((int)m1) - 1) : us0;
+    const unsigned us2 = m2 ? (unsigned)(__ffs((int)m2) - 1) : us0;
+    const unsigned us3 = m3 ? (unsigned)(__ffs((int)m3) - 1) : us0;
+    blist = us0 | us1 << 4 | us2 << 8 | us3 << 12;
+    const bool overflow = nu > 4, uniform = nu == 1;
     const unsigned kind = direct ? 2u : ((overflow || (TORCH_ORDER && !uniform)) ? 1u : 0u);
-    binfo = (int)(uc0 | uc1 << 5 | uc2 << 10 | uc3 << 15 | kind << 20 | (unsigned)nu << 22);
+    binfo = (int)((cnt & 0xFFFFFu) | kind << 20 | (unsigned)min(nu, 7) << 22);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA'd rows are in LDS (only this wave reads them)
+  GP_STAMP(3);
   float acc16[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       unsigned bl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int b = (cy8 * 2 + (j >> 1)) * 4 + cx8 * 2 + (j & 1);
+        const int b = (cy8 * 2 + (j >> 1)) * 16 + cx8 * 2 + (j & 1);          // a lane of block (row, column)
         info[j] = __builtin_amdgcn_readlane(binfo, b);
         bl[j] = (unsigned)__builtin_amdgcn_readlane((int)blist, b);
       }
@@ -303,10 +313,9 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float acc4[8];
+          setn8(acc4, raw[j][0], (float)(int)((unsigned)info[j] & 31u));
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-#pragma unroll
-          for (int k = 0; k < V; ++k) addn8(acc4, raw[j][k], (float)(int)(((unsigned)info[j] >> (5 * k)) & 31u));
+          for (int k = 1; k < V; ++k) addn8(acc4, raw[j][k], (float)(int)(((unsigned)info[j] >> (5 * k)) & 31u));
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
         }
@@ -323,10 +332,10 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
           float acc4[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc4[q] = 0.f;
-          const int inf = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 4 + xq4);      // (j is a run-time index here)
+          const int inf = __builtin_amdgcn_readlane(binfo, (cy8 * 2 + by) * 16 + xq4);      // (j is a run-time index here)
           const int kind = (inf >> 20) & 3;
           if (kind == 0) {
-            const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 4 + xq4);
+            const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)blist, (cy8 * 2 + by) * 16 + xq4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               addn8(acc4, rows[((bw >> (4 * k)) & 15u) * 64 + lane], (float)(int)(((unsigned)inf >> (5 * k)) & 31u));

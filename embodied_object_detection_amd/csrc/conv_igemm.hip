@@ -18,6 +18,7 @@ using namespace eodconv;
 // thread and slab (Cout % 4 == 0); VEC = 1 for the odd-width heads.  32-bit indices (check_desc bounds rows x Cout below 2^31).
 template <int VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
+  EOD_CHAIN_PRIO();
   int M = p.M;
   if (p.m_count) {
     const int c = *p.m_count;

@@ -65,6 +65,7 @@ struct LevelOff {
 #define GN_ROWS 32
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, LevelOff lo, int C, int groups,
                                                           double* __restrict__ partial) {
+  EOD_CHAIN_PRIO();
   // chunk -> level
   int level = 0, first_chunk = 0;
   for (;;) {
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, LevelOff lo, int C, int groups, float eps,
                                                            float* __restrict__ stats) {
+  EOD_CHAIN_PRIO();
   // one wave per (level, group): lanes stride over the chunks, fixed-shape shuffle tree -> deterministic
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              LevelOff lo, int C, int groups, const float* __restrict__ stats) {
+  EOD_CHAIN_PRIO();
   const int c4 = C >> 2;
   const int cpg = C / groups;
   const size_t total = (size_t)lo.off[lo.levels] * c4;

@@ -11,6 +11,10 @@
 #define EOD_ERR_CAPACITY (-5)
 
 #define EOD_WAVE 64
+// First statement of every small kernel of the latency-bound chains (proposal decoding, cascade glue, selection, memory write):
+// their waves share SIMDs with resident GEMM waves of the concurrently running mask passes; with a raised wave priority the
+// instruction arbiter serves them first (the GEMM waves keep the default 0).
+#define EOD_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -21,6 +21,7 @@ constexpr int ZS_MAX_C = 24;
 __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
                                                            const int* __restrict__ count, int R_cap, int D, int C1, float temp) {
+  EOD_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
   const int R = dyn_rows(count, R_cap);
   if ((int)(blockIdx.x * 4) >= R) return;    // whole workgroup beyond the count
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, float* __restrict__ out,
                                     const int* __restrict__ count, int R_cap, float wx, float wy, float ww, float wh, int clip,
                                     float img_w, float img_h) {
+  EOD_CHAIN_PRIO();
   const int R = dyn_rows(count, R_cap);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
@@ -95,6 +97,7 @@ __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, co
 
 __global__ void cascade_scores_kernel(float* __restrict__ prob_acc, const float* __restrict__ prop_scores, const int* __restrict__ count,
                                       int R_cap, int C1, float inv_stages) {
+  EOD_CHAIN_PRIO();
   const int R = dyn_rows(count, R_cap);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R * C1) return;
@@ -106,6 +109,7 @@ __global__ void cascade_scores_kernel(float* __restrict__ prob_acc, const float*
 __global__ __launch_bounds__(256) void memory_scores_kernel(const float* __restrict__ featn, const float* __restrict__ zs,
                                                              const float* __restrict__ ps, float* __restrict__ scores,
                                                              const int* __restrict__ count, int R_cap, int D, int C1) {
+  EOD_CHAIN_PRIO();
   const int R = dyn_rows(count, R_cap);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

@@ -148,6 +148,7 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap
 __global__ __launch_bounds__(512) void mw_unique_rows_kernel(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
                                                               int R_cap, int* __restrict__ inst_rows, int* __restrict__ k_u,
                                                               int* __restrict__ k_out) {
+  EOD_CHAIN_PRIO();
   __shared__ int flag[512];
   const int t = threadIdx.x;
   flag[t] = 0;
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restric
                                                            const int* __restrict__ proj, int H, int W, int n_cells, float thr,
                                                            unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
                                                            int* __restrict__ err) {
+  EOD_CHAIN_PRIO();
   const int K = *k_u;
   if (K == 0) return;
   bool bad = false;
@@ -259,6 +261,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
 
 __global__ __launch_bounds__(1024) void mw_count_pixels_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
                                                                 int* __restrict__ block_cnt) {
+  EOD_CHAIN_PRIO();
   if (*k_u == 0) return;
   const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
   int c = 0;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(1024) void mw_count_pixels_kernel(const unsigned ch
 __global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
                                                           const int* __restrict__ proj, int n_cells, const int* __restrict__ block_cnt,
                                                           int* __restrict__ sel_pix, int* __restrict__ n_sel, int* __restrict__ cell_mark) {
+  EOD_CHAIN_PRIO();
   if (*k_u == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_sel = 0;
     return;
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __
 
 __global__ __launch_bounds__(1024) void mw_count_cells_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
                                                                int* __restrict__ block_cnt) {
+  EOD_CHAIN_PRIO();
   if (*k_u == 0) return;
   const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
   int c = 0;
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(1024) void mw_count_cells_kernel(const int* __restr
 __global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
                                                          const int* __restrict__ block_cnt, int* __restrict__ cell_slot,
                                                          int* __restrict__ slot_cell, int* __restrict__ n_slots) {
+  EOD_CHAIN_PRIO();
   if (*k_u == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_slots = 0;
     return;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ 
 
 __global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ wtab, int* __restrict__ slot_cnt,
                                                              const int* __restrict__ n_slots, int K_cap) {
+  EOD_CHAIN_PRIO();
   const size_t total = (size_t)(*n_slots) * K_cap;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) wtab[i] = 0;
   const int ns = *n_slots;
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restr
                                                              const unsigned char* __restrict__ cover, const int* __restrict__ proj,
                                                              int n_cells, const int* __restrict__ cell_slot, int W, int K_cap, float thr,
                                                              long long* __restrict__ wtab, int* __restrict__ slot_cnt) {
+  EOD_CHAIN_PRIO();
   const int K = *k_u;
   const int S = *n_sel;
   const int lane = threadIdx.x & 63;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restri
                                                         const int* __restrict__ slot_cell, const int* __restrict__ n_slots,
                                                         const float* __restrict__ featn, const int* __restrict__ inst_rows,
                                                         const int* __restrict__ k_u, int K_cap, int D, float* __restrict__ mem) {
+  EOD_CHAIN_PRIO();
   const int K = *k_u;
   const int NS = *n_slots;
   const int lane = threadIdx.x & 63;
@@ -427,6 +436,7 @@ __global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restri
 // cleared by eod_memory_normalize_dirty_f16.  Cells written by mw_apply are a subset (sampled pixels are pixels of the frame).
 __global__ __launch_bounds__(256) void mw_obs_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark, const int* __restrict__ k_u,
                                                       int N, float* __restrict__ obs, int* __restrict__ dirty) {
+  EOD_CHAIN_PRIO();
   if (*k_u == 0) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     if (cell_flag[i]) {

@@ -38,6 +38,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* __restrict__ mem, const float* __restrict__ obs,
                                                                    int* __restrict__ dirty, __half* __restrict__ out, int n_cells) {
+  EOD_CHAIN_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n_groups = (n_cells + 63) >> 6;
@@ -171,6 +172,7 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 template <bool TORCH_ORDER>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
                                                            int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
+  EOD_CHAIN_PRIO();
   static_assert(GP_CAP <= 16, "slot ids must fit a nibble");
   // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
   extern __shared__ __align__(1024) unsigned char smem_raw[];
@@ -322,6 +324,8 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       };
       if (kinds == 0 && nmax <= 2) {
         listed(std::integral_constant<int, 2>{});
+      } else if (kinds == 0 && nmax == 3) {
+        listed(std::integral_constant<int, 3>{});
       } else if (kinds == 0) {
         listed(std::integral_constant<int, 4>{});
       } else {
@@ -468,6 +472,7 @@ struct ProjArgs {
 __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Wsplit,
                                                             const float* __restrict__ sinv, const float* __restrict__ bias,
                                                             float* __restrict__ P, ProjArgs a) {
+  EOD_CHAIN_PRIO();
   const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int lvl = t >= a.tile_off[2] ? 2 : (t >= a.tile_off[1] ? 1 : 0);
   const int row0 = a.level_off[lvl] + (t - a.tile_off[lvl]) * 64;

@@ -26,6 +26,7 @@ struct RoiArgs {
 };
 
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
+  EOD_CHAIN_PRIO();
   int R = p.R_cap;
   if (p.count) {
     const int c = *p.count;

@@ -97,6 +97,7 @@ __device__ __forceinline__ int next_pow2(int n) {
 // label, IoU > thr).  Word bj of 64 consecutive rows is then 512 contiguous bytes, which is what the scan reads.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ labels,
                                                        const int* __restrict__ n_ptr, int nb, float thr, u64* __restrict__ mask) {
+  EOD_CHAIN_PRIO();
   const int n = *n_ptr;
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__
                                                         const int* __restrict__ labels, const int* __restrict__ rows,
                                                         const int* __restrict__ n_ptr, int nb, const u64* __restrict__ mask,
                                                         int max_keep, int keep_ties, int* __restrict__ keep_idx, ScanOut o) {
+  EOD_CHAIN_PRIO();
   const int n = *n_ptr;
   const int tid = threadIdx.x;
   __shared__ u64 sh_removed;
@@ -291,6 +293,7 @@ struct CnArgs {
 // one block per level: per-level top-k by score (E = 8: levels up to 8192 positions, E = 16: up to 16384)
 template <int E>
 __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
+  EOD_CHAIN_PRIO();
   __shared__ u64 xch[1024 * E];
   __shared__ int sh_cnt;
   const int level = blockIdx.x;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
 // 1000 + 1000 + <=1000 + ... <= 4096 candidates with half the sort of E = 8)
 template <int E>
 __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_sorted) {
+  EOD_CHAIN_PRIO();
   __shared__ u64 xch[1024 * E];
   const int total_slots = p.pk_off[p.levels];
   u64 v[E];
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
                                                                const int* __restrict__ count, int R_cap, int C1, float img_w,
                                                                float img_h, float thr, float* sorted_boxes, float* sorted_scores,
                                                                int* sorted_labels, int* sorted_rows, int* n_sorted) {
+  EOD_CHAIN_PRIO();
   constexpr int E = 8;
   __shared__ u64 xch[1024 * E];
   __shared__ int sh_cnt;

@@ -61,14 +61,18 @@ class BatchedSequences:
         torch.cuda.empty_cache()                 # the duplicate weight uploads of scenes 1.. are released
         self.device = self.scenes[0].device
         self.streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(batch)]
+        self.trunk_stream = torch.cuda.Stream(device=self.device, priority=-1)
         self._ev_in = torch.cuda.Event()
         self._ev_trunk = torch.cuda.Event()
-        self._ev_done = [torch.cuda.Event() for _ in range(batch)]
+        self._ev_done = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(batch)]      # [scene][step parity]
         for m in self.scenes:
             # the trunk comes from the batched pass; inside a scene the box cascade / memory write still run beside the mask passes
             # (`intra_scene_overlap`), the scenes overlap each other on their own streams
             m.prefetch_trunk = False
         self.intra_scene_overlap = False     # measured at 960x960, B = 4: 121.6 frames/s in order vs 89.5 with the shared side streams
+        # the batched trunk of step t + 1 depends on the images only: it runs on its own stream beside the scenes' chains of step t
+        # (the batch's form of the single-sequence look-ahead) instead of as a barrier between two steps
+        self.trunk_lookahead = True
 
     def __call__(self, episodes: List[List[dict]]):
         return self.forward(episodes)
@@ -102,16 +106,34 @@ class BatchedSequences:
         outs: List[List[dict]] = [[] for _ in range(B)]
         pending: List[List] = [[] for _ in range(B)]
         cur = torch.cuda.current_stream(self.device)
+        ts = self.trunk_stream if self.trunk_lookahead else cur
+
+        def enqueue_trunk(t: int):
+            """the batched trunk of step t on `ts`; it overwrites, for every scene, the pyramid set of frame t - 3"""
+            frames = [episodes[b][t] for b in range(B)]
+            for b, m in enumerate(self.scenes):
+                # with the look-ahead, frame t - 1 is only being enqueued now; what must be over is frame t - 2 (scenes run their
+                # frames in order, so its event covers frame t - 3, the last user of that set); without it, frame t - 1
+                if t >= (2 if self.trunk_lookahead else 1):
+                    ts.wait_event(self._ev_done[b][t % 2 if self.trunk_lookahead else (t - 1) % 2])
+                rd = m._pyr_reader.get((m._pyramid + 1) % 3)
+                if rd is not None:
+                    ts.wait_event(rd)                    # a trailing detection pass may still read that set
+            with torch.cuda.stream(ts):
+                self._batched_trunk(frames)
+                self._ev_trunk.record(ts)
+
+        if self.trunk_lookahead:
+            self._ev_in.record(cur)
+            ts.wait_event(self._ev_in)
+        enqueue_trunk(0)
         for t in range(T):
             frames = [episodes[b][t] for b in range(B)]
-            # the batched trunk runs on the caller's stream once every scene has finished with the pyramid set it overwrites
-            for b in range(B):
-                cur.wait_event(self._ev_done[b])
-            self._batched_trunk(frames)
-            self._ev_trunk.record(cur)
             for b, (m, f) in enumerate(zip(self.scenes, frames)):
                 s = self.streams[b]
                 s.wait_event(self._ev_trunk)
+                if t == 0 and self.trunk_lookahead:
+                    s.wait_event(self._ev_in)
                 with torch.cuda.stream(s):
                     if f["memory_reset"]:
                         m.reset_memory(int(episodes[b][0]["memory"].shape[0]))
@@ -122,13 +144,17 @@ class BatchedSequences:
                     m.overlap_branches = self.intra_scene_overlap
                     m.inference_frame(f, refresh_memory_snapshot=refresh, materialize=False)
                     pending[b].append(m._post_ticket())
-                    self._ev_done[b].record(s)
-                    if len(pending[b]) == 3:
+                    self._ev_done[b][t % 2].record(s)
+            if t + 1 < T:
+                enqueue_trunk(t + 1)
+            for b, m in enumerate(self.scenes):
+                if len(pending[b]) == 3:
+                    with torch.cuda.stream(self.streams[b]):
                         outs[b].append({"instances": m._materialize(pending[b].pop(0))})
         for b, m in enumerate(self.scenes):
             with torch.cuda.stream(self.streams[b]):
                 for ticket in pending[b]:
                     outs[b].append({"instances": m._materialize(ticket)})
-            cur.wait_event(self._ev_done[b])
+            cur.wait_event(self._ev_done[b][(T - 1) % 2])
         torch.cuda.current_stream(self.device).synchronize()
         return outs

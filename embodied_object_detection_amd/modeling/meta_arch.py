@@ -115,6 +115,10 @@ class CustomRCNNRecurrent:
         # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
         # the mask (an fp32 matmul on a half-masked stream takes the same time).
         self.early_memory_selection = False
+        # where the (deferred, low-priority) detection mask pass may start: "cascade" (as soon as the detections exist),
+        # "proposal_masks" / "memory_write" (behind this frame's critical chain: it then runs beside the NEXT frame's
+        # latency-bound front instead of beside this frame's proposal masks and memory write)
+        self.detection_pass_after = "cascade"
         self._det_stream = None
         self._ev_call = None
         self._ev_det = [None] * RESULT_SETS   # per result set: detection pass + paste finished
@@ -443,8 +447,11 @@ class CustomRCNNRecurrent:
                     self._ev_sel.record(mem_stream)
                     self._mark("mem_select", mem_stream)
             pipelined = self.pipeline_detection_pass
-            if pipelined:
+            det_after = self.detection_pass_after if (pipelined and lazy and update_mem and self.overlap_memory_write) else "cascade"
+            if pipelined and det_after == "cascade":
                 self._enqueue_detection_pass(views, shapes, det, (H, W), frame)
+            elif pipelined:
+                pass        # enqueued below, behind the proposal masks / the memory write
             else:
                 main.wait_event(self._ev_box)
                 self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
@@ -455,6 +462,8 @@ class CustomRCNNRecurrent:
                                                                 bufs=self.roi_heads.proposal_pass_buffers())
                 self._ev_pm.record(main)
                 self._mark("prop_masks", main)
+            if pipelined and det_after == "proposal_masks":
+                self._enqueue_detection_pass(views, shapes, det, (H, W), frame, after=self._ev_pm)
             if update_mem and self.overlap_memory_write:
                 # the memory write needs the proposal masks (main stream) and the selection (side stream): it runs on the side
                 # stream beside the detection mask pass; the main stream joins at the end of the frame
@@ -466,6 +475,8 @@ class CustomRCNNRecurrent:
                     self._ev_mem.record(mem_stream)
                     self._mark("mem_write", mem_stream)
                 mem_done = True
+                if pipelined and det_after == "memory_write":
+                    self._enqueue_detection_pass(views, shapes, det, (H, W), frame, after=self._ev_mem)
         else:
             pipelined = False
             det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
@@ -523,7 +534,7 @@ class CustomRCNNRecurrent:
         ops.paste_masks(self.roi_heads.det_masks, P["boxes"], P["src"], P["count"], self.roi_heads.topk, out_h, out_w,
                         self.mask_threshold, P["masks"])
 
-    def _enqueue_detection_pass(self, views, shapes, det, image_hw, frame):
+    def _enqueue_detection_pass(self, views, shapes, det, image_hw, frame, after=None):
         """`forward_with_given_boxes` (detic_roi_heads.py:257) + `detector_postprocess` + paste (custom_rcnn.py:579-580) of this
         frame on the detection stream (lowest priority: its GEMMs fill whatever the latency-bound chains of the frame -- and of
         the next frame -- leave idle)."""
@@ -534,6 +545,8 @@ class CustomRCNNRecurrent:
         det_boxes, det_scores, det_classes, det_rows, det_count = det
         k = self._post_slot
         ds.wait_event(self._ev_box)
+        if after is not None:
+            ds.wait_event(after)
         with torch.cuda.stream(ds):
             self._mark("det_pass_begin", ds)
             self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)

@@ -82,48 +82,81 @@ def episode_offsets(frames_per_scene: Sequence[int], episode_len: int = 20) -> L
     return off
 
 
+def _record_episode(rec: "RecordBuffer", sid: int, im_id: int, idx: int, inputs, outputs, every: int) -> int:
+    """Detections (COCO maxDets 100) and ground truth of every `every`-th frame of one episode (train_mp3d.py:187-188)."""
+    outs = [outputs[i] for i in range(0, len(outputs), every)]
+    ins = [inputs[i] for i in range(0, len(inputs), every)]
+    for inp, out in zip(ins, outs):
+        inst = out["instances"]
+        n = min(len(inst), 100)                                     # COCO maxDets
+        if n:
+            b = inst.pred_boxes.tensor[:n].float().cpu().numpy()
+            s = inst.scores[:n].float().cpu().numpy()
+            c = inst.pred_classes[:n].cpu().numpy()
+            for j in range(n):
+                rec.add([KIND_DET, sid, im_id, float(c[j]), float(s[j]), *b[j].tolist(), idx])
+        gt = inp.get("instances")
+        if gt is not None:
+            if isinstance(gt, dict):                                   # synthetic frames
+                gboxes, gcls = gt["gt_boxes"], gt["gt_classes"]
+            else:                                                       # Instances (map_mp3d_batch_to_coco)
+                gboxes, gcls = gt.gt_boxes.tensor, gt.gt_classes
+            gb = gt_to_coco_xyxy(gboxes)
+            gc = gcls.tolist()
+            for j in range(len(gc)):
+                rec.add([KIND_GT, sid, im_id, float(gc[j]), 0.0, *gb[j].tolist(), idx])
+        im_id += 1
+    return im_id
+
+
 def inference_on_scenes(model, scenes: Iterable, rank: int = 0, max_rows: int = 1 << 16, every: int = 5,
                         on_episode: Optional[Callable] = None, scene_episode_offset: Optional[Dict[int, int]] = None) -> Dict:
     """Run this rank's scenes; returns {'records': RecordBuffer, 'frames': n, 'seconds': t}.
 
     `scenes`: iterable of objects with `.seq_id` and `.episodes()` yielding lists of frame dicts (data/synthetic.py schema).
     Records carry (scene id, frame index) and the GLOBAL episode index, so the aggregate is identical however the scenes are
-    sharded (COCO's stable sorts break score ties by image order)."""
+    sharded (COCO's stable sorts break score ties by image order).
+
+    `model` is either the meta-architecture (`model([episode])`, one scene after the other, train_mp3d.py:186) or a
+    `modeling.batched.BatchedSequences` of B scenes: this rank's scenes then run B at a time in lock-step (BASELINE configs[4];
+    scenes are independent, so the records are the same set)."""
     rec = RecordBuffer(max_rows)
     frames = 0
     t0 = time.perf_counter()
-    for scene in scenes:
-        sid = int(scene.seq_id)
-        idx = (scene_episode_offset or {}).get(sid, 0)
-        im_id = 0
-        for inputs in scene.episodes():
-            outputs = model([inputs])                                      # train_mp3d.py:186
-            frames += len(inputs)
-            outs = [outputs[i] for i in range(0, len(outputs), every)]     # :187-188
-            ins = [inputs[i] for i in range(0, len(inputs), every)]
-            for inp, out in zip(ins, outs):
-                inst = out["instances"]
-                n = min(len(inst), 100)                                     # COCO maxDets
-                if n:
-                    b = inst.pred_boxes.tensor[:n].float().cpu().numpy()
-                    s = inst.scores[:n].float().cpu().numpy()
-                    c = inst.pred_classes[:n].cpu().numpy()
-                    for j in range(n):
-                        rec.add([KIND_DET, sid, im_id, float(c[j]), float(s[j]), *b[j].tolist(), idx])
-                gt = inp.get("instances")
-                if gt is not None:
-                    if isinstance(gt, dict):                                   # synthetic frames
-                        gboxes, gcls = gt["gt_boxes"], gt["gt_classes"]
-                    else:                                                       # Instances (map_mp3d_batch_to_coco)
-                        gboxes, gcls = gt.gt_boxes.tensor, gt.gt_classes
-                    gb = gt_to_coco_xyxy(gboxes)
-                    gc = gcls.tolist()
-                    for j in range(len(gc)):
-                        rec.add([KIND_GT, sid, im_id, float(gc[j]), 0.0, *gb[j].tolist(), idx])
-                im_id += 1
-            if on_episode is not None:
-                on_episode(idx, inputs, outputs)
-            idx += 1
+    lockstep = len(getattr(model, "scenes", ())) if hasattr(model, "trunk_lookahead") else 0
+    if lockstep > 1:
+        scenes = list(scenes)
+        for g in range(0, len(scenes), lockstep):
+            group = scenes[g:g + lockstep]
+            its = [iter(sc.episodes()) for sc in group]
+            sids = [int(sc.seq_id) for sc in group]
+            idxs = [(scene_episode_offset or {}).get(sid, 0) for sid in sids]
+            im_ids = [0] * len(group)
+            while True:
+                eps = [next(it, None) for it in its]
+                if all(e is None for e in eps):
+                    break
+                outs = model(eps + [None] * (lockstep - len(group)))
+                for k, e in enumerate(eps):
+                    if e is None:
+                        continue
+                    frames += len(e)
+                    im_ids[k] = _record_episode(rec, sids[k], im_ids[k], idxs[k], e, outs[k], every)
+                    if on_episode is not None:
+                        on_episode(idxs[k], e, outs[k])
+                    idxs[k] += 1
+    else:
+        for scene in scenes:
+            sid = int(scene.seq_id)
+            idx = (scene_episode_offset or {}).get(sid, 0)
+            im_id = 0
+            for inputs in scene.episodes():
+                outputs = model([inputs])                                      # train_mp3d.py:186
+                frames += len(inputs)
+                im_id = _record_episode(rec, sid, im_id, idx, inputs, outputs, every)
+                if on_episode is not None:
+                    on_episode(idx, inputs, outputs)
+                idx += 1
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     return {"records": rec, "frames": frames, "seconds": time.perf_counter() - t0}

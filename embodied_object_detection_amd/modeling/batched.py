@@ -49,8 +49,10 @@ def _share_weights(dst: CustomRCNNRecurrent, src: CustomRCNNRecurrent):
 
 
 class BatchedSequences:
-    """`BatchedSequences(cfg, B)(episodes)`: `episodes` = list of B frame lists of equal length (one per sequence); returns a list of
-    B output lists, each what `CustomRCNNRecurrent.forward([episode_b])` returns."""
+    """`BatchedSequences(cfg, B)(episodes)`: `episodes` = list of B frame lists, one per sequence (`None` or `[]`: that sequence
+    sits this call out; lengths may differ: a sequence whose episode has ended drops out of the lock-step, the trunk then runs
+    with N = the number still active); returns a list of B output lists, each what `CustomRCNNRecurrent.forward([episode_b])`
+    returns."""
 
     def __init__(self, cfg, batch: int, state_dict: Optional[Dict[str, torch.Tensor]] = None):
         if batch < 1:
@@ -77,20 +79,22 @@ class BatchedSequences:
     def __call__(self, episodes: List[List[dict]]):
         return self.forward(episodes)
 
-    def _batched_trunk(self, frames: List[dict]):
-        """One N = B pass of preprocess + ResNet-50 + FPN top-down; every scene's P3..P5 are copied into the pyramid set its next
-        frame reads, and the scene is told that its trunk has been computed ahead."""
+    def _batched_trunk(self, scenes: List[CustomRCNNRecurrent], frames: List[dict]):
+        """One N = len(frames) pass of preprocess + ResNet-50 + FPN top-down; every scene's P3..P5 are copied into the pyramid set
+        its next frame reads, and the scene is told that its trunk has been computed ahead."""
         m0 = self.scenes[0]
         B = len(frames)
         H, W = int(frames[0]["image"].shape[-2]), int(frames[0]["image"].shape[-1])
+        if any((int(f["image"].shape[-2]), int(f["image"].shape[-1])) != (H, W) for f in frames):
+            raise ValueError("the frames of one lock-step must have one size")
         xs = []
-        for m, f in zip(self.scenes, frames):
+        for m, f in zip(scenes, frames):
             x4, Hp, Wp = ops.preprocess_image(m._device_image(f), m.pixel_mean, m.pixel_std)
             xs.append(x4)
         x = torch.cat(xs, dim=0)                 # [B,Hp,Wp,4] (a device copy; no arithmetic)
         c = m0.backbone.bottom_up.forward(x, Hp, Wp, N=B)
         p345 = m0.backbone.top_down_batched(c, Hp, Wp, B)
-        for b, (m, f) in enumerate(zip(self.scenes, frames)):
+        for b, (m, f) in enumerate(zip(scenes, frames)):
             nxt = (m._pyramid + 1) % 3
             shapes, off, feats, views, pooled = m.backbone._plan(Hp, Wp, nxt)
             for l in range(3):
@@ -98,20 +102,23 @@ class BatchedSequences:
             m._prefetched = (f["image"], Hp, Wp)
         return Hp, Wp
 
-    def forward(self, episodes: List[List[dict]]):
+    def forward(self, episodes: List[Optional[List[dict]]]):
         B = len(self.scenes)
-        if len(episodes) != B or len({len(e) for e in episodes}) != 1:
-            raise ValueError(f"need {B} episodes of equal length")
-        T = len(episodes[0])
+        if len(episodes) != B:
+            raise ValueError(f"need {B} episodes (None for a sequence that sits this call out)")
+        episodes = [e if e else [] for e in episodes]
+        T = max(len(e) for e in episodes)
         outs: List[List[dict]] = [[] for _ in range(B)]
         pending: List[List] = [[] for _ in range(B)]
         cur = torch.cuda.current_stream(self.device)
         ts = self.trunk_stream if self.trunk_lookahead else cur
+        active = lambda t: [b for b in range(B) if t < len(episodes[b])]
 
         def enqueue_trunk(t: int):
-            """the batched trunk of step t on `ts`; it overwrites, for every scene, the pyramid set of frame t - 3"""
-            frames = [episodes[b][t] for b in range(B)]
-            for b, m in enumerate(self.scenes):
+            """the batched trunk of step t on `ts`; it overwrites, for every active scene, the pyramid set of its frame t - 3"""
+            act = active(t)
+            for b in act:
+                m = self.scenes[b]
                 # with the look-ahead, frame t - 1 is only being enqueued now; what must be over is frame t - 2 (scenes run their
                 # frames in order, so its event covers frame t - 3, the last user of that set); without it, frame t - 1
                 if t >= (2 if self.trunk_lookahead else 1):
@@ -120,19 +127,19 @@ class BatchedSequences:
                 if rd is not None:
                     ts.wait_event(rd)                    # a trailing detection pass may still read that set
             with torch.cuda.stream(ts):
-                self._batched_trunk(frames)
+                self._batched_trunk([self.scenes[b] for b in act], [episodes[b][t] for b in act])
                 self._ev_trunk.record(ts)
 
+        self._ev_in.record(cur)
         if self.trunk_lookahead:
-            self._ev_in.record(cur)
             ts.wait_event(self._ev_in)
-        enqueue_trunk(0)
+        if T:
+            enqueue_trunk(0)
         for t in range(T):
-            frames = [episodes[b][t] for b in range(B)]
-            for b, (m, f) in enumerate(zip(self.scenes, frames)):
-                s = self.streams[b]
+            for b in active(t):
+                m, f, s = self.scenes[b], episodes[b][t], self.streams[b]
                 s.wait_event(self._ev_trunk)
-                if t == 0 and self.trunk_lookahead:
+                if t == 0:
                     s.wait_event(self._ev_in)
                 with torch.cuda.stream(s):
                     if f["memory_reset"]:
@@ -155,6 +162,7 @@ class BatchedSequences:
             with torch.cuda.stream(self.streams[b]):
                 for ticket in pending[b]:
                     outs[b].append({"instances": m._materialize(ticket)})
-            cur.wait_event(self._ev_done[b][(T - 1) % 2])
+            if episodes[b]:
+                cur.wait_event(self._ev_done[b][(len(episodes[b]) - 1) % 2])
         torch.cuda.current_stream(self.device).synchronize()
         return outs

@@ -122,3 +122,24 @@ def test_config5_batch_of_4_equals_4_single_runs(synthetic_sd):
     """BASELINE.json configs[4]: 4 sequences batched per GPU at 960x960 with a 512x512 memory grid; detections, masks and memory
     state of every sequence are bitwise those of its own single-sequence run."""
     _batch_equals_singles(synthetic_sd, 960, 960, 512, 0.08, 4, 2)
+
+
+def test_eval_loop_in_lockstep_gives_the_same_records(synthetic_sd):
+    """`inference_on_scenes` with a `BatchedSequences` of 2: three scenes of different lengths (25, 40 and 12 frames: ragged episodes,
+    one scene without a partner) produce exactly the records of the one-scene-after-the-other loop (`train_mp3d.py:186`)."""
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.engine.eval_loop import episode_offsets, inference_on_scenes
+    from embodied_object_detection_amd.modeling.batched import BatchedSequences
+    lens = [25, 40, 12]
+    mk = lambda: [SyntheticSequence(70 + s, H=128, W=160, n_frames=n, map_w=24, map_h=24, cell=0.5) for s, n in enumerate(lens)]
+    offs = {70 + s: o for s, o in enumerate(episode_offsets(lens))}
+    seq = inference_on_scenes(build_model(_cfg(), synthetic_sd), mk(), 0, max_rows=1 << 16, every=5, scene_episode_offset=offs)
+    seen = []
+    par = inference_on_scenes(BatchedSequences(_cfg(), 2, synthetic_sd), mk(), 0, max_rows=1 << 16, every=5, scene_episode_offset=offs,
+                              on_episode=lambda idx, inp, out: seen.append((idx, len(inp), len(out))))
+    assert seq["frames"] == par["frames"] == sum(lens)
+    assert sorted(seen) == [(0, 20, 20), (1, 5, 5), (2, 20, 20), (3, 20, 20), (4, 12, 12)]
+    a, b = sorted(seq["records"].rows), sorted(par["records"].rows)
+    assert len(a) == len(b) > 0
+    assert a == b

@@ -108,7 +108,10 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     The build moves far fewer (dirty rows only, distinct rows per tile once); `achieved` = algorithmic bytes / measured time."""
     from embodied_object_detection_amd import ops
     f = frames[idx]
-    model.inference_frame(frames[idx - 1], refresh_memory_snapshot=True, materialize=False)   # leaves this frame's dirty rows behind
+    follow = model.snapshot_follows_write
+    model.snapshot_follows_write = False       # this frame's write only MARKS its rows: the stand-alone normalise has work to do
+    model.inference_frame(frames[idx - 1], refresh_memory_snapshot=True, materialize=False)
+    model.snapshot_follows_write = follow
     torch.cuda.synchronize()
     snap = model._dirty.clone()
     n_dirty = int(snap.sum().item())
@@ -145,6 +148,25 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
           timed(lambda: model.backbone.merge(pooled, feats, H, W, model.backbone.map_feature_weight, "sum"))]
     restore()
     ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16)
+    model._dirty_pending = False
+    # The product path (TEST_TYPE default / episodic) has no normalise launch: the memory write refreshes the snapshot rows of the
+    # cells it touches (EodMemWriteDesc.snapshot_f16).  Its cost = the same write replayed with and without the snapshot.
+    standalone_a4 = us[0]
+    folded = None
+    if getattr(model, "_last_write", None) is not None and (follow if follow is not None else model.test_type in ("default", "episodic")):
+        keep = (model.implicit_memory.clone(), model.observations.clone(), model._mem_f16.clone())
+        pb, pm, rows_, cnt_, pj = model._last_write
+        wr = model._writer
+        scratch = torch.zeros_like(model._dirty)
+        w_mark = lambda: wr(model.roi_heads.featn0, pb, pm, rows_, cnt_, pj, model.implicit_memory, model.observations, dirty=scratch)
+        w_snap = lambda: wr(model.roi_heads.featn0, pb, pm, rows_, cnt_, pj, model.implicit_memory, model.observations,
+                            snapshot=model._mem_f16)
+        t_mark = [timed(w_mark) for _ in range(2)]
+        t_snap = [timed(w_snap) for _ in range(2)]
+        folded = max(0.0, min(t_snap) - min(t_mark))
+        model.implicit_memory.copy_(keep[0]); model.observations.copy_(keep[1]); model._mem_f16.copy_(keep[2])
+        us[0] = folded
+        names = ("snapshot rows inside eod_memory_write (mw_obs_snapshot_kernel - mw_obs_kernel)",) + names[1:]
     rows = sum(h * w for (h, w) in shapes[:3])
     alg = 4 * H * W + n_cells * (512 * 4 + 4) + 2 * 256 * 4 * rows + 3 * 512 * 256 * 4
     tot = sum(us)
@@ -158,6 +180,7 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
         pass
     return {"bound": "hbm", "class": "memory read + fusion (a4 + a8)", "kernels": dict(zip(names, [round(u, 2) for u in us])),
             "traffic": traffic,
+            "a4_standalone_normalize_dirty_us": round(standalone_a4, 2),
             "avg_us_total": round(tot, 2), "algorithmic_bytes": alg, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBPS, 4), "dirty_rows_this_frame": n_dirty, "memory_cells": n_cells,
             "note": "HIP events around %d back-to-back launches of each kernel on one stream, after the timed region (median of %d "
@@ -488,6 +511,43 @@ def main():
                                   "frac_of_bf16_dense_peak_issued": round(6.0 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
                                   "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
             variants["bf16x3_split_mfma"] = v
+
+        # two independent sequences per GPU in lock-step (scenes are independent: `train_mp3d.py --scenes-in-lockstep 2`): the
+        # latency-bound chains of one scene run beside the dense passes of the other
+        if not distributed:
+            from embodied_object_detection_amd.modeling.batched import BatchedSequences
+            try:
+                pair = BatchedSequences(cfg, 2, sd)
+                seq2 = SyntheticSequence(1000 + rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell)
+                fr2 = []
+                for i in range(n_frames - 1):
+                    f = seq2.frame(i)
+                    f["image"] = f["image"].to(dev)
+                    f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
+                    fr2.append(f)
+                half = args.steps // 2
+                both = lambda lo, hi: [e[lo:hi] for e in (frames[:n_frames - 1], fr2)]
+                for e0 in range(0, args.warmup, EPISODE_LEN):
+                    pair(both(e0, min(args.warmup, e0 + EPISODE_LEN)))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n2 = 0
+                for e0 in range(args.warmup, args.warmup + half, EPISODE_LEN):
+                    o2 = pair(both(e0, min(args.warmup + half, e0 + EPISODE_LEN)))
+                    n2 += sum(len(o) for o in o2)
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t0
+                log(f"two sequences in lock-step: {el2:.3f} s for {n2} frames ({n2 / el2:.1f} frames/s)")
+                variants["two_sequences_in_lockstep"] = {
+                    "value": round(n2 / el2, 3), "unit": "frames/s", "ms_per_step": round(el2 / max(n2, 1) * 1e3, 3),
+                    "note": f"BatchedSequences(cfg, 2): two independent scenes per GPU, {half} steps of 2 frames, through the boundary "
+                            "(Instances materialised), episodes of 20; the memory-independent trunk runs once per step with N = 2 as "
+                            "a look-ahead, every scene keeps its own memory; per-scene results bitwise those of a single-scene run "
+                            "(tests/test_fullsize_gpu.py)"}
+                del pair, fr2
+                torch.cuda.empty_cache()
+            except Exception as e:      # never lose the headline to a variant
+                log(f"lock-step variant failed: {e!r}")
 
     roofline_hbm = None
     if rank == 0:

@@ -62,7 +62,7 @@ class EodMemWriteDesc(C.Structure):
         ("det_count", C.c_void_p), ("K_cap", C.c_int32), ("R_cap", C.c_int32), ("proj", C.c_void_p),
         ("H", C.c_int32), ("W", C.c_int32), ("D", C.c_int32), ("n_cells", C.c_int32), ("mask_thresh", C.c_float),
         ("mem", C.c_void_p), ("obs", C.c_void_p), ("k_out", C.c_void_p), ("workspace", C.c_void_p),
-        ("workspace_bytes", C.c_size_t), ("dirty", C.c_void_p), ("err_flags", C.c_void_p),
+        ("workspace_bytes", C.c_size_t), ("dirty", C.c_void_p), ("err_flags", C.c_void_p), ("snapshot_f16", C.c_void_p),
     ]
 
 

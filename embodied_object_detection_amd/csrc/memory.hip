@@ -10,6 +10,7 @@
 // Detic/detic/modeling/meta_arch/custom_rcnn.py:884-936); here the gather is fused with the pooling and the
 // write works on the sparse set of selected pixels only.
 #include "eod_common.h"
+#include "memory_rows.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 
@@ -448,6 +449,40 @@ __global__ __launch_bounds__(256) void mw_obs_kernel(int* __restrict__ cell_flag
   }
 }
 
+// The same counters, and in the same pass the fp16 snapshot rows of exactly the cells whose count changed (`snapshot`: the
+// table the next frame's gather reads; a cell written by mw_apply is a sampled pixel's cell, hence among them): what
+// eod_memory_normalize_dirty_f16 would do at the start of the next frame, without its launch and its second scan of the flags.
+// The 4 waves of a workgroup share one 64-cell group and split its rows (bit index mod 4).
+__global__ __launch_bounds__(256) void mw_obs_snapshot_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark,
+                                                               const int* __restrict__ k_u, int N, float* __restrict__ obs,
+                                                               const float* __restrict__ mem, __half* __restrict__ snapshot) {
+  EOD_CHAIN_PRIO();
+  if (*k_u == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n_groups = (N + 63) >> 6;
+  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int c = (g << 6) + lane;
+    int f = 0;
+    float o = 0.f;
+    if (c < N) {
+      f = cell_flag[c];
+      o = obs[c];
+    }
+    __syncthreads();                       // every wave has read the flags and counts before wave 0 updates them
+    if (f) o += 1.0f;
+    if (wave == 0 && c < N) {
+      if (f) {
+        obs[c] = o;
+        cell_flag[c] = 0;
+      }
+      cell_mark[c] = 0;
+    }
+    const unsigned long long bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
+    eod_snapshot_rows(mem, snapshot, g, bal, lane, [&](int bit) { return __shfl(o, bit, 64); });
+  }
+}
+
 inline int blocks_for(size_t work, int per = 256, int cap = 4096) {
   size_t b = (work + per - 1) / per;
   if (b < 1) b = 1;
@@ -518,6 +553,7 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
     return EOD_ERR_BAD_DIMS;
   const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap, d->K_cap);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
+  if (d->snapshot_f16 && (!eod_aligned16(d->snapshot_f16) || !eod_aligned16(d->mem))) return EOD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
   hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, s, d->det_rows, d->det_count, d->K_cap, d->R_cap, w.inst_rows, w.k_u,
@@ -536,8 +572,14 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
                      w.n_sel, w.cover, d->proj, d->n_cells, w.cell_slot, d->W, d->K_cap, d->mask_thresh, w.wtab, w.slot_cnt);
   hipLaunchKernelGGL(mw_apply_kernel, dim3(1024), dim3(256), 0, s, w.wtab, w.slot_cnt, w.slot_cell, w.n_slots, d->featn, w.inst_rows,
                      w.k_u, d->K_cap, d->D, d->mem);
-  hipLaunchKernelGGL(mw_obs_kernel, dim3(blocks_for((size_t)d->n_cells)), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u, d->n_cells,
-                     d->obs, d->dirty);
+  if (d->snapshot_f16) {
+    int groups = (d->n_cells + 63) / 64;
+    hipLaunchKernelGGL(mw_obs_snapshot_kernel, dim3(groups < 4096 ? groups : 4096), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u,
+                       d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16));
+  } else {
+    hipLaunchKernelGGL(mw_obs_kernel, dim3(blocks_for((size_t)d->n_cells)), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u, d->n_cells,
+                       d->obs, d->dirty);
+  }
   return eod_launch_status();
 }
 

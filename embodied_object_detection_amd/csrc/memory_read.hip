@@ -19,6 +19,7 @@
 //    of one fp32 rounding), every f16 x f16 product is exact in the fp32 accumulator: fp32-class result at 16/2 of the
 //    fp32-MFMA rate.  Out-of-range cell indices are clamped and flagged.
 #include "eod_common.h"
+#include "memory_rows.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -50,49 +51,8 @@ __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* _
     if (c < n_cells) f = dirty[c];
     __syncthreads();                       // every wave has read the flags before wave 0 clears them
     if (wave == 0 && f) dirty[c] = 0;
-    u64 bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
-    while (bal) {
-      // up to 4 dirty rows per step: their loads are independent and in flight together
-      int cells[4];
-      int nb = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (bal) {
-          cells[j] = (g << 6) + (int)__ffsll((long long)bal) - 1;
-          bal &= bal - 1;
-          ++nb;
-        } else {
-          cells[j] = cells[0];
-        }
-      }
-      f32x4 a[4], b[4];
-      float o[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* m = mem + (size_t)cells[j] * 512 + lane * 8;
-        a[j] = *reinterpret_cast<const f32x4*>(m);
-        b[j] = *reinterpret_cast<const f32x4*>(m + 4);
-        o[j] = obs[cells[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < nb) {
-          f32x4 x = a[j], y = b[j];
-          if (o[j] > 1.0f) {
-            x.x = __fdiv_rn(x.x, o[j]); x.y = __fdiv_rn(x.y, o[j]); x.z = __fdiv_rn(x.z, o[j]); x.w = __fdiv_rn(x.w, o[j]);
-            y.x = __fdiv_rn(y.x, o[j]); y.y = __fdiv_rn(y.y, o[j]); y.z = __fdiv_rn(y.z, o[j]); y.w = __fdiv_rn(y.w, o[j]);
-          }
-          __half2 h0 = __floats2half2_rn(x.x, x.y), h1 = __floats2half2_rn(x.z, x.w);
-          __half2 h2 = __floats2half2_rn(y.x, y.y), h3 = __floats2half2_rn(y.z, y.w);
-          uint4 pk;
-          pk.x = *reinterpret_cast<unsigned*>(&h0);
-          pk.y = *reinterpret_cast<unsigned*>(&h1);
-          pk.z = *reinterpret_cast<unsigned*>(&h2);
-          pk.w = *reinterpret_cast<unsigned*>(&h3);
-          *reinterpret_cast<uint4*>(out + (size_t)cells[j] * 512 + lane * 8) = pk;
-        }
-      }
-    }
+    const u64 bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
+    eod_snapshot_rows(mem, out, g, bal, lane, [&](int bit) { return obs[(g << 6) + bit]; });
   }
 }
 

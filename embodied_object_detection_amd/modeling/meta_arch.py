@@ -115,6 +115,7 @@ class CustomRCNNRecurrent:
         # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
         # the mask (an fp32 matmul on a half-masked stream takes the same time).
         self.early_memory_selection = False
+        self.front_event: Optional[torch.cuda.Event] = None      # one-stream schedule only: recorded after the box cascade
         # where the (deferred, low-priority) detection mask pass may start: "cascade" (as soon as the detections exist),
         # "proposal_masks" / "memory_write" (behind this frame's critical chain: it then runs beside the NEXT frame's
         # latency-bound front instead of beside this frame's proposal masks and memory write)
@@ -159,6 +160,11 @@ class CustomRCNNRecurrent:
         self._mem_f16: Optional[torch.Tensor] = None
         self._dirty: Optional[torch.Tensor] = None          # int32 [N]: rows of the fp16 snapshot that are out of date
         self._f16_valid = False
+        self._dirty_pending = False          # some write marked rows in `_dirty` that the snapshot does not have yet
+        # TEST_TYPE default / episodic read the memory as it stands at every frame (loader.py:289-293): the write refreshes the
+        # snapshot rows it invalidates itself (ops.MemoryWriter `snapshot`), no normalise launch at the start of the next frame.
+        # `longterm` freezes the snapshot after the first frame: there the write only marks the rows.
+        self.snapshot_follows_write: Optional[bool] = None      # None: decided by TEST_TYPE at every write
         self._err = torch.zeros((1,), dtype=torch.int32, device=self.device)   # device error word (EOD_FLAG_*), read with the count
         self._writer = None
         self._writer_key = None
@@ -197,6 +203,7 @@ class CustomRCNNRecurrent:
         _lib.check(lib.eod_fill_i32(self._mem_f16.data_ptr(), 0, self._mem_f16.numel() // 2, s), "fill")
         _lib.check(lib.eod_fill_i32(self._dirty.data_ptr(), 0, n_cells, s), "fill")
         self._f16_valid = True
+        self._dirty_pending = False
         self.semmap = None
 
     def invalidate_memory_snapshot(self):
@@ -207,11 +214,13 @@ class CustomRCNNRecurrent:
     def _refresh_memory_snapshot(self):
         """a4 + fp16 cast (create_implicit_memory + preprocess_spatial_memory): bring the resident fp16 table up to the state."""
         if self._f16_valid:
-            ops.memory_normalize_dirty_f16(self.implicit_memory, self.observations, self._dirty, self._mem_f16)
+            if self._dirty_pending:
+                ops.memory_normalize_dirty_f16(self.implicit_memory, self.observations, self._dirty, self._mem_f16)
         else:
             ops.memory_normalize_f16(self.implicit_memory, self.observations, out=self._mem_f16)
             _lib.check(_lib.load().eod_fill_i32(self._dirty.data_ptr(), 0, self._dirty.numel(), torch.cuda.current_stream().cuda_stream), "fill")
             self._f16_valid = True
+        self._dirty_pending = False
 
     def _ensure_frame_buffers(self, H: int, W: int, n_cells: int):
         key = (H, W, n_cells)
@@ -479,8 +488,13 @@ class CustomRCNNRecurrent:
                     self._enqueue_detection_pass(views, shapes, det, (H, W), frame, after=self._ev_mem)
         else:
             pipelined = False
-            det_boxes, det_scores, det_classes, det_rows, det_count = self.roi_heads.forward(
-                views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+            det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+            det_boxes, det_scores, det_classes, det_rows, det_count = det
+            if self.front_event is not None:
+                # the latency-bound front of the frame (memory fusion, tower, proposal decoding, cascade) ends here; what follows is
+                # dense (mask passes): BatchedSequences staggers its scenes on this point
+                self.front_event.record(torch.cuda.current_stream(self.device))
+            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
             if self.lazy_proposal_masks and update_mem:
                 # select the memory instances first, then run the mask head only on those proposals (same results: the other
                 # proposals' masks are never read, custom_rcnn.py:875-880)
@@ -566,8 +580,15 @@ class CustomRCNNRecurrent:
 
     def update_implicit_memory(self, prop_boxes, prop_scores, prop_count, prop_masks, proj, image_hw, mem_sel=None):
         rows, cnt = mem_sel if mem_sel is not None else self.select_memory_instances(prop_boxes, prop_scores, prop_count, image_hw)
-        self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations,
-                     dirty=self._dirty, err=self._err)
+        self._last_write = (prop_boxes, prop_masks, rows, cnt, proj)          # bench.py's HBM-class probe replays it
+        follow = self.snapshot_follows_write if self.snapshot_follows_write is not None else self.test_type in ("default", "episodic")
+        if follow and self._f16_valid and not self._dirty_pending:
+            self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations,
+                         err=self._err, snapshot=self._mem_f16)
+        else:
+            self._writer(self.roi_heads.featn0, prop_boxes, prop_masks, rows, cnt, proj, self.implicit_memory, self.observations,
+                         dirty=self._dirty, err=self._err)
+            self._dirty_pending = True
 
     def save_memory_snapshot(self, sequence_name: str) -> str:
         """`MODEL.TEST_SAVE_SEMMAP` dump (custom_rcnn.py:518-530): semmap, impicit_memory [sic], observations -> OUTPUT_DIR/memory/."""

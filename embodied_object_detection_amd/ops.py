@@ -446,9 +446,11 @@ class MemoryWriter:
         d.workspace, d.workspace_bytes, d.k_out = self.ws.data_ptr(), nbytes, self.k_out.data_ptr()
         self.desc = d
 
-    def __call__(self, featn, prop_boxes, prop_masks, det_rows, det_count, proj, mem, obs, dirty=None, err=None):
+    def __call__(self, featn, prop_boxes, prop_masks, det_rows, det_count, proj, mem, obs, dirty=None, err=None, snapshot=None):
+        """`snapshot` (fp16 [N,512], the table `memory_gather_pool` reads): refreshed in place for every cell whose observation
+        count changes (then `dirty` is not written); `dirty` alone: those cells are only marked for `memory_normalize_dirty_f16`."""
         d = self.desc
-        d.dirty, d.err_flags = _ptr(dirty), _ptr(err)
+        d.dirty, d.err_flags, d.snapshot_f16 = _ptr(dirty), _ptr(err), _ptr(snapshot)
         d.featn, d.prop_boxes, d.prop_masks = featn.data_ptr(), prop_boxes.data_ptr(), prop_masks.data_ptr()
         d.det_rows, d.det_count, d.proj, d.mem, d.obs = det_rows.data_ptr(), det_count.data_ptr(), proj.data_ptr(), mem.data_ptr(), obs.data_ptr()
         check(self.lib.eod_memory_write(C.byref(d), _stream()), "eod_memory_write")

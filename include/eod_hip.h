@@ -248,6 +248,9 @@ typedef struct EodMemWriteDesc {
   void* workspace; size_t workspace_bytes;
   int32_t* dirty;           /* [N] or NULL: set to 1 for every cell whose observation count changed (see normalize_dirty) */
   int32_t* err_flags;       /* [1] or NULL: EOD_FLAG_* */
+  uint16_t* snapshot_f16;   /* [N,512] fp16 or NULL: the normalised table eod_memory_gather_pool reads.  When given, the rows of
+                             * every cell whose observation count changed are refreshed by the write itself (the snapshot stays
+                             * current: no eod_memory_normalize_dirty_f16 launch before the next read) and `dirty` is not touched */
 } EodMemWriteDesc;
 size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap);
 int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream);

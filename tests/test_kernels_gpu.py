@@ -698,6 +698,23 @@ def test_memory_write_matches_oracle(dev, K, thresh):
         assert torch.equal(touched, touched_ref), "set of written cells must be bit-exact"
         close(mem_d, mem_ref, rtol=1e-5, atol=1e-4)
         assert bool(((mem_d.cpu() != mem0).any(dim=1) <= dirty.cpu().bool()).all()), "written cells are a subset of the dirty rows"
+        # write-through snapshot: the same call with `snapshot` leaves exactly the table normalize_dirty would produce, bit for
+        # bit, and the same memory / counters; rows of untouched cells keep whatever they held
+        snap_a = ops.memory_normalize_f16(mem0.to(dev), obs0.to(dev))
+        ops.memory_normalize_dirty_f16(mem_d, obs_d, dirty, snap_a)
+        assert int(dirty.sum().item()) == 0
+        mem_e, obs_e = mem0.to(dev), obs0.to(dev)
+        snap_b = ops.memory_normalize_f16(mem_e, obs_e)
+        marker = (obs_ref == obs0).nonzero().squeeze(1)[:5].to(dev)
+        snap_b[marker] = 7.0                                    # must survive: those cells did not change
+        snap_a[marker] = 7.0
+        wr(featn.to(dev), boxes.to(dev), masks.to(dev), dr.to(dev), cnt, proj.int().to(dev), mem_e, obs_e, err=err, snapshot=snap_b)
+        assert torch.equal(mem_e, mem_d) and torch.equal(obs_e, obs_d)
+        assert torch.equal(snap_b, snap_a), "write-through snapshot == incremental normalise of the dirty rows"
+        assert torch.equal(snap_b.cpu(), torch.where(((obs_ref == obs0)[:, None]) & (torch.arange(N)[:, None] >= 0) &
+                                                     torch.isin(torch.arange(N), marker.cpu())[:, None],
+                                                     torch.full((N, 512), 7.0).half(),
+                                                     OM.create_implicit_memory(mem_d.cpu(), obs_ref).half()))
     if K > 0:
         # an index image written for another map size: clamped and flagged, no fault; valid pixels behave as before
         bad = proj.clone()

@@ -22,6 +22,8 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first GPU call; see embodied_object_detection_amd/__init__.py
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -123,12 +125,16 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     # consumes its dirty flags, so every launch is preceded by the 160 KB copy that restores them and the copies alone are
     # timed the same way and subtracted.
     batch = 20
+    blocker = torch.empty((64 << 20,), dtype=torch.float32, device=proj.device)      # 256 MB fill: ~0.2 ms of a busy chip
 
     def timed(body, pre=None):
         out = []
         for _ in range(reps // 3):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(2_000_000)          # ~1 ms of spinning first: the host has queued the whole batch before it starts
+            # ~1 ms of work first, so that the host has queued the whole batch before it starts: streaming fills rather than a
+            # spin kernel, which leaves the chip idle long enough for its clocks to drop (in a frame these kernels follow dense work)
+            for _f in range(5):
+                blocker.fill_(0.0)
             a.record()
             for _i in range(batch):
                 if pre is not None:

@@ -460,6 +460,24 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
+  // The residual P (mode "sum") and the per-column scale / bias are requested FIRST: they arrive while the k-loop runs, instead of
+  // costing a load round trip after it (written as load-modify-store per element the compiler must also keep every load behind
+  // the previous store -- the addresses may alias -- and the epilogue becomes serial round trips).
+  const int col = col_tile * 32 + r;
+  const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
+  float old[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int rbase = row0 + 32 * m + 4 * hi;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int row = rbase + (i & 3) + 8 * (i >> 2);
+      row = row < row_end ? row : row_end - 1;            // clamped address instead of a divergent branch per element
+      old[m][i] = a.mode == 0 ? P[(size_t)row * 256 + col] : 0.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
   // Software pipeline, written out: the 4 fragment loads of k-step s + 3 are issued before the 4 MFMAs of k-step s (four
   // register sets).  Left to the compiler the loop became load -> s_waitcnt vmcnt(0) -> MFMA with ONE load in flight (50 us).
   constexpr int DEPTH = 4;
@@ -484,27 +502,16 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __res
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi.  All residual loads of a 32x32 tile are issued before
-  // its stores: written as load-modify-store per element, the compiler must keep every load behind the previous store (the
-  // addresses may alias) and the epilogue becomes serial round trips.
-  const int col = col_tile * 32 + r;
-  const float si = sinv[lvl * 256 + col], b = bias[lvl * 256 + col];
+  // epilogue: C/D layout col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 hi; the residuals were fetched before the loop.
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int rbase = row0 + 32 * m + 4 * hi;
-    float old[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int row = rbase + (i & 3) + 8 * (i >> 2);
-      row = row < row_end ? row : row_end - 1;            // clamped address instead of a divergent branch per element
-      old[i] = P[(size_t)row * 256 + col];
-    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = rbase + (i & 3) + 8 * (i >> 2);
       // same rounding steps as conv -> "* weight" -> "+ P_l" in the reference (timm.py:174,177,182): no contraction
       const float v = __fmul_rn(__fadd_rn(__fmul_rn(acc[m][i], si), b), a.weight);
-      if (row < row_end) P[(size_t)row * 256 + col] = a.mode == 0 ? __fadd_rn(v, old[i]) : v;
+      if (row < row_end) P[(size_t)row * 256 + col] = a.mode == 0 ? __fadd_rn(v, old[m][i]) : v;
     }
   }
 }

@@ -52,5 +52,5 @@ for (H, W) in ((640, 640), (960, 960)):
     proj = ops.MemoryProjector(ws, bs, dev)
     pooled = (torch.randn((ops.pooled_rows(H, W), 512), device=dev)).half()
     feats = torch.randn((ops.pooled_rows(H, W) + 200, 256), device=dev)
-    us = timed(lambda: proj(pooled, feats, H, W, 5.0, "mem_only"))
+    us = timed(lambda: proj(pooled, feats, H, W, 5.0, "sum"))
     print(f"{H}x{W} project_fuse {us:8.1f} us")

@@ -54,15 +54,21 @@ class BatchedSequences:
     with N = the number still active); returns a list of B output lists, each what `CustomRCNNRecurrent.forward([episode_b])`
     returns."""
 
-    def __init__(self, cfg, batch: int, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+    def __init__(self, cfg, batch: int, state_dict: Optional[Dict[str, torch.Tensor]] = None, concurrent_scenes: int = 0):
+        """`concurrent_scenes`: how many scenes may be in flight at once (scene b runs on stream b % concurrent_scenes; 0 = the
+        default, 2).  Two are enough to put one scene's latency-bound front beside the other's dense mask passes; more only evict
+        each other's tiles from the L2s.  Measured, B = 4: 960x960 158.6 / 157.0 / 150.2 frames/s and 640x640 210.4 / 204.7 / 201.1
+        frames/s with 2 / 3 / 4 in flight."""
         if batch < 1:
             raise ValueError("batch must be >= 1")
+        self.concurrent_scenes = int(concurrent_scenes)
         self.scenes: List[CustomRCNNRecurrent] = [CustomRCNNRecurrent(cfg, state_dict) for _ in range(batch)]
         for m in self.scenes[1:]:
             _share_weights(m, self.scenes[0])
         torch.cuda.empty_cache()                 # the duplicate weight uploads of scenes 1.. are released
         self.device = self.scenes[0].device
-        self.streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(batch)]
+        self._stream_pool = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(batch)]
+        self.streams = list(self._stream_pool)
         self.trunk_stream = torch.cuda.Stream(device=self.device, priority=-1)
         self._ev_in = torch.cuda.Event()
         self._ev_trunk = torch.cuda.Event()
@@ -114,6 +120,10 @@ class BatchedSequences:
             raise ValueError(f"need {B} episodes (None for a sequence that sits this call out)")
         episodes = [e if e else [] for e in episodes]
         T = max(len(e) for e in episodes)
+        first = next((e[0] for e in episodes if e), None)
+        if first is not None:
+            n_conc = self.concurrent_scenes if self.concurrent_scenes > 0 else 2
+            self.streams = [self._stream_pool[b % max(1, min(n_conc, B))] for b in range(B)]
         outs: List[List[dict]] = [[] for _ in range(B)]
         pending: List[List] = [[] for _ in range(B)]
         cur = torch.cuda.current_stream(self.device)

@@ -1,5 +1,6 @@
 """CPU-side tests (no GPU): the C ABI surface, the config / registry / checkpoint boundary, the evaluator, scene sharding and
 the single-collective aggregation over a world_size-2 gloo group."""
+import ctypes
 import os
 import re
 import socket
@@ -387,3 +388,30 @@ def test_bench_refuses_more_gpus_than_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_ctypes_descriptors_match_the_header_layout(tmp_path):
+    """The ctypes mirrors of the descriptor structs (`_lib.py`) against the C header compiled by gcc: same size, every field at
+    the same offset (a field added on one side only, or in another order, fails here and not as a silent misread on the GPU)."""
+    import shutil
+    import subprocess
+    from embodied_object_detection_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    structs = [getattr(_lib, n) for n in ("EodConvDesc", "EodProposalDesc", "EodDetDesc", "EodMemWriteDesc")]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "eod_hip.h")}"', "int main(void) {"]
+    for st in structs:
+        lines.append(f'  printf("{st.__name__} %zu\\n", sizeof({st.__name__}));')
+        for name, _t in st._fields_:
+            lines.append(f'  printf("{st.__name__}.{name} %zu\\n", offsetof({st.__name__}, {name}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c11", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st in structs:
+        assert int(got[st.__name__]) == ctypes.sizeof(st), st.__name__
+        for name, _t in st._fields_:
+            assert int(got[f"{st.__name__}.{name}"]) == getattr(st, name).offset, f"{st.__name__}.{name}"

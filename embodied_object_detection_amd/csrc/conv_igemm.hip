@@ -134,6 +134,22 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     int maxs = nchunks / 4;
     splitk = want < maxs ? want : maxs;
     if (splitk < 1) splitk = 1;
+  } else if (tiles >= 256 && tiles <= 1024 && d->m_count == nullptr && nchunks >= 18) {
+    // A few hundred tiles on 256 CUs: every workgroup is resident at once and a CU works through its workgroups' MFMAs one
+    // after the other, so the launch takes ceil(tiles / 256) tile times -- the CenterNet tower's 536 tiles take 3 where 2.09
+    // would do.  Split-K makes the units finer: time ~ ceil(tiles * s / 256) / s (+ ~0.12 of a tile for the slab reduce).
+    // Measured (tools/conv_bench.py tower, reduce included): 8 556 rows x 256 x 2304: s = 1 122-135 us, 2 109-118, 3 106-113,
+    // 4 110.  Static row counts only: a device-side count (the mask passes) is not known here, and their two variants
+    // (lazy / all proposals) must walk K in the same order to stay bitwise equal.
+    double best = 1e30;
+    for (int sct = 1; sct <= 4; ++sct) {
+      if (nchunks / sct < 9) break;
+      const double est = (double)((tiles * sct + 255) / 256) / sct + (sct > 1 ? 0.12 : 0.0);
+      if (est < best - 1e-9) {
+        best = est;
+        splitk = sct;
+      }
+    }
   }
   if (splitk > nchunks) splitk = nchunks;
   pl.cps = (nchunks + splitk - 1) / splitk;

@@ -36,6 +36,12 @@ def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=
                 print(name, t, sk, "ERR", ex)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "masktiles":
+    bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 11, 13, 12), iters=30)
+    bench("mask_fcn 45 rois", 45, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 11), iters=30)
+if which == "tower":
+    bench("tower-like 3x3 256 92x93", 1, 92, 93, 256, 256, 3, 1, 1, tiles=(13,), splitks=(1, 2, 3, 4, 6, 1, 2, 3), iters=40)
+    bench("prop-mask 45 rois", 45, 14, 14, 256, 256, 3, 1, 1, tiles=(13,), splitks=(1, 2, 3, 4, 1, 2), iters=40)
 if which in ("all", "mask"):
     bench("mask_fcn 256 rois", 256, 14, 14, 256, 256, 3, 1, 1, tiles=(3, 23, 13, 22, 21))
     bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(23, 13, 22, 21))

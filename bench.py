@@ -103,7 +103,7 @@ def pmc_traffic():
         return None
 
 
-def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
+def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30, gather_frames=None):
     """The HBM-bound class: memory read = a4 (obs-normalise + fp16 cast) + a8 (gather, cascaded pooling, three 1x1
     projections, x weight, fusion into P3..P5), on the frame's real data, each kernel bracketed by HIP events on the stream it is
     launched on, one stream, `reps` repetitions.  Algorithmic bytes are the reference algorithm's (full-map normalise, U = N):
@@ -151,8 +151,14 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     t_restore = timed(None, restore)
     us = [max(0.0, timed(lambda: ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16),
                          restore) - t_restore),
-          timed(lambda: ops.memory_gather_pool(model._mem_f16, proj, H, W, out=pooled, err=model._err)),
+          0.0,
           timed(lambda: model.backbone.merge(pooled, feats, H, W, model.backbone.map_feature_weight, "sum"))]
+    # the gather's cost depends on the frame's index image (how many distinct cells a 16x16 pixel quadrant and a 4x4 block see:
+    # 14.7-20.1 us over the frames of the synthetic scene, tools/gather_by_frame.py): mean over frames spread over the timed region
+    gf = [i for i in (gather_frames or [idx]) if 0 <= i < len(frames)]
+    per_frame = {i: timed(lambda p_=frames[i]["proj_indices"]: ops.memory_gather_pool(model._mem_f16, p_, H, W, out=pooled, err=model._err))
+                 for i in gf}
+    us[1] = float(np.mean(list(per_frame.values())))
     restore()
     ops.memory_normalize_dirty_f16(model.implicit_memory, model.observations, model._dirty, model._mem_f16)
     model._dirty_pending = False
@@ -188,6 +194,7 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30):
     return {"bound": "hbm", "class": "memory read + fusion (a4 + a8)", "kernels": dict(zip(names, [round(u, 2) for u in us])),
             "traffic": traffic,
             "a4_standalone_normalize_dirty_us": round(standalone_a4, 2),
+            "gather_pool_us_by_frame": {str(k): round(v, 2) for k, v in per_frame.items()},
             "avg_us_total": round(tot, 2), "algorithmic_bytes": alg, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBPS, 4), "dirty_rows_this_frame": n_dirty, "memory_cells": n_cells,
             "note": "HIP events around %d back-to-back launches of each kernel on one stream, after the timed region (median of %d "
@@ -560,7 +567,8 @@ def main():
     roofline_hbm = None
     if rank == 0:
         try:
-            roofline_hbm = hbm_class_probe(model, frames, args.warmup + 2, H, W, seq.n_cells)
+            spread = sorted({args.warmup + int(args.steps * q) for q in (0.1, 0.3, 0.5, 0.7, 0.9)})
+            roofline_hbm = hbm_class_probe(model, frames, args.warmup + 2, H, W, seq.n_cells, gather_frames=spread)
             log(f"hbm class: {roofline_hbm['kernels']} -> {roofline_hbm['achieved']} GB/s ({roofline_hbm['frac']})")
         except Exception as e:      # never lose the headline to the probe
             log(f"hbm probe failed: {e!r}")

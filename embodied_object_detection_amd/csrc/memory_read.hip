@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void normalize_dirty_f16_kernel(const float* _
 // ------------------------------------------------------------------------------------------------------
 // a8: gather + cascaded average pooling, one workgroup per 32x32 pixel tile
 // ------------------------------------------------------------------------------------------------------
+constexpr int GP_LIST = 8;      // a 4x4 block with up to this many distinct cells is summed as a (row, count) list
 constexpr int GP_CAP = 16;      // distinct rows cached per 16x16 quadrant (16 KiB of LDS per wave); pixels beyond it read L2/HBM directly
 
 // acc += float(half): ONE v_fma_mix_f32 (f16 source operand, * 1.0, f32 accumulate; a single rounding, identical to convert + add).
@@ -124,8 +125,8 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 }
 
 // TORCH_ORDER: every 4x4 block is summed pixel by pixel in torch's row-major order (bit-identical to F.avg_pool2d on every
-// input).  Default (false): a block with <= 4 distinct cells is summed as sum count x row in cache-slot order -- the same 16
-// numbers, <= 4 roundings instead of 15, identical to the sequential sum whenever that sum is exact (exponents inside the block
+// input).  Default (false): a block with <= 8 distinct cells is summed as sum count x row in cache-slot order -- the same 16
+// numbers, <= 8 roundings instead of 15, identical to the sequential sum whenever that sum is exact (exponents inside the block
 // span <= 9 bits per channel: 11-bit values + 4 bits of count in a 24-bit accumulator).  The kernel is instruction-issue bound
 // (in-kernel stamps: ~8 cycles per instruction and wave, two waves per SIMD): the per-block (cell, count) lists are built once per
 // wave in vector code, 16 blocks in parallel, and a block then costs ~12 instructions per distinct cell instead of ~180.
@@ -168,6 +169,25 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   // row's global -> LDS DMA (1 KiB, `buffer_load ... lds`: no VGPR staging) and assigns its slot to every pixel with that cell.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(mem), 0, 0xFFFFFFFFu, 0x00020000);
   GP_STAMP(1);
+  // Normally ONE pass over the quadrant.  A quadrant with more distinct cells than the cache holds (1-3 % of them at 640x640 with
+  // 0.2 m cells, most of them at 960x960 with 0.08 m cells) is redone as two passes over its upper and lower 16x8 half -- each a
+  // de-duplication of its own, each pooling its own two stride-8 cells -- instead of sending the overflowing pixels to the table
+  // one 4x4 block at a time; a half that still overflows falls back to that.
+  const int c_all[4] = {c[0], c[1], c[2], c[3]};
+  float acc16[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
+  const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
+  const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
+  const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
+  int npass = 1;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+  if (npass == 2) {
+    const bool mine = (lane >> 5) == pass;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = mine ? c_all[q] : -1;
+  }
   int sl[4] = {255, 255, 255, 255};      // cache slot of each pixel; 255 = not cached (read the table directly)
   int n_rows = 0;
 #pragma unroll 1
@@ -186,22 +206,26 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     }
     ++n_rows;
   }
+  if (npass == 1 && __ballot(max(max(c[0], c[1]), max(c[2], c[3])) >= 0) != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight target the slots that are about to be reused
+    npass = 2;
+    pass = -1;
+    continue;
+  }
   const unsigned slots = (unsigned)sl[0] | (unsigned)sl[1] << 8 | (unsigned)sl[2] << 16 | (unsigned)sl[3] << 24;
   GP_STAMP(2);
 
   // phase 3: pooling.  Each lane owns 8 consecutive channels.  Order mirrors torch: avg_pool2d(4) sums 16 pixels row-major in
   // f32, /16; each avg_pool2d(2) sums 4 values row-major, /4, rounds to fp16 (timm.py:152,168).
-  const int w8 = W >> 3, w16 = W >> 4, w32 = W >> 5, h8 = H >> 3, h16 = H >> 4;
-  const int t16 = (h8 * w8 + 31) >> 5;                 // first 32-row tile of the stride-16 level
-  const int t32 = t16 + ((h16 * w16 + 31) >> 5);       // ... of the stride-32 level
   // Per 4x4 block (16 per quadrant) a descriptor, computed ONCE in vector code, all 64 lanes at work (in-kernel stamps: unpacking
   // 16 slots per block with ~100 scalar instructions, not the adds, was 800 cycles per block; a first vector version that walked
   // the 16 pixels of a block in one lane was 1 200 instructions, this one is ~70):
-  //   binfo = counts of up to 4 distinct cached rows (5 bits each, ascending slot order, 0 for unused entries) | kind << 20 | n << 22
+  //   binfo  = counts of list entries 0-3 (5 bits each, ascending slot order, 0 for unused entries) | kind << 20 | n << 22
+  //   binfo2 = counts of list entries 4-7
   //           kind 0: the block is that list (a block of one row is {(row, 16)}: 16 v is exact and (16 v) / 16 = v)
-  //           kind 1: pixel by pixel (more than 4 distinct rows, or TORCH_ORDER)   kind 2: some pixel reads the table directly
-  //   blist = the rows' slots (4 bits each; unused entries repeat entry 0, their count 0 adds an exact zero)
-  int binfo;
+  //           kind 1: pixel by pixel (more than 8 distinct rows, or TORCH_ORDER)   kind 2: some pixel reads the table directly
+  //   blist  = the rows' slots (8 x 4 bits; unused entries repeat entry 0, their count 0 adds an exact zero)
+  int binfo, binfo2;
   unsigned blist;
   {
     // lane l holds pixel row (l >> 2) & 3 of block (row l >> 4, column l & 3): the four lanes of a block are l, l + 4, l + 8, l + 12
@@ -220,74 +244,91 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     const unsigned mm = m & 0xFFFFu;
     const int nu = __popc(mm);
     // the list is the block's slots in ascending order; a pixel's list position is the number of smaller slots present
-    unsigned cnt = 0;
+    unsigned cnt = 0, cnt2 = 0;                            // positions 0-3 / 4-7, 5 bits each
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned below = mm & ((1u << (sl[q] & 31)) - 1u);
-      cnt += 1u << (5 * (__popc(below) & 3));             // (positions >= 4 only occur in blocks that are not summed as a list)
+      const int pos = __popc(below);
+      const unsigned one = 1u << (5 * (pos & 3));         // (positions >= 8 only occur in blocks that are not summed as a list)
+      cnt += (pos & 4) ? 0u : one;
+      cnt2 += (pos & 4) ? one : 0u;
     }
     cnt += ror(cnt, ror4{});
     cnt += ror(cnt, ror8{});
-    const unsigned m1 = mm & (mm - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+    cnt2 += ror(cnt2, ror4{});
+    cnt2 += ror(cnt2, ror8{});
     const unsigned us0 = (unsigned)(__ffs((int)mm) - 1) & 15u;
-    const unsigned us1 = m1 ? (unsigned)(__ffs((int)m1) - 1) : us0;
-    const unsigned us2 = m2 ? (unsigned)(__ffs((int)m2) - 1) : us0;
-    const unsigned us3 = m3 ? (unsigned)(__ffs((int)m3) - 1) : us0;
-    blist = us0 | us1 << 4 | us2 << 8 | us3 << 12;
-    const bool overflow = nu > 4, uniform = nu == 1;
+    blist = us0;
+    unsigned rest = mm;
+#pragma unroll
+    for (int k = 1; k < GP_LIST; ++k) {
+      rest &= rest - 1u;
+      blist |= (rest ? (unsigned)(__ffs((int)rest) - 1) : us0) << (4 * k);
+    }
+    const bool overflow = nu > GP_LIST, uniform = nu == 1;
     const unsigned kind = direct ? 2u : ((overflow || (TORCH_ORDER && !uniform)) ? 1u : 0u);
-    binfo = (int)((cnt & 0xFFFFFu) | kind << 20 | (unsigned)min(nu, 7) << 22);
+    binfo = (int)((cnt & 0xFFFFFu) | kind << 20 | (unsigned)min(nu, 15) << 22);
+    binfo2 = (int)(cnt2 & 0xFFFFFu);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA'd rows are in LDS (only this wave reads them)
   GP_STAMP(3);
-  float acc16[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) acc16[q] = 0.f;
 #pragma unroll 1
-  for (int cy8 = 0; cy8 < 2; ++cy8) {
+  for (int cy8 = (npass == 2 ? pass : 0); cy8 < (npass == 2 ? pass + 1 : 2); ++cy8) {
 #pragma unroll 1
     for (int cx8 = 0; cx8 < 2; ++cx8) {
       float acc8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
       // descriptors of the cell's four 4x4 blocks
-      int info[4];
+      int info[4], info2[4];
       unsigned bl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int b = (cy8 * 2 + (j >> 1)) * 16 + cx8 * 2 + (j & 1);          // a lane of block (row, column)
         info[j] = __builtin_amdgcn_readlane(binfo, b);
+        info2[j] = __builtin_amdgcn_readlane(binfo2, b);
         bl[j] = (unsigned)__builtin_amdgcn_readlane((int)blist, b);
       }
       const unsigned kinds = ((unsigned)(info[0] | info[1] | info[2] | info[3]) >> 20) & 3u;
       int nmax = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) nmax = max(nmax, (info[j] >> 22) & 7);
+      for (int j = 0; j < 4; ++j) nmax = max(nmax, (info[j] >> 22) & 15);
+      auto count_of = [&](int j, int k) {
+        return (float)(int)((k < 4 ? ((unsigned)info[j] >> (5 * k)) : ((unsigned)info2[j] >> (5 * (k - 4)))) & 31u);
+      };
       // common case: every block is a short list.  Branch-free inside: the (8 or 16) row reads are issued first, then the
       // multiply-adds block by block; unused list entries re-read entry 0 with a count of 0 (an exact + 0).
       auto listed = [&](auto vtag) {
         constexpr int V = decltype(vtag)::value;
-        uint4 raw[4][V];
+        constexpr int G = V > 4 ? 2 : 4;             // blocks whose reads are in flight together (64 VGPRs of row data at most)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j0 = 0; j0 < 4; j0 += G) {
+          uint4 raw[G][V];
 #pragma unroll
-          for (int k = 0; k < V; ++k) raw[j][k] = rows[((bl[j] >> (4 * k)) & 15u) * 64 + lane];
+          for (int j = 0; j < G; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float acc4[8];
-          setn8(acc4, raw[j][0], (float)(int)((unsigned)info[j] & 31u));
+            for (int k = 0; k < V; ++k) raw[j][k] = rows[((bl[j0 + j] >> (4 * k)) & 15u) * 64 + lane];
 #pragma unroll
-          for (int k = 1; k < V; ++k) addn8(acc4, raw[j][k], (float)(int)(((unsigned)info[j] >> (5 * k)) & 31u));
+          for (int j = 0; j < G; ++j) {
+            float acc4[8];
+            setn8(acc4, raw[j][0], count_of(j0 + j, 0));
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
+            for (int k = 1; k < V; ++k) addn8(acc4, raw[j][k], count_of(j0 + j, k));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
+          }
         }
       };
       if (kinds == 0 && nmax <= 2) {
         listed(std::integral_constant<int, 2>{});
       } else if (kinds == 0 && nmax == 3) {
         listed(std::integral_constant<int, 3>{});
-      } else if (kinds == 0) {
+      } else if (kinds == 0 && nmax == 4) {
         listed(std::integral_constant<int, 4>{});
+      } else if (kinds == 0 && nmax <= 6) {
+        listed(std::integral_constant<int, 6>{});
+      } else if (kinds == 0) {
+        listed(std::integral_constant<int, 8>{});
       } else {
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
@@ -303,6 +344,12 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               addn8(acc4, rows[((bw >> (4 * k)) & 15u) * 64 + lane], (float)(int)(((unsigned)inf >> (5 * k)) & 31u));
+            if (((inf >> 22) & 15) > 4) {
+              const unsigned inf2 = (unsigned)__builtin_amdgcn_readlane(binfo2, (cy8 * 2 + by) * 16 + xq4);
+#pragma unroll
+              for (int k = 4; k < 8; ++k)
+                addn8(acc4, rows[((bw >> (4 * k)) & 15u) * 64 + lane], (float)(int)((inf2 >> (5 * (k - 4))) & 31u));
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
             continue;
@@ -325,23 +372,25 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
           } else {
-            // rare: more distinct cells in the quadrant than the LDS cache holds
+            // rare (1-3 % of the quadrants of a frame, but a workgroup that hits it sets the kernel's tail): more distinct cells in
+            // the quadrant than the LDS cache holds.  All 16 reads of the block -- LDS or table -- are issued before the first add:
+            // one memory round trip per block, not one per pixel row.
+            uint4 raw[16];
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy) {
-              uint4 raw[4];
               const int src_lane = (yq + dy) * 4 + xq4;
 #pragma unroll
               for (int dx = 0; dx < 4; ++dx) {
                 if (sl[4 * dy + dx] != 255) {
-                  raw[dx] = rows[sl[4 * dy + dx] * 64 + lane];
+                  raw[4 * dy + dx] = rows[sl[4 * dy + dx] * 64 + lane];
                 } else {
                   const int cell = __builtin_amdgcn_readlane(c[dx], src_lane);
-                  raw[dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * 512 + lane * 8);
+                  raw[4 * dy + dx] = *reinterpret_cast<const uint4*>(mem + (size_t)cell * 512 + lane * 8);
                 }
               }
-#pragma unroll
-              for (int dx = 0; dx < 4; ++dx) add8(acc4, raw[dx]);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) add8(acc4, raw[i]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc8[q] += acc4[q] * 0.0625f;
           }
@@ -360,6 +409,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
       }
     }
   }
+  }      // pass
   GP_STAMP(4);
   float v16[8];
 #pragma unroll

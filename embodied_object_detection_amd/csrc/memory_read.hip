@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
   // Normally ONE pass over the quadrant.  A quadrant with more distinct cells than the cache holds (1-3 % of them at 640x640 with
   // 0.2 m cells, most of them at 960x960 with 0.08 m cells) is redone as two passes over its upper and lower 16x8 half -- each a
   // de-duplication of its own, each pooling its own two stride-8 cells -- instead of sending the overflowing pixels to the table
-  // one 4x4 block at a time; a half that still overflows falls back to that.
+  // one 4x4 block at a time; a half that still overflows falls back to that.  (Splitting further, half -> 8x8 cells, was measured
+  // and gains nothing: what is left of the tail are tiles whose pixels are nearly all distinct cells -- far background --
+  // and those need ~1 MB of rows per tile whichever way they are fetched.)
   const int c_all[4] = {c[0], c[1], c[2], c[3]};
   float acc16[8];
 #pragma unroll
@@ -206,11 +208,19 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restri
     }
     ++n_rows;
   }
-  if (npass == 1 && __ballot(max(max(c[0], c[1]), max(c[2], c[3])) >= 0) != 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight target the slots that are about to be reused
-    npass = 2;
-    pass = -1;
-    continue;
+  if (npass == 1) {
+    const u64 left = __ballot(max(max(c[0], c[1]), max(c[2], c[3])) >= 0);
+    if (left != 0) {
+      npass = 2;
+      // The rounds take their keys from the lowest lane with pixels left, i.e. from the upper rows first: when every pixel of the
+      // upper half has its slot, this attempt IS pass 0 (the lower half's lanes are simply not pooled now) and only the lower
+      // half is de-duplicated again.  Otherwise both halves start over.
+      if ((left & 0xFFFFFFFFull) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight target the slots that are about to be reused
+        pass = -1;
+        continue;
+      }
+    }
   }
   const unsigned slots = (unsigned)sl[0] | (unsigned)sl[1] << 8 | (unsigned)sl[2] << 16 | (unsigned)sl[3] << 24;
   GP_STAMP(2);

@@ -113,6 +113,30 @@ def _batch_equals_singles(synthetic_sd, H, W, grid, cell, B, T):
         torch.cuda.empty_cache()
 
 
+def test_scenes_in_flight_do_not_change_results(synthetic_sd):
+    """1, 2 or 3 scenes in flight, with or without the look-ahead trunk and the stagger: three scenes, bitwise the same outputs."""
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.modeling.batched import BatchedSequences
+    seqs = [SyntheticSequence(90 + b, H=128, W=160, n_frames=4, map_w=24, map_h=24, cell=0.5) for b in range(3)]
+    eps = [[s.frame(i) for i in range(4)] for s in seqs]
+    ref = None
+    for conc, look, stag in ((1, True, True), (2, True, True), (3, True, False), (2, False, True)):
+        bs = BatchedSequences(_cfg(), 3, synthetic_sd, concurrent_scenes=conc)
+        bs.trunk_lookahead, bs.stagger = look, stag
+        outs = bs(eps)
+        got = [[(o["instances"].pred_boxes.tensor.clone(), o["instances"].scores.clone(), o["instances"].pred_masks.clone()) for o in ob]
+               for ob in outs] + [[m.implicit_memory.clone() for m in bs.scenes]]
+        if ref is None:
+            ref = got
+            continue
+        for a, b in zip(ref[:-1], got[:-1]):
+            for (b1, s1, m1), (b2, s2, m2) in zip(a, b):
+                assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(m1, m2)
+        assert all(torch.equal(x, y) for x, y in zip(ref[-1], got[-1]))
+        del bs
+        torch.cuda.empty_cache()
+
+
 def test_batch_of_3_equals_3_single_runs_small(synthetic_sd):
     """Lock-step batch (the trunk batched with N = 3, planned like one image) == three independent runs, bit for bit."""
     _batch_equals_singles(synthetic_sd, 128, 160, 24, 0.5, 3, 3)

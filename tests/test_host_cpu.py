@@ -415,3 +415,15 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
         assert int(got[st.__name__]) == ctypes.sizeof(st), st.__name__
         for name, _t in st._fields_:
             assert int(got[f"{st.__name__}.{name}"]) == getattr(st, name).offset, f"{st.__name__}.{name}"
+
+
+def test_package_import_asks_for_enough_hardware_queues():
+    """Two streams mapped onto one hardware queue run one after the other (tools/experiments/chain_contention.hip): the package
+    asks the runtime for 8 queues per priority before the first GPU call unless the user has chosen a value."""
+    import subprocess
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import embodied_object_detection_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "8"
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import embodied_object_detection_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "2"

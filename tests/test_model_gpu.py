@@ -361,6 +361,30 @@ def test_trunk_lookahead_gives_identical_results(setup):
             assert torch.equal(x.pred_masks, y.pred_masks)
 
 
+def test_detection_pass_position_and_snapshot_mode_change_nothing(setup):
+    """Where the deferred detection pass may start (behind the cascade / the proposal masks / the memory write) and how the fp16
+    snapshot is kept current (write-through rows or a normalise launch at the next frame) are scheduling choices: an episode gives
+    bitwise the same detections, masks and memory state."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    outs = []
+    for after, follow in (("cascade", None), ("proposal_masks", None), ("memory_write", None), ("cascade", False)):
+        model = build_model(_cfg(), sd)
+        model.detection_pass_after = after
+        model.snapshot_follows_write = follow
+        res = [o["instances"] for o in model([frames])]
+        outs.append((res, model.implicit_memory.clone(), model.observations.clone(), model._mem_f16.clone()))
+        if follow is False:
+            model._refresh_memory_snapshot()               # the marked rows are brought up to date on demand
+            outs[-1] = outs[-1][:3] + (model._mem_f16.clone(),)
+    ra, ma, oa, sa = outs[0]
+    for rb, mb, ob, sb in outs[1:]:
+        assert torch.equal(ma, mb) and torch.equal(oa, ob) and torch.equal(sa, sb)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor) and torch.equal(x.scores, y.scores)
+            assert torch.equal(x.pred_classes, y.pred_classes) and torch.equal(x.pred_masks, y.pred_masks)
+
+
 def test_on_disk_episodes_drive_the_model(setup, tmp_path):
     """§8f rank 1 end to end: episode files in the reference's layout (HDF5 + JPEG) -> loader mirror -> frame dicts -> model ->
     records; identical to feeding the decoded frames by hand."""

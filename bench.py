@@ -617,8 +617,16 @@ def main():
             d2 = [s_.elapsed_time(e_) for (s_, e_, _c) in ev_excl]
             f2 = [2.0 * (int(c.item()) if c is not None else 0) * 196 * 256 * 2304 for (_s, _e, c) in ev_excl]
             ach = sum(f2) / (sum(d2) * 1e-3) / 1e12
+            by_pass = {}
+            for name, sel in (("detection_pass", lambda r: r >= 150), ("proposal_mask_pass", lambda r: 0 < r < 150)):
+                dd = [t_ for t_, f_ in zip(d2, f2) if sel(f_ / (2.0 * 196 * 256 * 2304))]
+                ff = [f_ for f_ in f2 if sel(f_ / (2.0 * 196 * 256 * 2304))]
+                if dd:
+                    a_ = sum(ff) / (sum(dd) * 1e-3) / 1e12
+                    by_pass[name] = {"launches": len(dd), "rois_mean": round(sum(ff) / len(ff) / (2.0 * 196 * 256 * 2304), 1),
+                                     "avg_launch_ms": round(sum(dd) / len(dd), 4), "achieved": round(a_, 3), "frac": round(a_ / peak, 4)}
             roofline["exclusive_launches"] = {"achieved": round(ach, 3), "frac": round(ach / peak, 4), "launches": len(d2),
-                                              "avg_launch_ms": round(sum(d2) / len(d2), 4),
+                                              "avg_launch_ms": round(sum(d2) / len(d2), 4), "by_pass": by_pass,
                                               "note": "same kernel, same inputs, measured in a short extra pass on ONE stream "
                                                       "(model.overlap_branches = False) after the timed region: in the timed "
                                                       "region every launch shares the chip with the second stream's box cascade / "

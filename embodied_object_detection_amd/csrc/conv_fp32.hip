@@ -20,6 +20,10 @@
 // epilogue: deterministic, no atomics.
 #include "conv_common.h"
 
+#ifndef EOD_MFMA_PRIO
+#define EOD_MFMA_PRIO 1
+#endif
+
 namespace eodconv {
 namespace {
 
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LS + kk * 8);
+      if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
               acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc_b, 0, 0, 0);
             else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+      if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import ops
-from .meta_arch import CustomRCNNRecurrent
+from .meta_arch import PYRAMID_SETS, CustomRCNNRecurrent
 
 
 def _share_weights(dst: CustomRCNNRecurrent, src: CustomRCNNRecurrent):
@@ -107,7 +107,7 @@ class BatchedSequences:
         c = m0.backbone.bottom_up.forward(x, Hp, Wp, N=B)
         p345 = m0.backbone.top_down_batched(c, Hp, Wp, B)
         for b, (m, f) in enumerate(zip(scenes, frames)):
-            nxt = (m._pyramid + 1) % 3
+            nxt = (m._pyramid + 1) % PYRAMID_SETS
             shapes, off, feats, views, pooled = m.backbone._plan(Hp, Wp, nxt)
             for l in range(3):
                 views[l].copy_(p345[l][b:b + 1])
@@ -131,15 +131,15 @@ class BatchedSequences:
         active = lambda t: [b for b in range(B) if t < len(episodes[b])]
 
         def enqueue_trunk(t: int):
-            """the batched trunk of step t on `ts`; it overwrites, for every active scene, the pyramid set of its frame t - 3"""
+            """the batched trunk of step t on `ts`; it overwrites, for every active scene, the pyramid set of its frame t - PYRAMID_SETS"""
             act = active(t)
             for b in act:
                 m = self.scenes[b]
                 # with the look-ahead, frame t - 1 is only being enqueued now; what must be over is frame t - 2 (scenes run their
-                # frames in order, so its event covers frame t - 3, the last user of that set); without it, frame t - 1
+                # frames in order, so its event covers every earlier user of that set); without it, frame t - 1
                 if t >= (2 if self.trunk_lookahead else 1):
                     ts.wait_event(self._ev_done[b][t % 2 if self.trunk_lookahead else (t - 1) % 2])
-                rd = m._pyr_reader.get((m._pyramid + 1) % 3)
+                rd = m._pyr_reader.get((m._pyramid + 1) % PYRAMID_SETS)
                 if rd is not None:
                     ts.wait_event(rd)                    # a trailing detection pass may still read that set
             with torch.cuda.stream(ts):

@@ -36,6 +36,7 @@ _SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, ...]] = {}
 # t+2 has been enqueued, so that the host never waits for a detection pass that still trails on the GPU (the host needs ~3.7 ms
 # to enqueue a frame, about as long as the GPU needs to run one).
 RESULT_SETS = 3
+PYRAMID_SETS = 4        # current frame, the frame before (its detection pass may trail), and up to two frames computed ahead
 
 
 def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
@@ -115,6 +116,12 @@ class CustomRCNNRecurrent:
         # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
         # the mask (an fp32 matmul on a half-masked stream takes the same time).
         self.early_memory_selection = False
+        # how many coming frames of an episode the look-ahead computes at once (their images are all there when `forward` is
+        # called): 2 = the memory-independent trunk + FPN top-down of frames t+1 and t+2 as ONE N = 2 pass every second frame
+        # (planned like one image: bitwise the N = 1 results).  Measured at 640x640: the pass costs 1.23 ms per image instead of 1.61
+        # (tools/trunk_batch_time.py) and the frames without a trunk beside them have a 1.7 ms front instead of 2.3 -- but the
+        # frames WITH the double trunk lose the same: 187.1 frames/s either way.  Default 1.
+        self.lookahead_frames = 1
         self.front_event: Optional[torch.cuda.Event] = None      # one-stream schedule only: recorded after the box cascade
         # where the (deferred, low-priority) detection mask pass may start: "cascade" (as soon as the detections exist),
         # "proposal_masks" / "memory_write" (behind this frame's critical chain: it then runs beside the NEXT frame's
@@ -277,7 +284,7 @@ class CustomRCNNRecurrent:
                 if self.implicit_memory is None:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
-                nxt = input_seq[i + 1] if i + 1 < len(input_seq) else None
+                nxt = input_seq[i + 1:i + 1 + max(1, int(self.lookahead_frames))] or None      # the frames that follow, in order
                 last = nxt is None and input_seq is batched_inputs[-1]
                 t0 = _time.perf_counter()
                 self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
@@ -336,10 +343,10 @@ class CustomRCNNRecurrent:
             p = p.to(torch.int32)
         return p.to(self.device, non_blocking=True).contiguous()
 
-    def _enqueue_trunk(self, frame: dict, after: torch.cuda.Event):
-        """Bottom-up pass + FPN top-down convs of a coming frame on the look-ahead stream, ordered after `after` (an event of the
-        main stream recorded once the previous look-ahead has been consumed and the previous frame has fully finished: the
-        pyramid set written here was last read by that frame)."""
+    def _enqueue_trunk(self, frames: List[dict], after: torch.cuda.Event):
+        """Bottom-up pass + FPN top-down convs of the coming frame(s) on the look-ahead stream, ordered after `after` (an event of
+        the main stream recorded once the previous look-ahead has been consumed and the previous frame has fully finished).  Frame b
+        of the list is written into pyramid set (current + 1 + b); more than one frame = one batched pass."""
         if self._trunk_stream is None:
             # high priority like the side stream: its ~75 launches are small and must not queue behind the mask GEMMs' thousands
             # of workgroups
@@ -347,22 +354,35 @@ class CustomRCNNRecurrent:
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
         ts.wait_event(after)
-        nxt = (self._pyramid + 1) % 3
-        if nxt in self._pyr_reader:
-            ts.wait_event(self._pyr_reader[nxt])      # a trailing detection pass may still read that set
+        sets = [(self._pyramid + 1 + b) % PYRAMID_SETS for b in range(len(frames))]
+        for st in sets:
+            if st in self._pyr_reader:
+                ts.wait_event(self._pyr_reader[st])      # a trailing detection pass may still read that set
         with torch.cuda.stream(ts):
             self._mark("trunk_lookahead_begin", ts)
-            image = self._device_image(frame)
-            x4, Hp, Wp = ops.preprocess_image(image, self.pixel_mean, self.pixel_std)
-            self.backbone.top_down(self.backbone.bottom_up.forward(x4, Hp, Wp), Hp, Wp, nxt)
+            xs = []
+            for f in frames:
+                x4, Hp, Wp = ops.preprocess_image(self._device_image(f), self.pixel_mean, self.pixel_std)
+                xs.append(x4)
+            if len(frames) == 1:
+                self.backbone.top_down(self.backbone.bottom_up.forward(xs[0], Hp, Wp), Hp, Wp, sets[0])
+            else:
+                n = len(frames)
+                c = self.backbone.bottom_up.forward(torch.cat(xs, dim=0), Hp, Wp, N=n)
+                p345 = self.backbone.top_down_batched(c, Hp, Wp, n)
+                for b, st in enumerate(sets):
+                    views = self.backbone._plan(Hp, Wp, st)[3]
+                    for l in range(3):
+                        views[l].copy_(p345[l][b:b + 1])
             self._ev_trunk.record(ts)
             self._mark("trunk_lookahead", ts)
-        self._prefetched = (frame["image"], Hp, Wp)
+        self._prefetched = [(f["image"], Hp, Wp) for f in frames]
 
     def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
-                        next_frame: Optional[dict] = None, trailing_detection_pass: bool = False):
+                        next_frame=None, trailing_detection_pass: bool = False):
         """One frame: `inference` (custom_rcnn.py:548-582) + `update_implicit_memory` (681-760).  `next_frame` (optional) is the
-        frame the caller will pass next: its memory-independent bottom-up pass is started early.  `trailing_detection_pass`
+        frame the caller will pass next -- or the list of the frames it will pass next, in order: their memory-independent
+        bottom-up passes are started early (`lookahead_frames` of them at a time as one batched pass).  `trailing_detection_pass`
         (set by `forward` for every frame but the last of a call): do not join the detection-pass stream at the end of the frame;
         the caller reads the results through `_post_ticket` / `_materialize` only."""
         H, W = int(frame["image"].shape[-2]), int(frame["image"].shape[-1])
@@ -383,16 +403,30 @@ class CustomRCNNRecurrent:
                 self._refresh_memory_snapshot()
             mem_f16 = self._mem_f16
 
-        pre, self._prefetched = self._prefetched, None
-        if pre is not None:
-            # whatever was started ahead (used or not) must be finished before this frame touches either pyramid set
+        pre_list, self._prefetched = self._prefetched, None
+        if isinstance(pre_list, tuple):            # (image, Hp, Wp) handed over by BatchedSequences
+            pre_list = [pre_list]
+        if pre_list:
+            # whatever was started ahead (used or not) must be finished before this frame touches any pyramid set
             torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
-        hit = pre is not None and pre[0] is frame["image"]
-        # every frame moves to the next of three pyramid sets (the look-ahead wrote P3..P5 of a hit into exactly that one); a
-        # trailing detection pass of the frame that last used the set must be over before a miss recomputes into it
-        self._pyramid = (self._pyramid + 1) % 3
+        hit = bool(pre_list) and pre_list[0][0] is frame["image"]
+        pre = pre_list[0] if hit else None
+        # frames computed ahead beyond this one stay valid only if the caller really passes them next (checked frame by frame)
+        still_ahead = pre_list[1:] if hit else []
+        # every frame moves to the next of PYRAMID_SETS pyramid sets (the look-ahead wrote P3..P5 of a hit into exactly that one);
+        # a trailing detection pass of the frame that last used the set must be over before a miss recomputes into it
+        self._pyramid = (self._pyramid + 1) % PYRAMID_SETS
         if not hit and self._pyramid in self._pyr_reader:
             torch.cuda.current_stream(self.device).wait_event(self._pyr_reader[self._pyramid])
+        coming = [] if next_frame is None else (list(next_frame) if isinstance(next_frame, (list, tuple)) else [next_frame])
+        if still_ahead and not (coming and all(a[0] is c["image"] for a, c in zip(still_ahead, coming)) and len(coming) >= len(still_ahead)):
+            still_ahead = []                       # the hint changed: what was computed ahead is dropped
+        if still_ahead:
+            self._prefetched = still_ahead         # nothing new to start: the next frame's trunk is already there
+            coming = []
+        else:
+            coming = coming[:max(1, int(self.lookahead_frames))]
+        next_frame = coming if coming else None
         look_ahead = next_frame is not None and self.prefetch_trunk and self.overlap_branches
         if look_ahead and self.lookahead_at_start:
             # it may start NOW, beside this frame's memory fusion, tower and proposal decoding (a short latency-bound chain

@@ -348,13 +348,16 @@ def test_trunk_lookahead_gives_identical_results(setup):
     ra = [a([[f]])[0]["instances"] for f in frames]
     b = build_model(_cfg(), sd)
     rb = [o["instances"] for o in b([frames])]                       # look-ahead inside the episode
+    b2 = build_model(_cfg(), sd)
+    b2.lookahead_frames = 2                                          # two coming frames as one N = 2 pass every second frame
+    rb2 = [o["instances"] for o in b2([frames])]
     c = build_model(_cfg(), sd)
     rc = []
     for i, f in enumerate(frames):                                   # deliberately wrong hints
         if f["memory_reset"]:
             c.reset_memory(setup["n_cells"])
         rc.append(c.inference_frame(f, next_frame=frames[0])["instances"])
-    for other, m in ((rb, b), (rc, c)):
+    for other, m in ((rb, b), (rb2, b2), (rc, c)):
         assert torch.equal(a.implicit_memory, m.implicit_memory) and torch.equal(a.observations, m.observations)
         for x, y in zip(ra, other):
             assert torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor) and torch.equal(x.scores, y.scores)

@@ -155,6 +155,70 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restr
   }
 }
 
+// Finalize + apply in ONE launch (one launch less on the frame's dependent chain): a workgroup owns one 32-row chunk of one level,
+// first reduces that level's chunk partials to (mean, rstd) for every group -- one wave per group, lanes striding over the chunks,
+// the same fixed-shape shuffle tree and the same double arithmetic as gn_finalize_kernel, hence the same bits -- into LDS, then
+// normalises its rows.  The redundant reductions are 32 groups x <= 200 partial pairs per workgroup out of L2.
+__global__ __launch_bounds__(256) void gn_finalize_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      LevelOff lo, int C, int groups, float eps,
+                                                                      const double* __restrict__ partial) {
+  EOD_CHAIN_PRIO();
+  __shared__ float s_stats[64][2];
+  int level = 0, first_chunk = 0;
+  for (;;) {
+    const int rows_l = lo.off[level + 1] - lo.off[level];
+    const int nch_l = (rows_l + GN_ROWS - 1) / GN_ROWS;
+    if ((int)blockIdx.x < first_chunk + nch_l || level + 1 >= lo.levels) break;
+    first_chunk += nch_l;
+    ++level;
+  }
+  const int rows = lo.off[level + 1] - lo.off[level];
+  const int nch = (rows + GN_ROWS - 1) / GN_ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = wave; g < groups; g += 4) {
+    double s = 0.0, q = 0.0;
+    for (int c = lane; c < nch; c += 64) {
+      s += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
+      q += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    if (lane == 0) {
+      const double n = (double)rows * (C / groups);
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stats[g][0] = (float)mean;
+      s_stats[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int r0 = lo.off[level] + ((int)blockIdx.x - first_chunk) * GN_ROWS;
+  const int r1 = min(r0 + GN_ROWS, lo.off[level + 1]);
+  const int c4 = C >> 2;
+  const int cpg = C / groups;
+  const int total = (r1 - r0) * c4;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int cc = (i % c4) * 4;
+    const int row = r0 + i / c4;
+    const int g = cc / cpg;
+    const float mean = s_stats[g][0], rstd = s_stats[g][1];
+    const size_t o = (size_t)row * C + cc;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cc);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + cc);
+    f32x4 r;
+    r.x = fmaxf((v.x - mean) * rstd * ga.x + be.x, 0.f);
+    r.y = fmaxf((v.y - mean) * rstd * ga.y + be.y, 0.f);
+    r.z = fmaxf((v.z - mean) * rstd * ga.z + be.z, 0.f);
+    r.w = fmaxf((v.w - mean) * rstd * ga.w + be.w, 0.f);
+    *reinterpret_cast<f32x4*>(y + o) = r;
+  }
+}
+
 // one wave per row: dot(x[row,:], w) + b -> sigmoid
 __global__ __launch_bounds__(256) void mask_predictor_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
                                                               float* __restrict__ prob, int rows, int C,
@@ -246,10 +310,15 @@ extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, 
   const int cpg = C / groups;
   if (cpg > 64 || (cpg & (cpg - 1)) != 0 || 256 % cpg != 0) return EOD_ERR_BAD_DIMS;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((levels * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, lo, C, groups,
-                     eps, stats);
-  hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)lo.off[levels] * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
-                     gamma, beta, lo, C, groups, stats);
+  if (groups <= 64) {
+    hipLaunchKernelGGL(gn_finalize_apply_relu_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, lo, C, groups,
+                       eps, partial);
+  } else {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((levels * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, lo, C, groups,
+                       eps, stats);
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)lo.off[levels] * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                       gamma, beta, lo, C, groups, stats);
+  }
   return eod_launch_status();
 }
 

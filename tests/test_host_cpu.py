@@ -427,3 +427,38 @@ def test_package_import_asks_for_enough_hardware_queues():
     code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import embodied_object_detection_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
     assert out == "2"
+
+
+class _StubLockstep:
+    """Stand-in with the surface `inference_on_scenes` recognises a `BatchedSequences` by: B scenes, one call per step of episodes."""
+    device = torch.device("cpu")
+    trunk_lookahead = True
+
+    def __init__(self, B):
+        self.scenes = [_StubModel() for _ in range(B)]
+        self.calls = []
+
+    def __call__(self, episodes):
+        assert len(episodes) == len(self.scenes)
+        self.calls.append([None if e is None else len(e) for e in episodes])
+        return [[] if e is None else m([e]) for m, e in zip(self.scenes, episodes)]
+
+
+def test_eval_loop_groups_ragged_scenes_for_a_lockstep_model():
+    """The driver's grouping for a B-scene model: scenes taken B at a time, episodes in parallel, a scene whose episodes have run
+    out passes None, a group smaller than B is padded with None; the records are those of the one-scene-after-the-other loop."""
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.engine.eval_loop import episode_offsets, inference_on_scenes
+    lens = [45, 20, 7]
+    mk = lambda: [SyntheticSequence(s, H=64, W=96, n_frames=n, map_w=16, map_h=16, cell=0.5, projector=_cpu_projector())
+                  for s, n in enumerate(lens)]
+    offs = dict(enumerate(episode_offsets(lens)))
+    seq = inference_on_scenes(_StubModel(), mk(), 0, max_rows=1 << 14, scene_episode_offset=offs)
+    stub = _StubLockstep(2)
+    seen = []
+    par = inference_on_scenes(stub, mk(), 0, max_rows=1 << 14, scene_episode_offset=offs,
+                              on_episode=lambda idx, inp, out: seen.append((idx, len(inp), len(out))))
+    assert stub.calls == [[20, 20], [20, None], [5, None], [7, None]]
+    assert sorted(seen) == [(0, 20, 20), (1, 20, 20), (2, 5, 5), (3, 20, 20), (4, 7, 7)]
+    assert seq["frames"] == par["frames"] == sum(lens)
+    assert sorted(seq["records"].rows) == sorted(par["records"].rows) and len(seq["records"].rows) > 0

@@ -41,17 +41,22 @@ class RecordBufferOverflow(RuntimeError):
     pass
 
 
-def rows_needed(frames_per_rank: int, every: int = 5, max_dets: int = 100, max_gt: int = 156) -> int:
-    """Capacity of the fixed-shape collective buffer for a rank that evaluates `frames_per_rank` frames: every `every`-th
-    frame contributes at most `max_dets` detections (COCO maxDets) and its GT boxes.  Every rank must pass the SAME number
-    (the buffer shape is part of the collective), so callers take the maximum over ranks of the per-rank frame counts."""
-    imgs = (int(frames_per_rank) + every - 1) // every + 1
+def rows_needed(episodes, every: int = 5, max_dets: int = 100, max_gt: int = 156) -> int:
+    """Capacity of the fixed-shape collective buffer for a rank.  `episodes`: the lengths of the episodes the rank runs (or one
+    frame count, taken as ONE episode): every episode contributes ceil(len / every) evaluated frames (train_mp3d.py:187-188 takes
+    frames 0, 5, 10, ... of EACH episode), each at most `max_dets` detections (COCO maxDets) and its GT boxes.  Every rank must
+    pass the SAME number (the buffer shape is part of the collective), so callers take the maximum over ranks."""
+    if isinstance(episodes, (int, np.integer)):
+        episodes = [int(episodes)]
+    imgs = sum((int(n) + every - 1) // every for n in episodes) + 1
     return max(1024, imgs * (max_dets + max_gt))
 
 
 class RecordBuffer:
-    """Host-side staging of this rank's records; `to_tensor` pads to the fixed [rows, ROW] shape of the collective.
-    A row that does not fit raises: a silently truncated buffer would give a wrong AP without an error."""
+    """Host-side staging of this rank's records; `to_tensor` pads to the fixed [rows + 1, ROW] shape of the collective: the last
+    row is a status row (kind 0, column 1 = number of records that did not fit).  A row that does not fit is COUNTED, not raised:
+    raising on the overflowing rank alone would leave the other ranks waiting in the collective.  `gather_records` raises
+    `RecordBufferOverflow` on EVERY rank after the all-reduce -- a silently truncated buffer would give a wrong AP."""
 
     def __init__(self, max_rows: int):
         self.max_rows = max_rows
@@ -61,15 +66,14 @@ class RecordBuffer:
     def add(self, row: Sequence[float]):
         if len(self.rows) >= self.max_rows:
             self.dropped += 1
-            raise RecordBufferOverflow(
-                f"record buffer full ({self.max_rows} rows): size it with eval_loop.rows_needed(frames_per_rank) -- the "
-                "aggregate AP would silently lose detections otherwise")
+            return
         self.rows.append(list(row))
 
     def to_tensor(self, device) -> torch.Tensor:
-        t = torch.zeros((self.max_rows, ROW), dtype=torch.float32)
+        t = torch.zeros((self.max_rows + 1, ROW), dtype=torch.float32)
         if self.rows:
             t[:len(self.rows)] = torch.tensor(self.rows, dtype=torch.float32)
+        t[self.max_rows, 1] = float(self.dropped)
         return t.to(device)
 
 
@@ -163,24 +167,33 @@ def inference_on_scenes(model, scenes: Iterable, rank: int = 0, max_rows: int = 
 
 
 def gather_records(rec: RecordBuffer, rank: int, world: int, device) -> np.ndarray:
-    """ONE collective: every rank writes its slice of a zero [world, rows, ROW] buffer, all_reduce(SUM)."""
-    if rec.dropped:
-        raise RecordBufferOverflow(f"{rec.dropped} records were dropped")
+    """ONE collective: every rank writes its slice of a zero [world, rows + 1, ROW] buffer, all_reduce(SUM).  The status rows
+    travel with it, so an overflow on any rank raises on all of them, after the collective."""
     local = rec.to_tensor(device)
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         if world != 1:
             raise RuntimeError(f"world={world} but torch.distributed is not initialised")
-        return local.cpu().numpy()[None]
-    # also with ONE rank the buffer goes through the collective (RCCL on GPUs, gloo on CPU): same code path at every size
-    buf = torch.zeros((world,) + tuple(local.shape), dtype=torch.float32, device=device)
-    buf[rank] = local
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    return buf.cpu().numpy()
+        out = local.cpu().numpy()[None]
+    else:
+        # also with ONE rank the buffer goes through the collective (RCCL on GPUs, gloo on CPU): same code path at every size
+        buf = torch.zeros((world,) + tuple(local.shape), dtype=torch.float32, device=device)
+        buf[rank] = local
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        out = buf.cpu().numpy()
+    dropped = out[:, -1, 1]
+    if dropped.sum() > 0:
+        raise RecordBufferOverflow(
+            "record buffer full: " + ", ".join(f"rank {r} dropped {int(d)} records" for r, d in enumerate(dropped) if d > 0)
+            + f" ({rec.max_rows} rows per rank): size it with eval_loop.rows_needed(episode lengths of the busiest rank) -- the "
+              "aggregate AP would silently lose detections otherwise")
+    return out[:, :-1]
 
 
-def evaluate_gathered(buf: np.ndarray, num_classes: int) -> Dict[str, Dict[str, float]]:
-    """Quartile + overall COCO bbox results (train_mp3d.py:301-358) from the gathered [world, rows, ROW] records."""
+def records_by_image(buf: np.ndarray):
+    """Gathered [world, rows, ROW] records -> (detections, ground truth, quartile) keyed by the canonical image id
+    (scene * 1e6 + evaluated-frame index in the scene).  Quartile = the driver's `idx % 100` buckets of the GLOBAL episode index
+    (train_mp3d.py:210-217)."""
     dets, gts, quart = {}, {}, {}
     for r in range(buf.shape[0]):
         rows = buf[r]
@@ -198,6 +211,12 @@ def evaluate_gathered(buf: np.ndarray, num_classes: int) -> Dict[str, Dict[str, 
             e["boxes"] = np.asarray(e["boxes"], dtype=np.float64).reshape(-1, 4)
             e["scores"] = np.asarray(e["scores"], dtype=np.float64)
             e["classes"] = np.asarray(e["classes"], dtype=np.int64)
+    return dets, gts, quart
+
+
+def evaluate_gathered(buf: np.ndarray, num_classes: int) -> Dict[str, Dict[str, float]]:
+    """Quartile + overall COCO bbox results (train_mp3d.py:301-358) from the gathered [world, rows, ROW] records."""
+    dets, gts, quart = records_by_image(buf)
     all_ids = sorted(set(dets) | set(gts))
     results = {"all": coco_eval(dets, gts, num_classes, image_ids=all_ids)}
     for qi, name in enumerate(("first_quartile", "second_quartile", "third_quartile", "fourth_quartile")):

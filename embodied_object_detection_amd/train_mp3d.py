@@ -56,15 +56,16 @@ def do_test(cfg, model, args, rank: int, world: int):
         ds = Mp3dScenes(loader)
         scenes, offs = ds.shard(rank, world), ds.episode_offsets()
         # same capacity on every rank (the buffer shape is part of the collective): the busiest rank's frame count
-        per_rank = [sum(len(sc.indices) for sc in ds.shard(r, world)) * 20 for r in range(world)]
+        per_rank = [[20] * sum(len(sc.indices) for sc in ds.shard(r, world)) for r in range(world)]     # <= 20 frames per episode
         print(f"[rank {rank}] {len(loader)} episode files in {len(ds)} scenes under {data_root}; this rank: {len(scenes)} scenes")
     else:
         H, W = args.synthetic_size
         mine = shard_scenes(args.synthetic_scenes, rank, world)
         scenes = [SyntheticSequence(s, H=H, W=W, n_frames=args.synthetic_frames) for s in mine]
         offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
-        per_rank = [len(shard_scenes(args.synthetic_scenes, r, world)) * args.synthetic_frames for r in range(world)]
-    res = inference_on_scenes(model, scenes, rank, max_rows=rows_needed(max(per_rank)), scene_episode_offset=offs)
+        eps = [min(20, args.synthetic_frames - e0) for e0 in range(0, args.synthetic_frames, 20)]           # episodes of 20
+        per_rank = [eps * len(shard_scenes(args.synthetic_scenes, r, world)) for r in range(world)]
+    res = inference_on_scenes(model, scenes, rank, max_rows=max(rows_needed(e) for e in per_rank), scene_episode_offset=offs)
     buf = gather_records(res["records"], rank, world, model.device)
     out = None
     if rank == 0:

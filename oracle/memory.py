@@ -187,5 +187,5 @@ class RecurrentOracle:
             self.observation_count = self.observation_count + obs_update
         self.implicit_memory = self.semmap_features
         self.observations = self.observation_count
-        self.last = {"K": int(boxes.shape[0]), "rows": rows, "masks": masks, "feats": feats,
-                     "observed_mem": observed_mem, "mean": mean}
+        self.last = {"K": int(boxes.shape[0]), "rows": rows, "masks": masks, "feats": feats, "boxes": boxes,
+                     "masks28": proposals["pred_masks"][rows].squeeze(1), "observed_mem": observed_mem, "mean": mean}

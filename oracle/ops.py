@@ -212,14 +212,13 @@ def fast_rcnn_inference_single(boxes: torch.Tensor, scores: torch.Tensor, image_
 # --------------------------------------------------------------------------------------------
 # paste_masks_in_image (A12; calls `custom_rcnn.py:880` and inside `detector_postprocess`)
 # --------------------------------------------------------------------------------------------
-def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw: Tuple[int, int], threshold: float = 0.5,
-                chunk: int = 16) -> torch.Tensor:
-    """masks [K,28,28] probabilities, boxes [K,4] -> bool [K,H,W].
+def paste_masks_prob(masks: torch.Tensor, boxes: torch.Tensor, hw: Tuple[int, int], chunk: int = 16) -> torch.Tensor:
+    """masks [K,28,28] probabilities, boxes [K,4] -> f32 [K,H,W]: the bilinear samples `paste_masks` thresholds.
 
     Full-image grid_sample form of detectron2 `_do_paste_mask(skip_empty=False)`."""
     K = masks.shape[0]
     H, W = hw
-    out = torch.zeros((K, H, W), dtype=torch.bool)
+    out = torch.zeros((K, H, W), dtype=torch.float32)
     for s in range(0, K, chunk):
         m = masks[s:s + chunk, None].float()
         b = boxes[s:s + chunk].float()
@@ -232,6 +231,16 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw: Tuple[int, int], t
         gx = img_x[:, None, :].expand(n, H, W)
         gy = img_y[:, :, None].expand(n, H, W)
         grid = torch.stack([gx, gy], dim=3)
-        img = F.grid_sample(m, grid, align_corners=False)
-        out[s:s + chunk] = img[:, 0] >= threshold
+        out[s:s + chunk] = F.grid_sample(m, grid, align_corners=False)[:, 0]
+    return out
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw: Tuple[int, int], threshold: float = 0.5,
+                chunk: int = 16) -> torch.Tensor:
+    """masks [K,28,28] probabilities, boxes [K,4] -> bool [K,H,W] (`paste_masks_prob` >= threshold)."""
+    K = masks.shape[0]
+    H, W = hw
+    out = torch.zeros((K, H, W), dtype=torch.bool)
+    for s in range(0, K, chunk):
+        out[s:s + chunk] = paste_masks_prob(masks[s:s + chunk], boxes[s:s + chunk], hw, chunk) >= threshold
     return out

@@ -1,0 +1,99 @@
+"""Evidence for the memory WRITE path at full size (custom_rcnn.py:884-936), shared by test_write_parity_gpu.py and
+test_tolerance_gpu.py.  TEST INFRASTRUCTURE: the oracle is the checker, the HIP model is the thing checked.
+
+Two statements are separated here:
+
+1. *Given the HIP frame's own memory instances* (its kept proposal rows, their CLIP-space features and their pasted masks, read
+   back from the device after the frame), the state the HIP write leaves must be what `oracle.memory.memory_write_sparse`
+   computes from exactly those inputs: written-cell set bit-exact, values to 1e-5 relative on every cell.
+2. Where the HIP frame's pasted masks differ from the oracle frame's, every differing pixel must be a knife-edge decision of the
+   0.5 threshold (`|p - 0.5|` tiny in the oracle's own bilinear sample): the only way two fp32 implementations of the same frame
+   can disagree on a mask pixel.  A single such flip shifts the phase of the every-8th-observed-pixel rule (custom_rcnn.py:913-914)
+   for all later pixels, so it legitimately changes the written values of the frame (not a kernel error).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from oracle import memory as OM
+from oracle import ops as OO
+
+FLIP_BAND = 1e-5      # |p - 0.5| of an oracle mask sample that the HIP path may decide the other way
+
+
+def hip_write_inputs(model, H: int, W: int) -> Dict[str, torch.Tensor]:
+    """What the HIP memory write of the frame just run consumed, read back from the device: unique kept proposal rows
+    (ascending, custom_rcnn.py:875), their boxes, 50 x normalised stage-0 features, 28x28 mask probabilities, and the masks pasted
+    by the product's own paste kernel (`eod_paste_masks`, the arithmetic `mw_coverage` / `mw_accumulate` apply per pixel)."""
+    from embodied_object_detection_amd import ops
+    prop_boxes, prop_masks, rows, cnt, proj = model._last_write
+    torch.cuda.synchronize()
+    k = int(cnt.item())
+    urows = torch.unique(rows[:k].long())
+    K = int(urows.numel())
+    boxes = prop_boxes[urows].contiguous()
+    pasted = torch.zeros((max(K, 1), H, W), dtype=torch.uint8, device=prop_boxes.device)
+    if K:
+        count = torch.tensor([K], dtype=torch.int32, device=prop_boxes.device)
+        ops.paste_masks(prop_masks, boxes, urows.to(torch.int32).contiguous(), count, K, H, W, 0.5, pasted)
+        torch.cuda.synchronize()
+    return dict(rows=urows.cpu(), boxes=boxes.cpu(), featn=model.roi_heads.featn0[urows].cpu(),
+                masks28=prop_masks[urows].cpu(), pasted=pasted[:K].cpu().bool(), proj=proj.cpu().long(), K=K)
+
+
+def check_write_against_oracle(model, mem_before: torch.Tensor, obs_before: torch.Tensor, H: int, W: int, rel: float = 1e-5) -> dict:
+    """Statement 1.  `mem_before` / `obs_before`: the state the HIP model held before the frame (CPU copies)."""
+    ev = hip_write_inputs(model, H, W)
+    n_cells = mem_before.shape[0]
+    got_mem, got_obs = model.implicit_memory.cpu(), model.observations.cpu()
+    exp_mem = mem_before.clone()
+    observed = torch.zeros((n_cells,), dtype=torch.bool)
+    if ev["K"]:
+        mean, observed = OM.memory_write_sparse(ev["featn"], ev["pasted"], ev["proj"], n_cells)
+        exp_mem[observed] = exp_mem[observed] + mean
+    exp_obs = obs_before.clone()
+    if ev["K"]:                                           # update_implicit_memory returns early without instances (:689-690)
+        exp_obs[torch.unique(ev["proj"])] += 1
+    written = (got_mem != mem_before).any(dim=1)
+    scale = exp_mem.abs().max(dim=1).values.clamp_min(1.0)
+    cell_rel = (got_mem - exp_mem).abs().max(dim=1).values / scale
+    return dict(K=ev["K"], written_cells=int(written.sum()), expected_cells=int(observed.sum()),
+                cell_set_exact=bool(torch.equal(written, observed)), max_rel_err=float(cell_rel.max()),
+                cells_over_tol=int((cell_rel > rel).sum()), observations_exact=bool(torch.equal(got_obs, exp_obs)), evidence=ev)
+
+
+def mask_flip_attribution(ev: Dict[str, torch.Tensor], oracle_last: dict, H: int, W: int) -> dict:
+    """Statement 2.  Pairs the HIP frame's memory instances with the oracle frame's (same box to 1e-3 px) and classifies every
+    pasted-mask pixel on which the two disagree by the oracle's own pre-threshold sample."""
+    out = dict(instances_hip=ev["K"], instances_oracle=int(oracle_last.get("K", 0)), paired=0, unpaired=0, flipped_pixels=0,
+               flips_outside_band=0, max_flip_distance=0.0, masks_identical=False)
+    if not ev["K"] or not out["instances_oracle"]:
+        out["masks_identical"] = ev["K"] == out["instances_oracle"]
+        return out
+    ob, om28, opasted = oracle_last["boxes"], oracle_last["masks28"], oracle_last["masks"]
+    prob = None
+    identical = ev["K"] == out["instances_oracle"]
+    for i in range(ev["K"]):
+        d = (ob - ev["boxes"][i][None]).abs().max(dim=1).values
+        j = int(d.argmin())
+        if float(d[j]) > 1e-3:
+            out["unpaired"] += 1
+            identical = False
+            continue
+        out["paired"] += 1
+        diff = ev["pasted"][i] != opasted[j]
+        n = int(diff.sum())
+        if n:
+            identical = False
+            if prob is None:
+                prob = {}
+            if j not in prob:
+                prob[j] = OO.paste_masks_prob(om28[j:j + 1], ob[j:j + 1], (H, W))[0]
+            dist = (prob[j][diff] - 0.5).abs()
+            out["flipped_pixels"] += n
+            out["flips_outside_band"] += int((dist >= FLIP_BAND).sum())
+            out["max_flip_distance"] = max(out["max_flip_distance"], float(dist.max()))
+    out["masks_identical"] = bool(identical and out["unpaired"] == 0 and out["paired"] == out["instances_oracle"])
+    return out

@@ -262,6 +262,41 @@ def test_sharded_eval_world2_equals_single_process():
         assert sharded["all"][k] == pytest.approx(single["all"][k], abs=1e-9), "sharding must not change the aggregate AP"
 
 
+def _run_rank_overflow(rank, world, port, q):
+    """Rank 1's buffer is too small, rank 0's is fine (same SHAPE on both, as the collective requires: rank 0 simply has fewer
+    records): both ranks must raise after the all-reduce, neither may hang in it."""
+    import torch.distributed as dist
+    from embodied_object_detection_amd.engine.eval_loop import RecordBuffer, RecordBufferOverflow, gather_records
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rec = RecordBuffer(4)
+    for i in range(2 if rank == 0 else 7):
+        rec.add([1, rank, i, 0, 0.5, 0, 0, 1, 1, 0])
+    try:
+        gather_records(rec, rank, world, torch.device("cpu"))
+        q.put((rank, "no error"))
+    except RecordBufferOverflow as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_overflow_on_one_rank_raises_on_every_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_rank_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(got) == {0, 1}
+    for r in (0, 1):
+        assert "rank 1 dropped 3 records" in got[r] and "rank 0 dropped" not in got[r], got
+
+
 # ---------------------------------------------------------------------------------------------------------
 # synthetic loader schema
 # ---------------------------------------------------------------------------------------------------------
@@ -360,15 +395,21 @@ def test_bench_contract_helpers_and_committed_line():
 
 
 def test_record_buffer_overflow_raises():
-    """A full record buffer must fail loudly (a truncated buffer would give a wrong AP without an error)."""
+    """A full record buffer must fail loudly (a truncated buffer would give a wrong AP without an error) -- at the collective,
+    where every rank sees it, not in the middle of one rank's inference."""
     import pytest
-    from embodied_object_detection_amd.engine.eval_loop import RecordBuffer, RecordBufferOverflow, rows_needed
+    from embodied_object_detection_amd.engine.eval_loop import RecordBuffer, RecordBufferOverflow, gather_records, rows_needed
     rec = RecordBuffer(2)
     rec.add([1] * 10)
     rec.add([1] * 10)
+    assert gather_records(rec, 0, 1, "cpu").shape == (1, 2, 10)
+    rec.add([1] * 10)
+    assert rec.dropped == 1 and len(rec.rows) == 2
     with pytest.raises(RecordBufferOverflow):
-        rec.add([1] * 10)
+        gather_records(rec, 0, 1, "cpu")
     assert rows_needed(2000) >= (2000 // 5) * 200
+    # ragged episodes: frames 0, 5, 10, ... of EVERY episode are evaluated (train_mp3d.py:187-188): 3 episodes of 6 -> 6 frames, not 4
+    assert rows_needed([6, 6, 6]) >= 6 * 256 > rows_needed(18) - 256 * 2
 
 
 def test_bench_refuses_more_gpus_than_devices():

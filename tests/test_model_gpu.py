@@ -135,13 +135,24 @@ def conv_math(request):
 
 @pytest.mark.parametrize("conv_math", ["fp32", "bf16x3"], indirect=True)
 def test_recurrent_frames_match_oracle(setup, conv_math):
-    """Same tolerances for both arithmetic modes: fp32 MFMA (default) and the three-way bf16 split on the bf16 MFMA pipe."""
+    """FREE-RUNNING sequence, both arithmetic modes (fp32 MFMA, three-way bf16 split), absolute north_star tolerances: 1e-3 px on the
+    boxes and 1e-3 on the scores of every matched detection.  The two implementations stay in lock-step for as long as their memory
+    instances' pasted masks agree pixel for pixel; then the memories must agree too (cell set bit-exact, 1e-5 relative).  A frame
+    whose masks differ must show counted knife-edge decisions of the 0.5 threshold (tests/_write_parity.py) -- nothing else may
+    separate the two states -- and only then is the HIP state re-synchronised to the oracle's for the next frame."""
+    import _write_parity as WP
     from embodied_object_detection_amd import ops
     assert ops.get_conv_math() == conv_math
     model, frames, sd, ocfg = setup["model"], setup["frames"], setup["sd"], setup["ocfg"]
     oracle = OM.RecurrentOracle(sd, ocfg)
     H, W = setup["H"], setup["W"]
+    n_cells = setup["n_cells"]
+    resyncs = 0
     for i, f in enumerate(frames):
+        if f["memory_reset"]:
+            mem_before, obs_before = torch.zeros((n_cells, 512)), torch.zeros((n_cells,))
+        else:
+            mem_before, obs_before = model.implicit_memory.cpu().clone(), model.observations.cpu().clone()
         ref = oracle.step(f, i, frames)
         out = model([[f]])[0]["instances"]
         r = ref["instances"]
@@ -149,26 +160,38 @@ def test_recurrent_frames_match_oracle(setup, conv_math):
         assert abs(n_ref - n_got) <= max(3, int(0.02 * n_ref)), (n_ref, n_got)
         gb, gs, gc = out.pred_boxes.tensor.cpu(), out.scores.cpu(), out.pred_classes.cpu()
         idx, iou = _match(r["pred_boxes"], gb, r["pred_classes"], gc)
-        ok = (iou > 0.99) & ((gs[idx] - r["scores"]).abs() < 1e-3) & (gc[idx] == r["pred_classes"])
-        box_err = (gb[idx] - r["pred_boxes"]).abs().max(dim=1).values
-        ok &= box_err < 1e-2
+        ok = (iou > 0.99) & (gc[idx] == r["pred_classes"])
         frac = ok.float().mean().item()
         assert frac >= 0.98, f"frame {i}: only {frac:.3f} of detections match"
-        # tight tolerance on the matched majority (north_star: 1e-3 on coords / scores)
-        tight = ((gs[idx] - r["scores"]).abs() < 1e-3) & (box_err < 1e-3 * max(H, W))
-        assert tight[ok].float().mean().item() >= 0.99
+        box_err = (gb[idx] - r["pred_boxes"]).abs().max(dim=1).values[ok]
+        score_err = (gs[idx] - r["scores"]).abs()[ok]
+        print(f"[{conv_math} frame {i}] matched {int(ok.sum())}/{n_ref}, max dbox {float(box_err.max()):.2e} px, max dscore "
+              f"{float(score_err.max()):.2e}")
+        assert float(box_err.max()) < 1e-3 and float(score_err.max()) < 1e-3, (i, float(box_err.max()), float(score_err.max()))
         # pasted masks of matched detections
         gm = out.pred_masks.cpu()
         mism = (gm[idx][ok] != r["pred_masks"][ok]).float().mean().item()
         assert mism < 5e-3, f"frame {i}: mask mismatch {mism}"
         # memory state after the write
         assert torch.equal(model.observations.cpu(), oracle.observations), f"frame {i}: observation counters differ"
-        mref = oracle.implicit_memory
-        mgot = model.implicit_memory.cpu()
-        cell_err = (mgot - mref).abs().max(dim=1).values
-        bad = (cell_err > 1e-2 * max(1.0, mref.abs().max().item())).float().mean().item()
-        assert bad <= 0.02, f"frame {i}: {bad:.3f} of memory cells differ"
+        w = WP.check_write_against_oracle(model, mem_before, obs_before, H, W)
+        ev = w.pop("evidence")
+        assert w["cell_set_exact"] and w["cells_over_tol"] == 0 and w["observations_exact"], (i, w)
+        fl = WP.mask_flip_attribution(ev, oracle.last, H, W)
+        print(f"[{conv_math} frame {i}] write {w} flips {fl}")
+        assert fl["flips_outside_band"] == 0, (i, fl)
+        mref, mgot = oracle.implicit_memory, model.implicit_memory.cpu()
+        if fl["masks_identical"]:
+            assert torch.equal((mgot != 0).any(dim=1), (mref != 0).any(dim=1)), f"frame {i}: written-cell sets differ without a mask flip"
+            rel = ((mgot - mref).abs().max(dim=1).values / mref.abs().max(dim=1).values.clamp_min(1.0)).max().item()
+            assert rel <= 1e-4, f"frame {i}: memory differs by {rel:.2e} relative without a mask flip"
+        else:
+            assert fl["flipped_pixels"] > 0 or fl["unpaired"] > 0 or fl["instances_hip"] != fl["instances_oracle"], (i, fl)
+            model.implicit_memory.copy_(mref.to(model.device))
+            model.invalidate_memory_snapshot()
+            resyncs += 1
         assert int(model.last_stats["mem_k"].item()) > 0 or oracle.last["K"] == 0
+    print(f"[{conv_math}] {resyncs} of {len(frames)} frames re-synchronised after counted mask flips")
 
 
 def test_memory_types_and_fusions(setup):
@@ -437,6 +460,19 @@ def test_on_disk_episodes_drive_the_model(setup, tmp_path):
     assert torch.equal(model.implicit_memory, ref_model.implicit_memory)
     from embodied_object_detection_amd.evaluation.coco_ap import KIND_GT
     assert sum(1 for r in res["records"].rows if r[0] == KIND_GT) == 4   # one GT box per frame reached the evaluator
+    # and against the ORACLE on the loader's own frame dicts (disk -> loader -> mapping -> oracle): north_star tolerance on the first
+    # frame (no recurrent state yet), the observation counters after it, and a matched majority on the second
+    oracle = OM.RecurrentOracle(sd, setup["ocfg"])
+    disk_frames = [f for s_ in seen for f in s_[1]]
+    for i in range(2):
+        r = oracle.step(disk_frames[i], i, disk_frames)["instances"]
+        gb, gs, gc = got[i].pred_boxes.tensor.cpu(), got[i].scores.cpu(), got[i].pred_classes.cpu()
+        idx, iou = _match(r["pred_boxes"], gb, r["pred_classes"], gc)
+        ok = (iou > 0.99) & (gc[idx] == r["pred_classes"])
+        assert ok.float().mean().item() >= 0.98, i
+        if i == 0:
+            assert float((gb[idx] - r["pred_boxes"]).abs().max(dim=1).values[ok].max()) < 1e-3
+            assert float((gs[idx] - r["scores"]).abs()[ok].max()) < 1e-3
 
 
 def test_embodied_predictor_mirrors_the_robot_demo_call(synthetic_sd):

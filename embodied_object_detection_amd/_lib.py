@@ -33,7 +33,7 @@ class EodConvDesc(C.Structure):
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
         ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
-        ("plan_rows", C.c_int32),
+        ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32),
     ]
 
 
@@ -53,6 +53,8 @@ class EodDetDesc(C.Structure):
         ("img_w", C.c_float), ("img_h", C.c_float), ("score_thresh", C.c_float), ("nms_thresh", C.c_float),
         ("topk", C.c_int32), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_classes", C.c_void_p),
         ("out_rows", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("out_unique_rows", C.c_void_p), ("out_unique_count", C.c_void_p), ("unique_cap", C.c_int32),
+        ("out_rep_of", C.c_void_p), ("out_rep_list", C.c_void_p), ("out_rep_count", C.c_void_p),
     ]
 
 
@@ -89,7 +91,7 @@ SIGNATURES = {
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),
     "eod_zs_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                  C.c_int, C.c_float, C.c_void_p]),
+                                  C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "eod_apply_deltas": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "eod_cascade_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
@@ -97,7 +99,7 @@ SIGNATURES = {
     "eod_fast_rcnn_inference": (C.c_int, [C.POINTER(EodDetDesc), C.c_void_p]),
     "eod_detector_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p]),
+                                           C.c_void_p, C.c_void_p]),
     "eod_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.c_void_p]),
     "eod_unproject_grid_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,

@@ -290,28 +290,229 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   store_wave_tiles<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Few-row / deep-K layers without split-K slabs: the K range is split over the WAVES of a workgroup.
+//
+// A layer with fewer than 256 tiles of 64x64 (ResNet layer3/4 at batch 1, FPN laterals, the box heads' 1024-wide FC layers,
+// P6/P7) used to be split along K into fp32 slabs in global memory + a reduce launch.  Here a workgroup owns a 32x32 output
+// tile and each of its NW waves (4 or 8) walks a contiguous 1/NW of K with wave-PRIVATE operand staging: no workgroup barrier
+// inside the K loop, no slabs, no second launch.  The NW partial accumulators are added in wave order through LDS (fixed
+// order: deterministic) and wave 0 applies the fused epilogue.  The K walk does not depend on the row count, so a batch of
+// images gives bitwise the rows of the single-image call without a shared plan.
+// ------------------------------------------------------------------------------------------------------
+template <int NW, bool MULTI>
+__global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
+  constexpr int BK = 32;
+  constexpr int LS = BK + 4;
+  constexpr int AR = 4;          // tile rows per lane and operand: row = (lane >> 3) + 8 i, float4 column = lane & 7
+  __shared__ __attribute__((aligned(16))) float lds[NW * 2 * 32 * LS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  float* As = lds + wave * (2 * 32 * LS);
+  float* Bs = As + 32 * LS;
+
+  int M = p.M;
+  if (p.m_count) {
+    const int c = *p.m_count;
+    const int lim = c * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  const int ntiles = ((M + 31) / 32) * p.tiles_n;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+
+  // this wave's chunks
+  const int cpw = (p.nchunks + NW - 1) / NW;
+  const int c_begin = wave * cpw;
+  int c_end = c_begin + cpw;
+  if (c_end > p.nchunks) c_end = p.nchunks;
+
+  const int lr = lane >> 3, lq = lane & 7;
+  unsigned a_voff[AR];
+  unsigned long long a_mask[AR];
+  unsigned a_pitch[MULTI ? AR : 1];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lr + 8 * i;
+    int iy0 = 0, ix0 = 0, off = 0, hh = 1, ww = 1;
+    const bool rowok = m < M;
+    if (rowok) {
+      if (MULTI) {
+        int l = 0;
+        while (l + 1 < p.nlv && m >= p.lv_off[l + 1]) ++l;
+        const int local = m - p.lv_off[l];
+        ww = p.lv_w[l];
+        hh = p.lv_h[l];
+        const int oy = local / ww;
+        iy0 = oy - p.pad;
+        ix0 = (local - oy * ww) - p.pad;
+        off = p.lv_off[l];
+      } else {
+        const int t2 = (int)fdiv((unsigned)m, p.div_ow);
+        const int ox = m - t2 * p.OW;
+        const int img = (int)fdiv((unsigned)t2, p.div_oh);
+        const int oy = t2 - img * p.OH;
+        iy0 = oy * p.stride - p.pad;
+        ix0 = ox * p.stride - p.pad;
+        off = img * p.H * p.W;
+        hh = p.H;
+        ww = p.W;
+      }
+    }
+    a_mask[i] = rowok ? tap_mask(iy0, ix0, hh, ww, p.KH, p.KW) : 0ull;
+    a_voff[i] = (unsigned)(((off + iy0 * ww + ix0) * p.Cin + 4 * lq) * 4);
+    if (MULTI) a_pitch[i] = (unsigned)(ww * p.Cin * 4);
+  }
+  unsigned w_voff[AR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int n = n0 + lr + 8 * j;
+    w_voff[j] = n < p.Cout ? (unsigned)((n * p.Kpad + 4 * lq) * 4) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  f32x4 ar[AR], br[AR];
+  int nx_tap, nx_c0, nx_ky, nx_kx;
+  {
+    const int k0 = c_begin * BK;
+    nx_tap = k0 / p.Cin;
+    nx_c0 = k0 - nx_tap * p.Cin;
+    nx_ky = nx_tap / p.KW;
+    nx_kx = nx_tap - nx_ky * p.KW;
+  }
+  auto load_chunk = [&](int chunk) {
+    const int k0 = chunk * BK;
+    const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
+    nx_c0 += BK;
+    if (nx_c0 >= p.Cin) {
+      nx_c0 = 0;
+      ++nx_tap;
+      if (++nx_kx == p.KW) {
+        nx_kx = 0;
+        ++nx_ky;
+      }
+    }
+    const unsigned tap_off = MULTI ? (unsigned)((kx * p.Cin + c0) * 4) : (unsigned)(((ky * p.W + kx) * p.Cin + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = (a_mask[i] >> tap) & 1ull;
+      unsigned vo = a_voff[i] + tap_off;
+      if (MULTI) vo += (unsigned)ky * a_pitch[i];
+      vo = ok ? vo : 0xFFFFFFFFu;
+      ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0));
+    }
+    if (p.in_relu) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        ar[i].x = fmaxf(ar[i].x, 0.f);
+        ar[i].y = fmaxf(ar[i].y, 0.f);
+        ar[i].z = fmaxf(ar[i].z, 0.f);
+        ar[i].w = fmaxf(ar[i].w, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < AR; ++j)
+      br[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], k0 * 4, 0));
+  };
+
+  f32x16 acc, acc_b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[r] = 0.f;
+    acc_b[r] = 0.f;
+  }
+  const int frag_row = lane & 31;
+  const int frag_k = 4 * (lane >> 5);
+  const float* a_base = As + frag_row * LS + frag_k;
+  const float* b_base = Bs + frag_row * LS + frag_k;
+
+  if (c_begin < c_end) load_chunk(c_begin);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + 8 * i) * LS + 4 * lq) = ar[i];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + 8 * j) * LS + 4 * lq) = br[j];
+    // wave-private staging: the wave's own LDS writes are ordered before its reads by the waitcnt the compiler inserts; the
+    // fence keeps the compiler from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(b_base + kk * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc_b, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc_b, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc_b[r];
+
+  // partial sums of waves 1..NW-1 -> LDS (the operand tiles are dead), added by wave 0 in wave order
+  __syncthreads();
+  float* red = lds;     // [NW-1][16][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < NW; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
+  f32x16 out[1][1];
+  out[0][0] = acc;
+  store_wave_tiles<1, 1>(p, out, m0, n0, M, 0, lane);
+}
+
 }  // namespace
 
 template <int BM, int BN>
-static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s) {
+static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hipStream_t s, int dyn) {
   if (tap4)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, true, false>), grid, dim3(256), dyn, s, a);
   else if (a.nlv > 0 && bk == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, true>), grid, dim3(256), dyn, s, a);
   else if (a.nlv > 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, true>), grid, dim3(256), dyn, s, a);
   else if (bk == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64, false, false>), grid, dim3(256), dyn, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, false, false>), grid, dim3(256), dyn, s, a);
 }
 
-void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s) {
+// `lds_reserve`: dynamic LDS the launch allocates and the kernel never touches (EodConvDesc.lds_reserve): caps the workgroups per CU
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve) {
+  const int dyn = lds_reserve > 0 ? lds_reserve : 0;
   switch (tile) {
-    case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), 0, s, a); break;
-    case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s); break;
-    case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s); break;
-    default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s); break;
+    case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), dyn, s, a); break;
+    case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s, dyn); break;
+    case 2: launch_fp32_tile<128, 64>(a, tap4, bk, grid, s, dyn); break;
+    default: launch_fp32_tile<64, 64>(a, tap4, bk, grid, s, dyn); break;
+  }
+}
+
+// NW waves (4 or 8) per 32x32 tile; grid = ceil(M/32) * ceil(Cout/32) workgroups
+void launch_conv_wavek(const ConvArgs& a, int nw, dim3 grid, hipStream_t s) {
+  if (a.nlv > 0) {
+    if (nw == 8) hipLaunchKernelGGL((conv_wavek_kernel<8, true>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_wavek_kernel<4, true>), grid, dim3(256), 0, s, a);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((conv_wavek_kernel<8, false>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_wavek_kernel<4, false>), grid, dim3(256), 0, s, a);
   }
 }
 

@@ -80,7 +80,16 @@ struct Plan {
   int bk;    // K chunk staged per barrier pair: 32 or 64
   int glds;  // 2: bf16x3 split kernel (BK = 32); 0: fp32 MFMA kernel
   int bm, bn, tiles_m, tiles_n, splitk, cps, nchunks;
+  int wavek;  // 0, or the number of waves (4 / 8) of the 32x32-tile kernel that splits K over the waves of a workgroup
 };
+
+inline int wavek_env() {
+  static const int v = [] {
+    const char* e = getenv("EOD_CONV_WAVEK");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
 
 Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   // 256x128: bf16x3 8-wave kernel only; 64x256: fused mask-head tail (out_mode 2) only
@@ -125,6 +134,15 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     splitk = 1;
   } else if (d->force_splitk > 0) {
     splitk = d->force_splitk;
+  } else if (tiles < 256 && nchunks >= 8 && nchunks <= 192 && pl.glds == 0 && pl.bk == 32 && !d->tap4 && d->force_tile == 0 &&
+             wavek_env()) {
+    // Few rows, K up to 6144 (ResNet layer3/4 at batch 1, FPN laterals / outputs 4-5, P6/P7, the box heads' 1024-wide FC layers):
+    // K is split over the waves of a workgroup that owns a 32x32 tile (conv_wavek_kernel) -- no slabs, no reduce launch.  Eight
+    // waves once a wave's share would exceed 16 chunks.
+    pl.wavek = nchunks >= 64 ? 8 : 4;
+    pl.bm = pl.bn = 32;
+    pl.tiles_m = (M + 31) / 32;
+    pl.tiles_n = (d->Cout + 31) / 32;
   } else if (tiles < 256 && nchunks >= 8) {
     // Deep-K, few-row GEMMs (the box head's fc1: 320 x 12544 -> 1024, 80 tiles, 392 chunks) are a serial chain of ~1.5 us chunk
     // round trips per workgroup: 7 workgroups per CU instead of 2 shorten the chain 3.5x (105 -> ~35 us on the cascade's critical
@@ -198,6 +216,7 @@ int check_desc(const EodConvDesc* d) {
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(d->x) || !eod_aligned16(d->w) || !eod_aligned16(d->w_split)) return EOD_ERR_ALIGN;
   return EOD_OK;
 }
@@ -272,8 +291,9 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     if (!d->workspace || d->workspace_bytes < need) return EOD_ERR_CAPACITY;
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
-  if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
-  else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s);
+  if (pl.wavek) launch_conv_wavek(a, pl.wavek, grid, s);
+  else if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
+  else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s, d->lds_reserve);
   if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;
     const bool vec = a.Cout % 4 == 0;

@@ -20,7 +20,9 @@ __device__ __forceinline__ int dyn_rows(const int* count, int cap) {
 constexpr int ZS_MAX_C = 24;
 __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
-                                                           const int* __restrict__ count, int R_cap, int D, int C1, float temp) {
+                                                           const int* __restrict__ count, int R_cap, int D, int C1, float temp,
+                                                           const float* __restrict__ zs_mem, const float* __restrict__ prop_scores,
+                                                           float* __restrict__ mem_scores, float final_inv_stages) {
   EOD_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
   const int R = dyn_rows(count, R_cap);
@@ -32,24 +34,55 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
+  const bool active = row < R;
   float x[8];
-  float ss = 0.f;
-  {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8 + 4);
-    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-  }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) ss += x[q] * x[q];
-  ss = wave_reduce_sum(ss);
-  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+  for (int q = 0; q < 8; ++q) x[q] = 0.f;
+  if (active) {
+    float ss = 0.f;
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(feat + (size_t)row * D + lane * 8 + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) x[q] = temp * (x[q] / denom);
-  if (featn_out) {
-    *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8) = f32x4{x[0], x[1], x[2], x[3]};
-    *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8 + 4) = f32x4{x[4], x[5], x[6], x[7]};
+    for (int q = 0; q < 8; ++q) ss += x[q] * x[q];
+    ss = wave_reduce_sum(ss);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = temp * (x[q] / denom);
+    if (featn_out) {
+      *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8) = f32x4{x[0], x[1], x[2], x[3]};
+      *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8 + 4) = f32x4{x[4], x[5], x[6], x[7]};
+    }
+    const float ps = (final_inv_stages > 0.f && prop_scores) ? prop_scores[row] : 0.f;
+    for (int c = 0; c < C1; ++c) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
+      float s = 0.f;
+      s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
+      s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
+      s = wave_reduce_sum(s);
+      if (lane == 0) {
+        const float p = eod_sigmoid_precise(s);
+        float* o = prob_acc + (size_t)row * C1 + c;
+        float v = accumulate ? (*o + p) : p;
+        if (final_inv_stages > 0.f) v = sqrtf(v * final_inv_stages * ps);       // cascade score fusion (detic_roi_heads.py:164-173)
+        *o = v;
+      }
+    }
   }
+  if (!zs_mem) return;
+  // memory-side CLIP re-score (custom_rcnn.py:838-861) with the meta-architecture's own class matrix: same staging, same
+  // per-lane channel order and butterfly as eod_memory_scores on feat_norm_out
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * C1; i += blockDim.x) {
+    const int k = i / C1, c = i - k * C1;
+    zt[c * 512 + k] = zs_mem[i];
+  }
+  __syncthreads();
+  if (!active) return;
+  const float p = prop_scores[row];
   for (int c = 0; c < C1; ++c) {
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
     const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
@@ -57,11 +90,7 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
     s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
     s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
     s = wave_reduce_sum(s);
-    if (lane == 0) {
-      const float p = eod_sigmoid_precise(s);
-      float* o = prob_acc + (size_t)row * C1 + c;
-      *o = accumulate ? (*o + p) : p;
-    }
+    if (lane == 0) mem_scores[(size_t)row * C1 + c] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(s) * p) : 0.0f;
   }
 }
 
@@ -131,7 +160,7 @@ __global__ __launch_bounds__(512) void postprocess_kernel(const float* __restric
                                                            const int* __restrict__ classes, const int* __restrict__ count, int cap,
                                                            float sx, float sy, float out_w, float out_h, float* __restrict__ ob,
                                                            float* __restrict__ os, int* __restrict__ oc, int* __restrict__ osrc,
-                                                           int* __restrict__ ocount) {
+                                                           int* __restrict__ ocount, const int* __restrict__ remap) {
   __shared__ int sh_keep[512];
   __shared__ int sh_pos[512];
   const int D = dyn_rows(count, cap);
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(512) void postprocess_kernel(const float* __restric
     ob[q * 4 + 3] = b3;
     os[q] = scores[t];
     oc[q] = classes[t];
-    osrc[q] = t;
+    osrc[q] = remap ? remap[t] : t;
   }
 }
 
@@ -228,12 +257,18 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 }  // namespace
 
 extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_acc, int accumulate, float* feat_norm_out,
-                               const int32_t* count, int R_cap, int D, int C1, float temp, eod_stream_t stream) {
+                               const int32_t* count, int R_cap, int D, int C1, float temp, const float* zs_mem, const float* prop_scores,
+                               float* mem_scores_out, float final_inv_stages, eod_stream_t stream) {
   if (!feat || !zs || !prob_acc) return EOD_ERR_NULL;
-  if (D != 512 || C1 < 2 || C1 > ZS_MAX_C || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  if (zs_mem && (!prop_scores || !mem_scores_out)) return EOD_ERR_NULL;
+  if (final_inv_stages > 0.f && !prop_scores) return EOD_ERR_NULL;
+  // the class matrix is staged in 48 KB of LDS: vocabularies of more than ZS_MAX_C - 1 classes (RESET_CLS_TESTS) are refused here
+  // with a capacity error that ops.zs_classify words out
+  if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
+  if (C1 > ZS_MAX_C) return EOD_ERR_CAPACITY;
   if (!eod_aligned16(feat) || (feat_norm_out && !eod_aligned16(feat_norm_out))) return EOD_ERR_ALIGN;
   hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
-                     feat_norm_out, count, R_cap, D, C1, temp);
+                     feat_norm_out, count, R_cap, D, C1, temp, zs_mem, prop_scores, mem_scores_out, final_inv_stages);
   return eod_launch_status();
 }
 
@@ -266,11 +301,12 @@ extern "C" int eod_memory_scores(const float* featn, const float* zs, const floa
 
 extern "C" int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
                                         float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
-                                        int32_t* out_classes, int32_t* out_src, int32_t* out_count, eod_stream_t stream) {
+                                        int32_t* out_classes, int32_t* out_src, int32_t* out_count, const int32_t* remap,
+                                        eod_stream_t stream) {
   if (!boxes || !scores || !classes || !out_boxes || !out_scores || !out_classes || !out_src || !out_count) return EOD_ERR_NULL;
   if (cap <= 0 || cap > 512) return EOD_ERR_CAPACITY;
   hipLaunchKernelGGL(postprocess_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, boxes, scores, classes, count, cap, sx, sy, out_w,
-                     out_h, out_boxes, out_scores, out_classes, out_src, out_count);
+                     out_h, out_boxes, out_scores, out_classes, out_src, out_count, remap);
   return eod_launch_status();
 }
 

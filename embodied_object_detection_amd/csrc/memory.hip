@@ -92,23 +92,22 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------
-// a16-a19 write path
+// a16-a19 write path: three launches
+//   mw_cover_kernel    unique instance rows (custom_rcnn.py:875), per-pixel cover count, observed pixels per 4096-pixel block,
+//                      cells the frame hits
+//   mw_scatter_kernel  every 8th observed pixel in row-major order (custom_rcnn.py:913-914) adds its 1/cover share to the
+//                      (cell, instance) weight table
+//   mw_commit_kernel   per hit cell: mean of the per-pixel means from the weight table (f64, instance order), accumulate into the
+//                      memory, observation counter, fp16 snapshot row (or dirty mark); leaves every per-frame table zero again
 // ------------------------------------------------------------------------------------------------------
 struct MwWs {
   int* inst_rows;   // [R_cap] unique proposal rows, ascending
   int* k_u;         // [1]
   unsigned char* cover;  // [P]
-  int* sel_pix;     // [P/8+1]
-  int* n_sel;       // [1]
-  int* cell_flag;   // [N] any pixel of the frame hit the cell
-  int* cell_mark;   // [N] a selected pixel hit the cell
-  int* cell_slot;   // [N]
-  int* slot_cell;   // [U_max]
-  int* n_slots;     // [1]
-  long long* wtab;  // [U_max, K_cap] fixed point 2^-32: sum over the slot's sampled pixels of 1/cover for every instance
-  int* slot_cnt;    // [U_max]
+  int* cell_flag;   // [N] any pixel of the frame hit the cell                                   (zero between calls)
+  int* cell_cnt;    // [N] number of sampled pixels that hit the cell                             (zero between calls)
+  long long* wtab;  // [N, K_cap] fixed point 2^-32: sum over the cell's sampled pixels of 1/cover for every instance (zero between calls)
   int* blk_pix;     // [ceil(P/4096)]
-  int* blk_cell;    // [ceil(N/4096)]
   size_t bytes;
 };
 
@@ -125,49 +124,65 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap
     return p;
   };
   const size_t P = (size_t)H * W;
-  const size_t smax = P / 8 + 1;
-  const size_t umax = smax < (size_t)n_cells ? smax : (size_t)n_cells;
   w.inst_rows = (int*)take((size_t)R_cap * 4);
   w.k_u = (int*)take(4);
   w.cover = (unsigned char*)take(P);
-  w.sel_pix = (int*)take(smax * 4);
-  w.n_sel = (int*)take(4);
   w.cell_flag = (int*)take((size_t)n_cells * 4);
-  w.cell_mark = (int*)take((size_t)n_cells * 4);
-  w.cell_slot = (int*)take((size_t)n_cells * 4);
-  w.slot_cell = (int*)take(umax * 4);
-  w.n_slots = (int*)take(4);
-  w.wtab = (long long*)take(umax * (size_t)K_cap * 8);
-  w.slot_cnt = (int*)take(umax * 4);
+  w.cell_cnt = (int*)take((size_t)n_cells * 4);
+  w.wtab = (long long*)take((size_t)n_cells * (size_t)K_cap * 8);
   w.blk_pix = (int*)take(((P + 4095) / 4096 + 1) * 4);
-  w.blk_cell = (int*)take((((size_t)n_cells + 4095) / 4096 + 1) * 4);
   w.bytes = off;
   return w;
 }
 
-// unique(det_rows) ascending (custom_rcnn.py:875); single block
-__global__ __launch_bounds__(512) void mw_unique_rows_kernel(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
-                                                              int R_cap, int* __restrict__ inst_rows, int* __restrict__ k_u,
-                                                              int* __restrict__ k_out) {
-  EOD_CHAIN_PRIO();
-  __shared__ int flag[512];
+#define MW_MAX_R 512
+#define MW_MAX_K 128
+
+// unique(det_rows) ascending (custom_rcnn.py:875) by all 512 threads of the calling block's first 8 waves: flags in LDS, ballot
+// compaction.  Returns the count; `rows_s[0..count)` holds the rows.  Every thread of the block must call it.
+__device__ __forceinline__ int block_unique_rows(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap, int R_cap,
+                                                 int* flag_s /*[512]*/, int* wcnt_s /*[8]*/, int* rows_s /*[MW_MAX_K]*/) {
   const int t = threadIdx.x;
-  flag[t] = 0;
+  if (t < MW_MAX_R) flag_s[t] = 0;
   __syncthreads();
   int K = *det_count;
   K = K < K_cap ? K : K_cap;
   for (int i = t; i < K; i += blockDim.x) {
     const int r = det_rows[i];
-    if (r >= 0 && r < R_cap) flag[r] = 1;
+    if (r >= 0 && r < R_cap) flag_s[r] = 1;
   }
   __syncthreads();
-  if (t == 0) {
-    int n = 0;
-    for (int r = 0; r < R_cap; ++r)
-      if (flag[r]) inst_rows[n++] = r;
-    *k_u = n;
-    if (k_out) *k_out = n;
+  const int lane = t & 63, wave = t >> 6;
+  int f = 0;
+  unsigned long long bal = 0;
+  if (t < MW_MAX_R) {
+    f = flag_s[t];
+    bal = __ballot(f != 0);
+    if (lane == 0) wcnt_s[wave] = __popcll(bal);
   }
+  __syncthreads();
+  int total = 0, before = 0;
+#pragma unroll
+  for (int w = 0; w < MW_MAX_R / 64; ++w) {
+    const int c = wcnt_s[w];
+    if (w < wave) before += c;
+    total += c;
+  }
+  if (t < MW_MAX_R && f) {
+    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pos < MW_MAX_K) rows_s[pos] = t;
+  }
+  __syncthreads();
+  return total < MW_MAX_K ? total : MW_MAX_K;
+}
+
+__global__ __launch_bounds__(512) void mw_unique_rows_kernel(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
+                                                              int R_cap, int* __restrict__ inst_rows, int* __restrict__ k_u) {
+  EOD_CHAIN_PRIO();
+  __shared__ int flag_s[MW_MAX_R], wcnt_s[8], rows_s[MW_MAX_K];
+  const int n = block_unique_rows(det_rows, det_count, K_cap, R_cap, flag_s, wcnt_s, rows_s);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) inst_rows[i] = rows_s[i];
+  if (threadIdx.x == 0) *k_u = n;
 }
 
 // mask test of one instance at pixel centre (x+0.5, y+0.5): same arithmetic as paste_masks_kernel
@@ -193,46 +208,45 @@ __device__ __forceinline__ bool mask_hit(const float* __restrict__ m, float x0, 
   return v >= thr;
 }
 
-// per pixel: number of covering instances; marks every cell the frame hits (for the observation counters)
-__global__ __launch_bounds__(256) void mw_coverage_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                           const int* __restrict__ proj, int H, int W, int n_cells, float thr,
-                                                           unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
-                                                           int* __restrict__ err) {
-  EOD_CHAIN_PRIO();
-  const int K = *k_u;
-  if (K == 0) return;
-  bool bad = false;
-  const int total = H * W;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
-    const int y = p / W, x = p - y * W;
-    int cnt = 0;
-    for (int k = 0; k < K; ++k) {
-      const int r = inst_rows[k];
-      const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
-      // quick reject: a sample more than one mask pixel outside the box is zero
-      const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
-      const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
-      if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
-      if (mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr)) ++cnt;
-    }
-    cover[p] = (unsigned char)cnt;
-    int cell = proj[p];
-    if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
-      bad = true;
-      cell = cell < 0 ? 0 : n_cells - 1;
-    }
-    cell_flag[cell] = 1;
-  }
-  if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
-}
-
 __device__ __forceinline__ int clamp_cell(int cell, int n_cells) { return cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell); }
 
-// Stream compaction in two launches: per-block counts, then per-block local scan + prefix of the block counts.
-// Block = 1024 threads x 4 consecutive elements.  Used for (a) observed pixels -> every 8th in row-major order
-// (custom_rcnn.py:913-914) and (b) marked cells -> slot ids in ascending cell order.
 #define SCAN_ELEMS 4096
+
+// The instances whose box (grown by one mask pixel: a sample further out is exactly zero) reaches the image rows of this block's
+// 4096 pixels, in instance order: cand_s[i] = index k into the unique list, box_s[i] = its box.  Returns their number.
+__device__ __forceinline__ int block_band_candidates(const float* __restrict__ boxes, const int* rows_s, int K, int W, int P,
+                                                     int* cand_s, float* box_s, int* ncand_s) {
+  const int p0 = blockIdx.x * SCAN_ELEMS;
+  int p1 = p0 + SCAN_ELEMS - 1;
+  if (p1 > P - 1) p1 = P - 1;
+  const float ylo = (float)(p0 / W) + 0.5f, yhi = (float)(p1 / W) + 0.5f;
+  if (threadIdx.x == 0) *ncand_s = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {                      // one wave, instance order kept by ballot compaction
+    int base = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + (int)threadIdx.x;
+      bool in = false;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (k < K) {
+        const int r = rows_s[k];
+        b0 = boxes[r * 4 + 0]; b1 = boxes[r * 4 + 1]; b2 = boxes[r * 4 + 2]; b3 = boxes[r * 4 + 3];
+        const float my = (b3 - b1) * (1.0f / 14.0f);
+        in = !(yhi < b1 - my || ylo > b3 + my);
+      }
+      const unsigned long long bal = __ballot(in);
+      if (in) {
+        const int pos = base + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+        cand_s[pos] = k;
+        box_s[pos * 4 + 0] = b0; box_s[pos * 4 + 1] = b1; box_s[pos * 4 + 2] = b2; box_s[pos * 4 + 3] = b3;
+      }
+      base += __popcll(bal);
+    }
+    if (threadIdx.x == 0) *ncand_s = base;
+  }
+  __syncthreads();
+  return *ncand_s;
+}
 
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   __shared__ int wsum[16];
@@ -260,226 +274,215 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   return wsum[wave] + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void mw_count_pixels_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
-                                                                int* __restrict__ block_cnt) {
+// Launch 1.  Block = 1024 threads x 4 consecutive pixels.
+__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                         const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
+                                                         int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
+                                                         unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
+                                                         int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
+                                                         int* __restrict__ k_out, int* __restrict__ err) {
   EOD_CHAIN_PRIO();
-  if (*k_u == 0) return;
-  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (base + j < P) c += cover[base + j] > 0;
-  int total;
-  block_exclusive_scan_1024(c, &total);
-  if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void mw_select_kernel(const unsigned char* __restrict__ cover, const int* __restrict__ k_u, int P,
-                                                          const int* __restrict__ proj, int n_cells, const int* __restrict__ block_cnt,
-                                                          int* __restrict__ sel_pix, int* __restrict__ n_sel, int* __restrict__ cell_mark) {
-  EOD_CHAIN_PRIO();
-  if (*k_u == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_sel = 0;
-    return;
-  }
-  __shared__ int sh_off;
-  if (threadIdx.x < 64) {
-    int s = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) s += block_cnt[b];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) sh_off = s;
-  }
-  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-  int c = 0;
-  bool ob[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    ob[j] = (base + j < P) && cover[base + j] > 0;
-    c += ob[j];
-  }
-  int total;
-  int rank = block_exclusive_scan_1024(c, &total) + sh_off;   // the scan's barriers also publish sh_off
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (ob[j]) {
-      if ((rank & 7) == 0) {
-        sel_pix[rank >> 3] = base + j;
-        cell_mark[clamp_cell(proj[base + j], n_cells)] = 1;
-      }
-      ++rank;
+  __shared__ int flag_s[MW_MAX_R], wcnt_s[8], rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s;
+  __shared__ float box_s[MW_MAX_K * 4];
+  const int K = block_unique_rows(det_rows, det_count, K_cap, R_cap, flag_s, wcnt_s, rows_s);
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < K; i += blockDim.x) inst_rows[i] = rows_s[i];
+    if (threadIdx.x == 0) {
+      *k_u = K;
+      if (k_out) *k_out = K;
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_sel = (sh_off + total + 7) >> 3;
-}
-
-__global__ __launch_bounds__(1024) void mw_count_cells_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
-                                                               int* __restrict__ block_cnt) {
-  EOD_CHAIN_PRIO();
-  if (*k_u == 0) return;
+  if (K == 0) return;                      // update_implicit_memory returns before touching the state (custom_rcnn.py:689-690)
+  const int P = H * W;
+  const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
   const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (base + j < N) c += cell_mark[base + j] != 0;
-  int total;
-  block_exclusive_scan_1024(c, &total);
-  if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void mw_slots_kernel(const int* __restrict__ cell_mark, const int* __restrict__ k_u, int N,
-                                                         const int* __restrict__ block_cnt, int* __restrict__ cell_slot,
-                                                         int* __restrict__ slot_cell, int* __restrict__ n_slots) {
-  EOD_CHAIN_PRIO();
-  if (*k_u == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_slots = 0;
-    return;
-  }
-  __shared__ int sh_off;
-  if (threadIdx.x < 64) {
-    int s = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) s += block_cnt[b];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) sh_off = s;
-  }
-  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-  int c = 0;
-  bool mk[4];
+  bool bad = false;
+  int observed = 0;
+  unsigned pk = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    mk[j] = (base + j < N) && cell_mark[base + j] != 0;
-    c += mk[j];
+    const int p = base + j;
+    if (p >= P) break;
+    const int y = p / W, x = p - y * W;
+    const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+    int cnt = 0;
+    for (int i = 0; i < nc; ++i) {
+      const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
+      // quick reject: a sample more than one mask pixel outside the box is zero
+      const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
+      if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
+      if (mask_hit(masks + (size_t)rows_s[cand_s[i]] * 784, x0, y0, x1, y1, x, y, thr)) ++cnt;
+    }
+    pk |= (unsigned)(cnt & 0xFF) << (8 * j);
+    observed += cnt > 0;
+    int cell = proj[p];
+    if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
+      bad = true;
+      cell = cell < 0 ? 0 : n_cells - 1;
+    }
+    cell_flag[cell] = 1;
   }
+  if (base + 3 < P) {
+    *reinterpret_cast<unsigned*>(cover + base) = pk;              // P % 4 == 0 on this path (H, W multiples of 32)
+  } else {
+    for (int j = 0; j < 4 && base + j < P; ++j) cover[base + j] = (unsigned char)((pk >> (8 * j)) & 0xFF);
+  }
+  int total;
+  block_exclusive_scan_1024(observed, &total);
+  if (threadIdx.x == 0) blk_pix[blockIdx.x] = total;
+  if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
+}
+
+// Launch 2.  The per-cell mean of the per-pixel means (custom_rcnn.py:884-936) is linear in the instance features:
+//   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
+// so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
+// bitwise reproducible) instead of 512 channel atomics.
+__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
+                                                           const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
+                                                           const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
+                                                           long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
+  EOD_CHAIN_PRIO();
+  const int K = *k_u;
+  if (K == 0) return;
+  __shared__ int rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s, sh_off;
+  __shared__ float box_s[MW_MAX_K * 4];
+  const int P = H * W;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) rows_s[i] = inst_rows[i];
+  if (threadIdx.x >= 64 && threadIdx.x < 128) {       // second wave: observed pixels in the blocks before this one
+    int s = 0;
+    for (int b = threadIdx.x - 64; b < (int)blockIdx.x; b += 64) s += blk_pix[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 64) sh_off = s;
+  }
+  __syncthreads();
+  const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
+  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  unsigned pk = 0;
+  if (base + 3 < P) {
+    pk = *reinterpret_cast<const unsigned*>(cover + base);
+  } else {
+    for (int j = 0; j < 4 && base + j < P; ++j) pk |= (unsigned)cover[base + j] << (8 * j);
+  }
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c += ((pk >> (8 * j)) & 0xFF) != 0;
   int total;
   int rank = block_exclusive_scan_1024(c, &total) + sh_off;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (mk[j]) {
-      cell_slot[base + j] = rank;
-      slot_cell[rank] = base + j;
-      ++rank;
+    const int cv = (int)((pk >> (8 * j)) & 0xFF);
+    if (cv == 0) continue;
+    if ((rank & 7) == 0) {                           // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
+      const int p = base + j;
+      const int y = p / W, x = p - y * W;
+      const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+      const int cell = clamp_cell(proj[p], n_cells);
+      const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)cv);
+      long long* dst = wtab + (size_t)cell * K_cap;
+      atomicAdd(cell_cnt + cell, 1);
+      for (int i = 0; i < nc; ++i) {
+        const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
+        const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
+        if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
+        if (mask_hit(masks + (size_t)rows_s[cand_s[i]] * 784, x0, y0, x1, y1, x, y, thr))
+          atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
+      }
     }
+    ++rank;
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_slots = sh_off + total;
 }
 
-__global__ __launch_bounds__(256) void mw_zero_slots_kernel(long long* __restrict__ wtab, int* __restrict__ slot_cnt,
-                                                             const int* __restrict__ n_slots, int K_cap) {
-  EOD_CHAIN_PRIO();
-  const size_t total = (size_t)(*n_slots) * K_cap;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) wtab[i] = 0;
-  const int ns = *n_slots;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) slot_cnt[i] = 0;
-}
-
-// The per-cell mean of the per-pixel means (custom_rcnn.py:884-936) is linear in the instance features:
-//   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
-// so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
-// bitwise reproducible) instead of 512 channel atomics.  One wave per sampled pixel, lanes over the instances.
-__global__ __launch_bounds__(256) void mw_accumulate_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                             const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                             const int* __restrict__ sel_pix, const int* __restrict__ n_sel,
-                                                             const unsigned char* __restrict__ cover, const int* __restrict__ proj,
-                                                             int n_cells, const int* __restrict__ cell_slot, int W, int K_cap, float thr,
-                                                             long long* __restrict__ wtab, int* __restrict__ slot_cnt) {
+// Launch 3.  The 4 waves of a workgroup share one 64-cell group and split its hit cells (bit index mod 4); one wave per cell,
+// 8 consecutive channels per lane.  For a cell with sampled pixels: mean = (sum_k W_k f_k) / n in f64 (instance order),
+// mem[cell] += mean (custom_rcnn.py:738-743).  Every hit cell: observation counter + 1 (custom_rcnn.py:699-701,743) and either its
+// row of the fp16 snapshot (`snapshot`: the table the next frame's gather reads -- what eod_memory_normalize_dirty_f16 would do
+// at the start of the next frame, without its launch and its scan of the flags) or its `dirty` mark.  Resets the per-frame
+// tables it consumed (flags, counts, weight-table entries).
+template <bool SNAPSHOT>
+__global__ __launch_bounds__(256) void mw_commit_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_cnt, long long* __restrict__ wtab,
+                                                         const int* __restrict__ k_u, const int* __restrict__ inst_rows,
+                                                         const float* __restrict__ featn, int K_cap, int N, float* __restrict__ obs,
+                                                         float* __restrict__ mem, __half* __restrict__ snapshot, int* __restrict__ dirty) {
   EOD_CHAIN_PRIO();
   const int K = *k_u;
-  const int S = *n_sel;
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int s = blockIdx.x * wpb + (threadIdx.x >> 6); s < S; s += gridDim.x * wpb) {
-    const int p = sel_pix[s];
-    const int y = p / W, x = p - y * W;
-    const long long share = (long long)llrint(4294967296.0 / (double)cover[p]);
-    const int slot = cell_slot[clamp_cell(proj[p], n_cells)];
-    long long* dst = wtab + (size_t)slot * K_cap;
-    for (int k = lane; k < K; k += 64) {
-      const int r = inst_rows[k];
-      const float x0 = boxes[r * 4 + 0], y0 = boxes[r * 4 + 1], x1 = boxes[r * 4 + 2], y1 = boxes[r * 4 + 3];
-      if (mask_hit(masks + (size_t)r * 784, x0, y0, x1, y1, x, y, thr))
-        atomicAdd(reinterpret_cast<unsigned long long*>(dst + k), (unsigned long long)share);
-    }
-    if (lane == 0) atomicAdd(slot_cnt + slot, 1);
-  }
-}
-
-// one wave per slot: mean = (sum_k W_k f_k) / n in f64 (instance order), mem[cell] += mean (custom_rcnn.py:738-743)
-__global__ __launch_bounds__(256) void mw_apply_kernel(const long long* __restrict__ wtab, const int* __restrict__ slot_cnt,
-                                                        const int* __restrict__ slot_cell, const int* __restrict__ n_slots,
-                                                        const float* __restrict__ featn, const int* __restrict__ inst_rows,
-                                                        const int* __restrict__ k_u, int K_cap, int D, float* __restrict__ mem) {
-  EOD_CHAIN_PRIO();
-  const int K = *k_u;
-  const int NS = *n_slots;
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int slot = blockIdx.x * wpb + (threadIdx.x >> 6); slot < NS; slot += gridDim.x * wpb) {
-    double a[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a[q] = 0.0;
-    const long long* wt = wtab + (size_t)slot * K_cap;
-    for (int k = 0; k < K; ++k) {
-      const long long wk = wt[k];
-      if (wk == 0) continue;                      // wave-uniform
-      const double w = (double)wk * (1.0 / 4294967296.0);
-      const float* f = featn + (size_t)inst_rows[k] * D + lane;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] += w * (double)f[q * 64];
-    }
-    const double inv = 1.0 / (double)slot_cnt[slot];
-    float* m = mem + (size_t)slot_cell[slot] * D + lane;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) m[q * 64] = m[q * 64] + (float)(a[q] * inv);
-  }
-}
-
-// observation counters (custom_rcnn.py:699-701,743) + reset of the per-frame cell flags
-// `dirty` (caller-owned, may be NULL): every cell whose observation count (hence its normalised row) changed; consumed and
-// cleared by eod_memory_normalize_dirty_f16.  Cells written by mw_apply are a subset (sampled pixels are pixels of the frame).
-__global__ __launch_bounds__(256) void mw_obs_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark, const int* __restrict__ k_u,
-                                                      int N, float* __restrict__ obs, int* __restrict__ dirty) {
-  EOD_CHAIN_PRIO();
-  if (*k_u == 0) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    if (cell_flag[i]) {
-      obs[i] += 1.0f;
-      cell_flag[i] = 0;
-      if (dirty) dirty[i] = 1;
-    }
-    cell_mark[i] = 0;
-  }
-}
-
-// The same counters, and in the same pass the fp16 snapshot rows of exactly the cells whose count changed (`snapshot`: the
-// table the next frame's gather reads; a cell written by mw_apply is a sampled pixel's cell, hence among them): what
-// eod_memory_normalize_dirty_f16 would do at the start of the next frame, without its launch and its second scan of the flags.
-// The 4 waves of a workgroup share one 64-cell group and split its rows (bit index mod 4).
-__global__ __launch_bounds__(256) void mw_obs_snapshot_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_mark,
-                                                               const int* __restrict__ k_u, int N, float* __restrict__ obs,
-                                                               const float* __restrict__ mem, __half* __restrict__ snapshot) {
-  EOD_CHAIN_PRIO();
-  if (*k_u == 0) return;
+  if (K == 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n_groups = (N + 63) >> 6;
   for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int c = (g << 6) + lane;
-    int f = 0;
+    int f = 0, n = 0;
     float o = 0.f;
     if (c < N) {
       f = cell_flag[c];
       o = obs[c];
+      n = cell_cnt[c];
     }
     __syncthreads();                       // every wave has read the flags and counts before wave 0 updates them
     if (f) o += 1.0f;
-    if (wave == 0 && c < N) {
-      if (f) {
-        obs[c] = o;
-        cell_flag[c] = 0;
-      }
-      cell_mark[c] = 0;
+    if (wave == 0 && c < N && f) {
+      obs[c] = o;
+      cell_flag[c] = 0;
+      if (n) cell_cnt[c] = 0;
+      if (!SNAPSHOT && dirty) dirty[c] = 1;
     }
-    const unsigned long long bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
-    eod_snapshot_rows(mem, snapshot, g, bal, lane, [&](int bit) { return __shfl(o, bit, 64); });
+    unsigned long long bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
+    while (bal) {
+      const int bit = (int)__ffsll((long long)bal) - 1;
+      bal &= bal - 1;
+      const int cell = (g << 6) + bit;
+      const float ob = __shfl(o, bit, 64);
+      const int nb = __shfl(n, bit, 64);
+      float* mrow = mem + (size_t)cell * 512 + lane * 8;
+      if (nb == 0 && !SNAPSHOT) continue;
+      f32x4 x = *reinterpret_cast<const f32x4*>(mrow);
+      f32x4 y = *reinterpret_cast<const f32x4*>(mrow + 4);
+      if (nb > 0) {
+        long long* wt = wtab + (size_t)cell * K_cap;
+        const long long w0 = lane < K ? wt[lane] : 0;
+        const long long w1 = (lane + 64) < K ? wt[lane + 64] : 0;
+        if (w0) wt[lane] = 0;
+        if (w1) wt[lane + 64] = 0;
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          unsigned long long nz = __ballot((half ? w1 : w0) != 0);
+          while (nz) {
+            const int kl = (int)__ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            const long long wk = __shfl(half ? w1 : w0, kl, 64);
+            const double w = (double)wk * (1.0 / 4294967296.0);
+            const float* fr = featn + (size_t)inst_rows[kl + 64 * half] * 512 + lane * 8;
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(fr);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(fr + 4);
+            a[0] += w * (double)fa.x; a[1] += w * (double)fa.y; a[2] += w * (double)fa.z; a[3] += w * (double)fa.w;
+            a[4] += w * (double)fb.x; a[5] += w * (double)fb.y; a[6] += w * (double)fb.z; a[7] += w * (double)fb.w;
+          }
+        }
+        const double inv = 1.0 / (double)nb;
+        x.x = x.x + (float)(a[0] * inv); x.y = x.y + (float)(a[1] * inv); x.z = x.z + (float)(a[2] * inv); x.w = x.w + (float)(a[3] * inv);
+        y.x = y.x + (float)(a[4] * inv); y.y = y.y + (float)(a[5] * inv); y.z = y.z + (float)(a[6] * inv); y.w = y.w + (float)(a[7] * inv);
+        *reinterpret_cast<f32x4*>(mrow) = x;
+        *reinterpret_cast<f32x4*>(mrow + 4) = y;
+      }
+      if (SNAPSHOT) {
+        if (ob > 1.0f) {
+          x.x = __fdiv_rn(x.x, ob); x.y = __fdiv_rn(x.y, ob); x.z = __fdiv_rn(x.z, ob); x.w = __fdiv_rn(x.w, ob);
+          y.x = __fdiv_rn(y.x, ob); y.y = __fdiv_rn(y.y, ob); y.z = __fdiv_rn(y.z, ob); y.w = __fdiv_rn(y.w, ob);
+        }
+        __half2 h0 = __floats2half2_rn(x.x, x.y), h1 = __floats2half2_rn(x.z, x.w);
+        __half2 h2 = __floats2half2_rn(y.x, y.y), h3 = __floats2half2_rn(y.z, y.w);
+        uint4 pk;
+        pk.x = *reinterpret_cast<unsigned*>(&h0);
+        pk.y = *reinterpret_cast<unsigned*>(&h1);
+        pk.z = *reinterpret_cast<unsigned*>(&h2);
+        pk.w = *reinterpret_cast<unsigned*>(&h3);
+        *reinterpret_cast<uint4*>(snapshot + (size_t)cell * 512 + lane * 8) = pk;
+      }
+    }
   }
 }
 
@@ -526,22 +529,22 @@ extern "C" size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_ce
 
 extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int K_cap, int R_cap,
                                      eod_stream_t stream) {
-  // the per-frame cell flags must start at zero; every eod_memory_write leaves them zero again
+  // the per-frame cell tables must start at zero; every eod_memory_write leaves them zero again
   if (!workspace) return EOD_ERR_NULL;
-  if (K_cap <= 0) return EOD_ERR_BAD_DIMS;
+  if (K_cap <= 0 || K_cap > MW_MAX_K || R_cap <= 0 || R_cap > MW_MAX_R) return EOD_ERR_BAD_DIMS;
   const MwWs w = mw_carve(workspace, H, W, D, n_cells, R_cap, K_cap);
   if (workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   if (hipMemsetAsync(w.cell_flag, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
-  if (hipMemsetAsync(w.cell_mark, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  if (hipMemsetAsync(w.cell_cnt, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  if (hipMemsetAsync(w.wtab, 0, (size_t)n_cells * (size_t)K_cap * 8, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
   return eod_launch_status();
 }
 
 extern "C" int eod_unique_rows(const int32_t* rows, const int32_t* count, int K_cap, int R_cap, int32_t* out_rows, int32_t* out_count,
                                eod_stream_t stream) {
   if (!rows || !count || !out_rows || !out_count) return EOD_ERR_NULL;
-  if (K_cap <= 0 || R_cap <= 0 || R_cap > 512) return EOD_ERR_BAD_DIMS;
-  hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, rows, count, K_cap, R_cap, out_rows, out_count,
-                     (int*)nullptr);
+  if (K_cap <= 0 || K_cap > MW_MAX_K || R_cap <= 0 || R_cap > MW_MAX_R) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, rows, count, K_cap, R_cap, out_rows, out_count);
   return eod_launch_status();
 }
 
@@ -549,37 +552,28 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   if (!d || !d->featn || !d->prop_boxes || !d->prop_masks || !d->det_rows || !d->det_count || !d->proj || !d->mem || !d->obs ||
       !d->workspace)
     return EOD_ERR_NULL;
-  if (d->H <= 0 || d->W <= 0 || d->D != 512 || d->n_cells <= 0 || d->R_cap <= 0 || d->R_cap > 512 || d->K_cap <= 0)
+  if (d->H <= 0 || d->W <= 0 || d->D != 512 || d->n_cells <= 0 || d->R_cap <= 0 || d->R_cap > MW_MAX_R || d->K_cap <= 0 ||
+      d->K_cap > MW_MAX_K)
     return EOD_ERR_BAD_DIMS;
   const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap, d->K_cap);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
-  if (d->snapshot_f16 && (!eod_aligned16(d->snapshot_f16) || !eod_aligned16(d->mem))) return EOD_ERR_ALIGN;
+  if (!eod_aligned16(d->mem) || !eod_aligned16(d->featn) || (d->snapshot_f16 && !eod_aligned16(d->snapshot_f16))) return EOD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
-  hipLaunchKernelGGL(mw_unique_rows_kernel, dim3(1), dim3(512), 0, s, d->det_rows, d->det_count, d->K_cap, d->R_cap, w.inst_rows, w.k_u,
-                     d->k_out);
-  hipLaunchKernelGGL(mw_coverage_kernel, dim3(blocks_for((size_t)P)), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u,
-                     d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, d->err_flags);
-  const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS, cb = (d->n_cells + SCAN_ELEMS - 1) / SCAN_ELEMS;
-  hipLaunchKernelGGL(mw_count_pixels_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, w.blk_pix);
-  hipLaunchKernelGGL(mw_select_kernel, dim3(pb), dim3(1024), 0, s, w.cover, w.k_u, P, d->proj, d->n_cells, w.blk_pix, w.sel_pix, w.n_sel,
-                     w.cell_mark);
-  hipLaunchKernelGGL(mw_count_cells_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell);
-  hipLaunchKernelGGL(mw_slots_kernel, dim3(cb), dim3(1024), 0, s, w.cell_mark, w.k_u, d->n_cells, w.blk_cell, w.cell_slot, w.slot_cell,
-                     w.n_slots);
-  hipLaunchKernelGGL(mw_zero_slots_kernel, dim3(512), dim3(256), 0, s, w.wtab, w.slot_cnt, w.n_slots, d->K_cap);
-  hipLaunchKernelGGL(mw_accumulate_kernel, dim3(2048), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.sel_pix,
-                     w.n_sel, w.cover, d->proj, d->n_cells, w.cell_slot, d->W, d->K_cap, d->mask_thresh, w.wtab, w.slot_cnt);
-  hipLaunchKernelGGL(mw_apply_kernel, dim3(1024), dim3(256), 0, s, w.wtab, w.slot_cnt, w.slot_cell, w.n_slots, d->featn, w.inst_rows,
-                     w.k_u, d->K_cap, d->D, d->mem);
-  if (d->snapshot_f16) {
-    int groups = (d->n_cells + 63) / 64;
-    hipLaunchKernelGGL(mw_obs_snapshot_kernel, dim3(groups < 4096 ? groups : 4096), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u,
-                       d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16));
-  } else {
-    hipLaunchKernelGGL(mw_obs_kernel, dim3(blocks_for((size_t)d->n_cells)), dim3(256), 0, s, w.cell_flag, w.cell_mark, w.k_u, d->n_cells,
-                       d->obs, d->dirty);
-  }
+  const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS;
+  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
+                     d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, w.blk_pix, w.inst_rows, w.k_u, d->k_out,
+                     d->err_flags);
+  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
+                     d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt);
+  int groups = (d->n_cells + 63) / 64;
+  if (groups > 4096) groups = 4096;
+  if (d->snapshot_f16)
+    hipLaunchKernelGGL(mw_commit_kernel<true>, dim3(groups), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16), (int*)nullptr);
+  else
+    hipLaunchKernelGGL(mw_commit_kernel<false>, dim3(groups), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows,
+                       d->featn, d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty);
   return eod_launch_status();
 }
 

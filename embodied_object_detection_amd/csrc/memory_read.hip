@@ -10,9 +10,11 @@
 //    123 MB at 40 000 cells, 805 MB at 262 144) for a few thousand changed rows.
 //  * the gather fetches every DISTINCT cell of a 16x16 pixel quadrant once into LDS (wave-level ballot de-duplication, rows
 //    brought in by global -> LDS DMA; round 1 issued one 1 KiB row read per pixel: 420 MB of L2 traffic for <= 60 MB
-//    compulsory) and pools out of LDS with one v_fma_mix_f32 per element.  A 4x4
-//    block whose 16 pixels share one cell is the cell's value exactly (n*v is exact in f32 for n <= 16 and an 11-bit v), so
-//    the 16 adds are skipped; every other block is summed in torch's row-major order: results stay bit-identical.
+//    compulsory) and pools out of LDS.  Two summation orders (ABI argument `torch_order`): 1 = pixel by pixel in
+//    F.avg_pool2d's row-major order, bit-identical to the reference on every input (what the product path uses); 0 = per distinct
+//    cell of a 4x4 block, count x row with one v_fma_mix_f32 per element -- the same 16 numbers with fewer roundings, identical
+//    to the sequential sum only when that sum is exact (exponents inside the block within 9 bits per channel), ~9 us faster at
+//    640x640 (13.6 against 22.6 us on the synthetic scene, profiles/r02_mem_bench_rocprof.txt).
 //  * the three 1x1 projections + "x MAP_FEATURE_WEIGHT" + fusion are ONE launch on the f16 matrix cores: the pooled operand is
 //    exactly fp16 (timm.py:168 casts it), each fp32 weight is split into TWO f16 pieces of a per-row power-of-two scaling
 //    (round-to-nearest residual: h + m carries 11 + 1 + 11 + 1 = 24 significant bits, i.e. |w - (h + m)| <= 2^-24 |w|, the size
@@ -20,6 +22,7 @@
 //    fp32-MFMA rate.  Out-of-range cell indices are clamped and flagged.
 #include "eod_common.h"
 #include "memory_rows.h"
+#include <mutex>
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -596,7 +599,14 @@ extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* pr
   if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
   const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
-  static bool attr_set = false;
+  // the attribute belongs to the (device, function) pair: one flag per device ordinal, set under a mutex (a second device in the
+  // process, or a concurrent first call, must not launch a 72 KB dynamic-LDS kernel without it)
+  static std::mutex attr_mutex;
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return EOD_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(attr_mutex);
+  bool& attr_set = attr_set_dev[dev];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess ||

@@ -9,9 +9,11 @@
 // Every list has a fixed capacity and a device-side count.  Ordering is made total and deterministic with
 // 64-bit keys  (float bits of the score) << 32 | ~index : descending key order == descending score, ties ->
 // lower original index first (the rule the CPU oracle uses where upstream is implementation-defined).
-// Sorting is an in-LDS bitonic network (<= 16384 keys = 128 KiB of the 160 KiB LDS); NMS is the classic
-// 64x64-bit suppression matrix followed by a single-workgroup scan that resolves each 64-box diagonal block
-// in registers of one wave and stops as soon as the requested number of boxes has been kept.
+// Sorting is an in-LDS bitonic network (<= 16384 keys = 128 KiB of the 160 KiB LDS).  NMS runs in the SAME workgroup right behind
+// the sort (one launch per selection): the sorted list is walked in chunks of 64; a chunk's boxes are tested against the boxes kept
+// so far (16 waves share the kept list) and against each other (64x64-bit diagonal block, resolved in the registers of one wave),
+// and the walk stops as soon as the requested number of boxes has been kept -- exactly the greedy NMS of the suppression-matrix
+// form, without the [n, n/64] matrix, its launch and the scan's launch.
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
 #include <algorithm>
@@ -91,49 +93,8 @@ __device__ __forceinline__ int next_pow2(int n) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// NMS on a score-sorted list
+// NMS on a score-sorted list, by the workgroup that sorted it
 // ------------------------------------------------------------------------------------------------------
-// Suppression matrix, stored TRANSPOSED: maskT[bj*(nb*64) + i] bit t: box (bj*64+t) is suppressed by box i (j > i, same
-// label, IoU > thr).  Word bj of 64 consecutive rows is then 512 contiguous bytes, which is what the scan reads.
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ labels,
-                                                       const int* __restrict__ n_ptr, int nb, float thr, u64* __restrict__ mask) {
-  EOD_CHAIN_PRIO();
-  const int n = *n_ptr;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
-  __shared__ float cb[64 * 4];
-  __shared__ int cl[64];
-  const int t = threadIdx.x;
-  const int j = bj * 64 + t;
-  if (j < n) {
-    cb[t * 4 + 0] = boxes[j * 4 + 0];
-    cb[t * 4 + 1] = boxes[j * 4 + 1];
-    cb[t * 4 + 2] = boxes[j * 4 + 2];
-    cb[t * 4 + 3] = boxes[j * 4 + 3];
-    cl[t] = labels ? labels[j] : 0;
-  }
-  __syncthreads();
-  const int i = bi * 64 + t;
-  if (i >= n) return;
-  const float x1 = boxes[i * 4 + 0], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
-  const float area_i = (x2 - x1) * (y2 - y1);
-  const int li = labels ? labels[i] : 0;
-  u64 bits = 0;
-  const int jmax = min(64, n - bj * 64);
-  for (int c = 0; c < jmax; ++c) {
-    const int jj = bj * 64 + c;
-    if (jj <= i || cl[c] != li) continue;
-    const float a1 = cb[c * 4 + 0], b1 = cb[c * 4 + 1], a2 = cb[c * 4 + 2], b2 = cb[c * 4 + 3];
-    const float w = fmaxf(fminf(x2, a2) - fmaxf(x1, a1), 0.f);
-    const float h = fmaxf(fminf(y2, b2) - fmaxf(y1, b1), 0.f);
-    const float inter = w * h;
-    const float area_j = (a2 - a1) * (b2 - b1);
-    const float iou = inter / (area_i + area_j - inter);
-    if (iou > thr) bits |= (1ull << c);
-  }
-  mask[(size_t)bj * (nb * 64) + i] = bits;
-}
-
 struct ScanOut {
   // gathered outputs (any may be null)
   float* out_boxes;
@@ -142,44 +103,115 @@ struct ScanOut {
   int* out_rows;
   int* out_count;
   int cap;
+  // optional: torch.unique of out_rows (ascending, custom_rcnn.py:875) and its length
+  int* uniq_rows;
+  int* uniq_count;
+  int uniq_cap;
+  // optional: groups of kept entries that share one source row (= one class-agnostic box): rep_of[r] = first kept entry with
+  // the row of entry r; rep_list = the entries that are their own representative, ascending; rep_count = their number
+  int* rep_of;
+  int* rep_list;
+  int* rep_count;
 };
 
-// Single workgroup of nb (<=128) threads.  keep_ties: keep every kept box whose score equals the score of
-// kept box #max_keep (centernet.py:733-741, ">= kth"), else truncate at max_keep.
-__global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                        const int* __restrict__ labels, const int* __restrict__ rows,
-                                                        const int* __restrict__ n_ptr, int nb, const u64* __restrict__ mask,
-                                                        int max_keep, int keep_ties, int* __restrict__ keep_idx, ScanOut o) {
-  EOD_CHAIN_PRIO();
-  const int n = *n_ptr;
-  const int tid = threadIdx.x;
-  __shared__ u64 sh_removed;
-  __shared__ u64 sh_kept;
-  __shared__ int sh_total;
-  __shared__ int sh_stop;
-  u64 removed = 0;  // thread w owns word w
+#define NMS_KEPT_MAX 512
+
+struct NmsSmem {
+  float kb[NMS_KEPT_MAX * 4];   // kept boxes, in keep order
+  int kl[NMS_KEPT_MAX];         // their labels
+  int kidx[NMS_KEPT_MAX];       // their position in the sorted list
+  float cb[64 * 4];             // the chunk's boxes
+  int cl[64];
+  u64 diag[64];                 // bit c of word i: chunk box c (c > i) is suppressed by chunk box i
+  u64 supp;                     // bit i: chunk box i is suppressed by a box kept in an earlier chunk
+  int total, stop;
+  float kth;
+  int flag[NMS_KEPT_MAX];       // unique rows
+  int wcnt[8];
+};
+
+__device__ __forceinline__ bool iou_over(float x1, float y1, float x2, float y2, float area_i, float a1, float b1, float a2, float b2,
+                                         float thr) {
+  const float w = fmaxf(fminf(x2, a2) - fmaxf(x1, a1), 0.f);
+  const float h = fmaxf(fminf(y2, b2) - fmaxf(y1, b1), 0.f);
+  const float inter = w * h;
+  const float area_j = (a2 - a1) * (b2 - b1);
+  const float iou = inter / (area_i + area_j - inter);
+  return iou > thr;
+}
+
+// Greedy NMS over the first n entries of a score-sorted list (boxes / scores / labels / rows in global memory, written by this
+// workgroup before the call) + gather of the kept entries.  keep_ties: keep every kept box whose score equals the score of kept
+// box #max_keep (centernet.py:733-741, ">= kth"), else truncate at max_keep.  Block = 1024 threads.
+__device__ void block_greedy_nms(const float* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ labels,
+                                 const int* __restrict__ rows, int n, float thr, int max_keep, int keep_ties, const ScanOut& o,
+                                 NmsSmem* S) {
+  const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
   if (tid == 0) {
-    sh_total = 0;
-    sh_stop = 0;
+    S->total = 0;
+    S->stop = 0;
+    S->kth = -1.0f;
   }
   __syncthreads();
   const int nchunk = (n + 63) >> 6;
-  float kth = -1.0f;
-  // the diagonal block of chunk c+1 does not depend on the scan state: fetch it one chunk ahead
-  u64 diag_next = 0;
-  if (tid < 64 && tid < n) diag_next = mask[(size_t)tid];
   for (int c = 0; c < nchunk; ++c) {
-    if (tid == c) sh_removed = removed;
+    const int lim = min(64, n - c * 64);
+    if (tid < 64) {
+      if (tid < lim) {
+        const int j = c * 64 + tid;
+        S->cb[tid * 4 + 0] = boxes[j * 4 + 0];
+        S->cb[tid * 4 + 1] = boxes[j * 4 + 1];
+        S->cb[tid * 4 + 2] = boxes[j * 4 + 2];
+        S->cb[tid * 4 + 3] = boxes[j * 4 + 3];
+        S->cl[tid] = labels ? labels[j] : 0;
+      }
+      S->diag[tid] = 0;
+      if (tid == 0) S->supp = 0;
+    }
+    __syncthreads();
+    const int total0 = S->total;
+    const int nk = total0 < NMS_KEPT_MAX ? total0 : NMS_KEPT_MAX;
+    const bool valid = lane < lim;
+    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+    int lj = 0;
+    if (valid) {
+      a1 = S->cb[lane * 4 + 0]; b1 = S->cb[lane * 4 + 1]; a2 = S->cb[lane * 4 + 2]; b2 = S->cb[lane * 4 + 3];
+      lj = S->cl[lane];
+    }
+    // (A) against the boxes kept in earlier chunks: wave `grp` takes kept boxes grp, grp + 16, ...
+    bool sup = false;
+    if (valid) {
+      for (int j = grp; j < nk; j += 16) {
+        if (S->kl[j] != lj) continue;
+        const float x1 = S->kb[j * 4 + 0], y1 = S->kb[j * 4 + 1], x2 = S->kb[j * 4 + 2], y2 = S->kb[j * 4 + 3];
+        const float area_i = (x2 - x1) * (y2 - y1);
+        if (iou_over(x1, y1, x2, y2, area_i, a1, b1, a2, b2, thr)) {
+          sup = true;
+          break;
+        }
+      }
+    }
+    const u64 bal = __ballot(sup);
+    if (lane == 0 && bal) atomicOr(&S->supp, bal);
+    // (B) inside the chunk: lane = suppressor i, wave `grp` takes the later boxes grp*4 .. grp*4+3
+    if (valid) {
+      u64 bits = 0;
+      const float area_i = (a2 - a1) * (b2 - b1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c2 = grp * 4 + q;
+        if (c2 > lane && c2 < lim && S->cl[c2] == lj) {
+          if (iou_over(a1, b1, a2, b2, area_i, S->cb[c2 * 4 + 0], S->cb[c2 * 4 + 1], S->cb[c2 * 4 + 2], S->cb[c2 * 4 + 3], thr))
+            bits |= 1ull << c2;
+        }
+      }
+      if (bits) atomicOr(&S->diag[lane], bits);
+    }
     __syncthreads();
     if (tid < 64) {
-      const u64 diag = diag_next;
-      {
-        const int nrow = (c + 1) * 64 + tid;
-        diag_next = (c + 1 < nchunk && nrow < n) ? mask[(size_t)(c + 1) * (nb * 64) + nrow] : 0ull;
-      }
-      u64 cur = sh_removed;
+      const u64 diag = S->diag[tid];
+      u64 cur = S->supp;
       u64 kept = 0;
-      const int lim = min(64, n - c * 64);
       for (int i = 0; i < lim; ++i) {
         const unsigned lo = __shfl((unsigned)(diag & 0xFFFFFFFFull), i, 64);
         const unsigned hi = __shfl((unsigned)(diag >> 32), i, 64);
@@ -188,85 +220,140 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const float* __restrict__
           cur |= ((u64)hi << 32) | lo;
         }
       }
-      const int total0 = sh_total;
-      const int nk = __popcll(kept);
-      if (total0 + nk < max_keep) {
-        // fast path (every chunk but the last one): all lanes append their kept index in parallel
+      const int nkept = __popcll(kept);
+      if (total0 + nkept < max_keep) {
+        // fast path (every chunk but the last one): all lanes append their kept box in parallel
         if ((kept >> tid) & 1ull) {
           const int pos = total0 + __popcll(kept & ((1ull << tid) - 1ull));
-          if (pos < o.cap) keep_idx[pos] = c * 64 + tid;
+          if (pos < NMS_KEPT_MAX) {
+            S->kb[pos * 4 + 0] = a1; S->kb[pos * 4 + 1] = b1; S->kb[pos * 4 + 2] = a2; S->kb[pos * 4 + 3] = b2;
+            S->kl[pos] = lj;
+            S->kidx[pos] = c * 64 + tid;
+          }
         }
-        if (tid == 0) {
-          sh_total = total0 + nk;
-          sh_kept = kept;
-          sh_stop = 0;
-        }
-      } else
-      if (tid == 0) {
-        // append kept indices, honouring max_keep / ties
-        int total = sh_total;
+        if (tid == 0) S->total = total0 + nkept;
+      } else if (tid == 0) {
+        // append kept boxes one by one, honouring max_keep / ties
+        int total = total0;
         int stop = 0;
+        float kth = S->kth;
         for (int i = 0; i < lim; ++i) {
           if (!((kept >> i) & 1ull)) continue;
           const int idx = c * 64 + i;
+          bool take = false;
           if (total < max_keep) {
-            if (total < o.cap) keep_idx[total] = idx;
-            ++total;
-            if (total == max_keep) kth = scores[idx];
+            take = true;
           } else if (keep_ties && scores[idx] >= kth) {
-            if (total < o.cap) keep_idx[total] = idx;
-            ++total;
+            take = true;
           } else {
+            // boxes after this one have lower-or-equal score; with ties they may still be equal only if scores[idx] >= kth,
+            // which failed -> everything later is strictly lower: stop
             stop = 1;
-            // boxes after this one have lower-or-equal score; with ties they may still be equal only if
-            // scores[idx] >= kth, which failed -> everything later is strictly lower: stop.
-            kept &= ((1ull << i) - 1ull);
             break;
           }
+          if (take) {
+            if (total < NMS_KEPT_MAX) {
+              S->kb[total * 4 + 0] = S->cb[i * 4 + 0]; S->kb[total * 4 + 1] = S->cb[i * 4 + 1];
+              S->kb[total * 4 + 2] = S->cb[i * 4 + 2]; S->kb[total * 4 + 3] = S->cb[i * 4 + 3];
+              S->kl[total] = S->cl[i];
+              S->kidx[total] = idx;
+            }
+            ++total;
+            if (total == max_keep) kth = scores[idx];
+          }
         }
-        sh_total = total;
-        sh_kept = kept;
+        S->total = total;
+        S->kth = kth;
         // if the list is full and the next chunk starts below kth, stop
         if (!stop && total >= max_keep) {
           const int nxt = (c + 1) * 64;
           if (!keep_ties || nxt >= n || scores[nxt] < kth) stop = 1;
         }
-        sh_stop = stop;
+        S->stop = stop;
       }
     }
     __syncthreads();
-    if (sh_stop) break;
-    const u64 kept = sh_kept;
-    if (tid > c && tid < nb) {
-      // word `tid` of the chunk's 64 rows: 512 contiguous bytes, loaded unconditionally as 32 independent 16-byte loads
-      // (all in flight together) and masked by the kept bits -- no dependent load chain.
-      const ulonglong2* col = reinterpret_cast<const ulonglong2*>(mask + (size_t)tid * (nb * 64) + c * 64);
-      ulonglong2 v[32];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) v[q] = col[q];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        if ((kept >> (2 * q)) & 1ull) removed |= v[q].x;
-        if ((kept >> (2 * q + 1)) & 1ull) removed |= v[q].y;
-      }
-    }
-    __syncthreads();
+    if (S->stop) break;
   }
   __syncthreads();
-  int total = sh_total;
+  int total = S->total;
   if (total > o.cap) total = o.cap;
+  if (total > NMS_KEPT_MAX) total = NMS_KEPT_MAX;
   if (tid == 0 && o.out_count) *o.out_count = total;
   for (int r = tid; r < total; r += blockDim.x) {
-    const int idx = keep_idx[r];
+    const int idx = S->kidx[r];
     if (o.out_boxes) {
-      o.out_boxes[r * 4 + 0] = boxes[idx * 4 + 0];
-      o.out_boxes[r * 4 + 1] = boxes[idx * 4 + 1];
-      o.out_boxes[r * 4 + 2] = boxes[idx * 4 + 2];
-      o.out_boxes[r * 4 + 3] = boxes[idx * 4 + 3];
+      o.out_boxes[r * 4 + 0] = S->kb[r * 4 + 0];
+      o.out_boxes[r * 4 + 1] = S->kb[r * 4 + 1];
+      o.out_boxes[r * 4 + 2] = S->kb[r * 4 + 2];
+      o.out_boxes[r * 4 + 3] = S->kb[r * 4 + 3];
     }
     if (o.out_scores) o.out_scores[r] = scores[idx];
-    if (o.out_labels) o.out_labels[r] = labels ? labels[idx] : 0;
+    if (o.out_labels) o.out_labels[r] = S->kl[r];
     if (o.out_rows) o.out_rows[r] = rows ? rows[idx] : idx;
+  }
+  if (o.rep_of && rows) {
+    // entries of one source row carry the same box: the first of them represents the group (the mask head is class agnostic)
+    if (tid < NMS_KEPT_MAX) S->flag[tid] = 0x7FFFFFFF;
+    __syncthreads();
+    int my_row = -1;
+    if (tid < total) {
+      my_row = rows[S->kidx[tid]];
+      if (my_row >= 0 && my_row < NMS_KEPT_MAX) atomicMin(&S->flag[my_row], tid);
+    }
+    __syncthreads();
+    int is_rep = 0;
+    if (tid < total) {
+      const int rep = (my_row >= 0 && my_row < NMS_KEPT_MAX) ? S->flag[my_row] : tid;
+      o.rep_of[tid] = rep;
+      is_rep = rep == tid;
+    }
+    u64 rb = 0;
+    if (tid < NMS_KEPT_MAX) {
+      rb = __ballot(is_rep != 0);
+      if (lane == 0) S->wcnt[grp] = __popcll(rb);
+    }
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_KEPT_MAX / 64; ++w) {
+      const int cw = S->wcnt[w];
+      if (w < grp) before += cw;
+      all += cw;
+    }
+    if (tid < NMS_KEPT_MAX && is_rep) o.rep_list[before + __popcll(rb & ((1ull << lane) - 1ull))] = tid;
+    if (tid == 0) *o.rep_count = all;
+    __syncthreads();
+  }
+  if (o.uniq_rows) {
+    // torch.unique of the kept rows: flags over the row ids (< NMS_KEPT_MAX), ballot compaction, ascending
+    if (tid < NMS_KEPT_MAX) S->flag[tid] = 0;
+    __syncthreads();
+    for (int r = tid; r < total; r += blockDim.x) {
+      const int row = rows ? rows[S->kidx[r]] : S->kidx[r];
+      if (row >= 0 && row < NMS_KEPT_MAX) S->flag[row] = 1;
+    }
+    __syncthreads();
+    int f = 0;
+    u64 fb = 0;
+    if (tid < NMS_KEPT_MAX) {
+      f = S->flag[tid];
+      fb = __ballot(f != 0);
+      if (lane == 0) S->wcnt[grp] = __popcll(fb);
+    }
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_KEPT_MAX / 64; ++w) {
+      const int cw = S->wcnt[w];
+      if (w < grp) before += cw;
+      all += cw;
+    }
+    if (tid < NMS_KEPT_MAX && f) {
+      const int pos = before + __popcll(fb & ((1ull << lane) - 1ull));
+      if (pos < o.uniq_cap) o.uniq_rows[pos] = tid;
+    }
+    if (tid == 0 && o.uniq_count) *o.uniq_count = all < o.uniq_cap ? all : o.uniq_cap;
   }
 }
 
@@ -338,11 +425,13 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
 }
 
 // single block: merge the per-level lists, sort by sqrt-score, decode boxes (E*1024 >= packed slots: E = 4 covers the usual
-// 1000 + 1000 + <=1000 + ... <= 4096 candidates with half the sort of E = 8)
+// 1000 + 1000 + <=1000 + ... <= 4096 candidates with half the sort of E = 8), then class-agnostic NMS + post-NMS cut with ties
 template <int E>
-__global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_sorted) {
+__global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, float nms_thresh,
+                                                             int post_topk, ScanOut o) {
   EOD_CHAIN_PRIO();
   __shared__ u64 xch[1024 * E];
+  static_assert(sizeof(NmsSmem) <= sizeof(u64) * 1024 * E, "the NMS state reuses the sort's exchange buffer");
   const int total_slots = p.pk_off[p.levels];
   u64 v[E];
 #pragma unroll
@@ -353,7 +442,6 @@ __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* 
   block_sort_desc_reg<E>(v, xch);
   int n = 0;
   for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
-  if (threadIdx.x == 0) *n_sorted = n;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int r = threadIdx.x * E + e;
@@ -385,15 +473,18 @@ __global__ __launch_bounds__(1024) void cn_merge_decode_kernel(CnArgs p, float* 
     sorted_boxes[r * 4 + 3] = y2;
     sorted_scores[r] = key_score(k);
   }
+  __syncthreads();          // the sorted list (global) and the end of the sort's use of xch
+  block_greedy_nms(sorted_boxes, sorted_scores, nullptr, nullptr, n, nms_thresh, post_topk, 1, o, reinterpret_cast<NmsSmem*>(xch));
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fast_rcnn_inference candidates: threshold + sort
+// fast_rcnn_inference in one launch: threshold + sort + per-class NMS + top-k (+ unique rows)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                               const int* __restrict__ count, int R_cap, int C1, float img_w,
-                                                               float img_h, float thr, float* sorted_boxes, float* sorted_scores,
-                                                               int* sorted_labels, int* sorted_rows, int* n_sorted) {
+__global__ __launch_bounds__(1024) void det_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                           const int* __restrict__ count, int R_cap, int C1, float img_w,
+                                                           float img_h, float thr, float* sorted_boxes, float* sorted_scores,
+                                                           int* sorted_labels, int* sorted_rows, float nms_thresh, int topk,
+                                                           ScanOut o) {
   EOD_CHAIN_PRIO();
   constexpr int E = 8;
   __shared__ u64 xch[1024 * E];
@@ -439,7 +530,6 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
   block_sort_desc_reg<E>(v, xch);
   __syncthreads();
   const int n = sh_cnt;
-  if (threadIdx.x == 0) *n_sorted = n;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int q = threadIdx.x * E + e;
@@ -455,6 +545,9 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(const float* __res
     sorted_labels[q] = c;
     sorted_rows[q] = r;
   }
+  __syncthreads();          // the sorted list (global) and the end of the sort's use of xch
+  static_assert(sizeof(NmsSmem) <= sizeof(xch), "the NMS state reuses the sort's exchange buffer");
+  block_greedy_nms(sorted_boxes, sorted_scores, sorted_labels, sorted_rows, n, nms_thresh, topk, 0, o, reinterpret_cast<NmsSmem*>(xch));
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -464,9 +557,6 @@ struct SelWs {
   float* sorted_scores;
   int* sorted_labels;
   int* sorted_rows;
-  int* n_sorted;
-  int* keep_idx;
-  u64* mask;
   u64* cand_keys;
   int* cand_cnt;
   size_t bytes;
@@ -476,7 +566,7 @@ SelWs carve(void* base, int cap_sort, int keep_cap, int cand_slots) {
   SelWs w{};
   size_t off = 0;
   char* b = static_cast<char*>(base);
-  const int nb = (cap_sort + 63) / 64;
+  (void)keep_cap;
   auto take = [&](size_t bytes) {
     char* p = b ? b + off : nullptr;
     off += align_up(bytes);
@@ -486,9 +576,6 @@ SelWs carve(void* base, int cap_sort, int keep_cap, int cand_slots) {
   w.sorted_scores = reinterpret_cast<float*>(take((size_t)cap_sort * sizeof(float)));
   w.sorted_labels = reinterpret_cast<int*>(take((size_t)cap_sort * sizeof(int)));
   w.sorted_rows = reinterpret_cast<int*>(take((size_t)cap_sort * sizeof(int)));
-  w.n_sorted = reinterpret_cast<int*>(take(sizeof(int)));
-  w.keep_idx = reinterpret_cast<int*>(take((size_t)keep_cap * sizeof(int)));
-  w.mask = reinterpret_cast<u64*>(take((size_t)cap_sort * nb * sizeof(u64)));
   w.cand_keys = reinterpret_cast<u64*>(take((size_t)(cand_slots > 0 ? cand_slots : 1) * sizeof(u64)));
   w.cand_cnt = reinterpret_cast<int*>(take(8 * sizeof(int)));
   w.bytes = off;
@@ -512,7 +599,7 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
     const int n = d->level_off[l + 1] - d->level_off[l];
     if (n <= 0 || n > EOD_SORT_MAX || d->level_w[l] <= 0 || n % d->level_w[l] != 0) return EOD_ERR_CAPACITY;
   }
-  if (d->cap < d->post_nms_topk) return EOD_ERR_CAPACITY;
+  if (d->cap < d->post_nms_topk || d->cap > NMS_KEPT_MAX) return EOD_ERR_CAPACITY;
   const SelWs w = carve(d->workspace, slots, slots, slots);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
@@ -534,16 +621,13 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
     hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels), dim3(1024), 0, s, a);
   else
     hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels), dim3(1024), 0, s, a);
+  ScanOut o{d->out_boxes, d->out_scores, nullptr, nullptr, d->out_count, d->cap, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
   if (a.pk_off[d->levels] <= 4096)
-    hipLaunchKernelGGL(cn_merge_decode_kernel<4>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
+    hipLaunchKernelGGL(cn_merge_nms_kernel<4>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
+                       d->post_nms_topk, o);
   else
-    hipLaunchKernelGGL(cn_merge_decode_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, w.n_sorted);
-  const int nb = (slots + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, s, w.sorted_boxes, (const int*)nullptr, w.n_sorted, nb, d->nms_thresh,
-                     w.mask);
-  ScanOut o{d->out_boxes, d->out_scores, nullptr, nullptr, d->out_count, d->cap};
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(128), 0, s, w.sorted_boxes, w.sorted_scores, (const int*)nullptr,
-                     (const int*)nullptr, w.n_sorted, nb, w.mask, d->post_nms_topk, 1, w.keep_idx, o);
+    hipLaunchKernelGGL(cn_merge_nms_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
+                       d->post_nms_topk, o);
   return eod_launch_status();
 }
 
@@ -556,19 +640,17 @@ extern "C" int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream)
   if (!d || !d->boxes || !d->scores || !d->out_boxes || !d->out_scores || !d->out_classes || !d->out_rows || !d->out_count ||
       !d->workspace)
     return EOD_ERR_NULL;
-  if (d->R_cap <= 0 || d->R_cap > 1024 || d->C1 < 2 || d->topk <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->R_cap <= 0 || d->R_cap > 1024 || d->C1 < 2 || d->topk <= 0 || d->topk > NMS_KEPT_MAX) return EOD_ERR_BAD_DIMS;
   const int slots = d->R_cap * (d->C1 - 1);
   if (slots > 8192) return EOD_ERR_CAPACITY;
   const SelWs w = carve(d->workspace, slots, slots, 0);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(det_candidates_kernel, dim3(1), dim3(1024), 0, s, d->boxes, d->scores, d->count, d->R_cap, d->C1, d->img_w, d->img_h,
-                     d->score_thresh, w.sorted_boxes, w.sorted_scores, w.sorted_labels, w.sorted_rows, w.n_sorted);
-  const int nb = (slots + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, s, w.sorted_boxes, (const int*)w.sorted_labels, w.n_sorted, nb,
-                     d->nms_thresh, w.mask);
-  ScanOut o{d->out_boxes, d->out_scores, d->out_classes, d->out_rows, d->out_count, d->topk};
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(128), 0, s, w.sorted_boxes, w.sorted_scores, (const int*)w.sorted_labels,
-                     (const int*)w.sorted_rows, w.n_sorted, nb, w.mask, d->topk, 0, w.keep_idx, o);
+  if (d->out_unique_rows && (!d->out_unique_count || d->unique_cap <= 0 || d->R_cap > NMS_KEPT_MAX)) return EOD_ERR_BAD_DIMS;
+  if (d->out_rep_of && (!d->out_rep_list || !d->out_rep_count || d->R_cap > NMS_KEPT_MAX)) return EOD_ERR_BAD_DIMS;
+  ScanOut o{d->out_boxes, d->out_scores, d->out_classes, d->out_rows, d->out_count, d->topk, d->out_unique_rows, d->out_unique_count,
+            d->unique_cap, d->out_rep_of, d->out_rep_list, d->out_rep_count};
+  hipLaunchKernelGGL(det_select_kernel, dim3(1), dim3(1024), 0, s, d->boxes, d->scores, d->count, d->R_cap, d->C1, d->img_w, d->img_h,
+                     d->score_thresh, w.sorted_boxes, w.sorted_scores, w.sorted_labels, w.sorted_rows, d->nms_thresh, d->topk, o);
   return eod_launch_status();
 }

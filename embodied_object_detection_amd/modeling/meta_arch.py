@@ -84,6 +84,13 @@ class CustomRCNNRecurrent:
         # bitwise identical (tests/test_model_gpu.py::test_lazy_proposal_masks_give_identical_results).  `False` restores the
         # reference-faithful 256-proposal pass (bench.py reports it beside the headline).
         self.lazy_proposal_masks = True
+        # Detections that come from one proposal carry the SAME class-agnostic box (fast_rcnn_inference keeps up to 20 classes of a
+        # proposal as separate detections, detic_roi_heads.py:214-221) and the mask head is class agnostic (CLS_AGNOSTIC_MASK): their
+        # masks are identical.  Default: the mask head runs once per distinct box (~100 of 300 detections on the benchmark scene)
+        # and every detection of the group reads that mask; outputs are bitwise those of the 300-ROI pass
+        # (tests/test_model_gpu.py::test_detection_mask_groups_give_identical_results).  `False` restores the reference-faithful
+        # one-ROI-per-detection pass (bench.py reports it beside the headline).
+        self.dedup_detection_masks = True
         # The proposal mask pass (custom_rcnn.py:573) needs only the proposals and the FPN features, not the box cascade: the
         # cascade's small latency-bound launches (15 FC GEMMs, 3 ROIAligns, the selection sorts) are enqueued on a second,
         # high-priority HIP stream and run beside the proposal pass's large GEMMs.  The detection mask pass follows on the main
@@ -157,9 +164,10 @@ class CustomRCNNRecurrent:
         self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, state_dict, self.device, self.proposal_generator.cap)
         R = self.proposal_generator.cap
         self.mem_scores = torch.zeros((R, self.C1), dtype=torch.float32, device=self.device)
-        self.mem_selector = ops.DetectionSelector(R, self.C1, 100, self.device)
-        self._uniq_rows = torch.zeros((R,), dtype=torch.int32, device=self.device)
-        self._uniq_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        # inference_with_proposals' selection (custom_rcnn.py:862-875) in one launch: threshold, per-class NMS, top 100, unique rows
+        self.mem_selector = ops.DetectionSelector(R, self.C1, 100, self.device, unique=True)
+        self._uniq_rows, self._uniq_count = self.mem_selector.uniq_rows, self.mem_selector.uniq_count
+        self._mem_scores_frame = -1      # frame whose CLIP re-score `mem_scores` holds (written by stage 0 of the cascade)
         # recurrent state
         self.implicit_memory: Optional[torch.Tensor] = None   # [N,512] f32  (== semmap_features)
         self.observations: Optional[torch.Tensor] = None      # [N] f32      (== observation_count)
@@ -239,12 +247,11 @@ class CustomRCNNRecurrent:
             # (`forward`), so the host's read-back of the detection count never leaves the GPU idle
             D = self.roi_heads.topk
             dev = self.device
+            # boxes / scores / classes / masks of a set are allocated anew for every frame (`_postprocess_and_paste`) and handed to the
+            # caller as they are: no copy of the 0/1 byte masks ([300,H,W]: 123 MB at 640x640) when the Instances are built
             self._posts = [dict(
-                hw=(H, W),
-                boxes=torch.zeros((D, 4), dtype=torch.float32, device=dev), scores=torch.zeros((D,), dtype=torch.float32, device=dev),
-                classes=torch.zeros((D,), dtype=torch.int32, device=dev), src=torch.zeros((D,), dtype=torch.int32, device=dev),
-                count=torch.zeros((1,), dtype=torch.int32, device=dev),
-                masks=torch.zeros((D, H, W), dtype=torch.uint8, device=dev),
+                hw=(H, W), boxes=None, scores=None, classes=None, masks=None,
+                src=torch.zeros((D,), dtype=torch.int32, device=dev), count=torch.zeros((1,), dtype=torch.int32, device=dev),
                 count_host=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
                 ready=torch.cuda.Event(), err_ready=torch.cuda.Event()) for _ in range(RESULT_SETS)]
             self._post_slot = 0
@@ -459,7 +466,7 @@ class CustomRCNNRecurrent:
             # the side stream's ~45 small ones -- they all execute beside the two mask passes.
             if not lazy:
                 prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count,
-                                                                bufs=self.roi_heads.proposal_pass_buffers())
+                                                                bufs=self.roi_heads.proposal_pass_buffers(), tag=("prop_all", self._frame_no))
                 self._ev_pm.record(main)
             self._side_stream.wait_event(self._ev_props)
             with torch.cuda.stream(self._side_stream):
@@ -467,7 +474,10 @@ class CustomRCNNRecurrent:
                 if self._ev_det[k] is not None:
                     self._side_stream.wait_event(self._ev_det[k])     # the detection list set k is still read by frame t-2's pass
                 det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k,
-                                                 stage0_event=self._ev_s0 if lazy else None)
+                                                 stage0_event=self._ev_s0 if lazy else None,
+                                                 mem_rescore=(self.zs_weight, self.mem_scores) if update_mem else None)
+                if update_mem:
+                    self._mem_scores_frame = self._frame_no
                 det_boxes, det_scores, det_classes, det_rows, det_count = det
                 self._ev_box.record(self._side_stream)
                 self._mark("cascade+det_select", self._side_stream)
@@ -475,7 +485,6 @@ class CustomRCNNRecurrent:
             if lazy and not self.early_memory_selection:
                 with torch.cuda.stream(self._side_stream):
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-                    ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
                     self._ev_sel.record(self._side_stream)
                     self._mark("mem_select", self._side_stream)
             elif lazy:
@@ -486,7 +495,6 @@ class CustomRCNNRecurrent:
                 mem_stream.wait_event(self._ev_s0)
                 with torch.cuda.stream(mem_stream):
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-                    ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
                     self._ev_sel.record(mem_stream)
                     self._mark("mem_select", mem_stream)
             pipelined = self.pipeline_detection_pass
@@ -497,12 +505,12 @@ class CustomRCNNRecurrent:
                 pass        # enqueued below, behind the proposal masks / the memory write
             else:
                 main.wait_event(self._ev_box)
-                self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+                self._detection_masks(views, shapes, det_boxes, det_count)
             if lazy:
                 main.wait_event(self._ev_sel)
                 prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
                                                                 rows_count=self._uniq_count,
-                                                                bufs=self.roi_heads.proposal_pass_buffers())
+                                                                bufs=self.roi_heads.proposal_pass_buffers(), tag=("prop", self._frame_no))
                 self._ev_pm.record(main)
                 self._mark("prop_masks", main)
             if pipelined and det_after == "proposal_masks":
@@ -522,22 +530,24 @@ class CustomRCNNRecurrent:
                     self._enqueue_detection_pass(views, shapes, det, (H, W), frame, after=self._ev_mem)
         else:
             pipelined = False
-            det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W))
+            det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W),
+                                             mem_rescore=(self.zs_weight, self.mem_scores) if update_mem else None)
+            if update_mem:
+                self._mem_scores_frame = self._frame_no
             det_boxes, det_scores, det_classes, det_rows, det_count = det
             if self.front_event is not None:
                 # the latency-bound front of the frame (memory fusion, tower, proposal decoding, cascade) ends here; what follows is
                 # dense (mask passes): BatchedSequences staggers its scenes on this point
                 self.front_event.record(torch.cuda.current_stream(self.device))
-            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            self._detection_masks(views, shapes, det_boxes, det_count)
             if self.lazy_proposal_masks and update_mem:
                 # select the memory instances first, then run the mask head only on those proposals (same results: the other
                 # proposals' masks are never read, custom_rcnn.py:875-880)
                 mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
-                ops.unique_rows(mem_sel[0], mem_sel[1], 100, self.proposal_generator.cap, self._uniq_rows, self._uniq_count)
                 prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, rows=self._uniq_rows,
-                                                                rows_count=self._uniq_count)
+                                                                rows_count=self._uniq_count, tag=("prop", self._frame_no))
             else:
-                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count)
+                prop_masks = self.roi_heads.forward_mask_memory(views, shapes, prop_boxes, prop_count, tag=("prop_all", self._frame_no))
 
         # detector_postprocess (custom_rcnn.py:579-580)
         P = self._post
@@ -549,7 +559,8 @@ class CustomRCNNRecurrent:
             torch.cuda.current_stream(self.device).wait_event(self._ev_mem)
         elif update_mem:
             self.update_implicit_memory(prop_boxes, prop_scores, prop_count, prop_masks, proj, (H, W), mem_sel)
-        self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out}
+        self.last_stats = {"prop_count": prop_count, "det_count": P["count"], "mem_k": self._writer.k_out,
+                           "det_mask_rois": self.roi_heads.last_selector.rep_count if self.dedup_detection_masks else P["count"]}
         if pipelined and not trailing_detection_pass:
             torch.cuda.current_stream(self.device).wait_event(self._ev_det[self._post_slot])     # in-order callers see a finished frame
         if self.stats_log is not None:      # bench.py: device-side copies of the frame's counters, read after the timed region
@@ -558,7 +569,8 @@ class CustomRCNNRecurrent:
                     cnt = P["count"].clone()
             else:
                 cnt = P["count"].clone()
-            self.stats_log.append((prop_count.clone(), cnt, self._writer.k_out.clone(), self._uniq_count.clone()))
+            self.stats_log.append((prop_count.clone(), cnt, self._writer.k_out.clone(), self._uniq_count.clone(),
+                                   self.last_stats["det_mask_rois"].clone()))
         if not materialize:
             return None
         return {"instances": self._materialize(self._post_ticket())}
@@ -572,13 +584,31 @@ class CustomRCNNRecurrent:
         ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
         self.trace.append((self._frame_no, name, ev))
 
+    def _detection_masks(self, views, shapes, det_boxes, det_count):
+        """`forward_with_given_boxes` (detic_roi_heads.py:257): the mask head on the detections -- once per distinct box when
+        `dedup_detection_masks` (the groups come from the detection selection's launch)."""
+        rh = self.roi_heads
+        sel = rh.last_selector
+        if self.dedup_detection_masks:
+            return rh.forward_mask(views, shapes, det_boxes, sel.rep_count, rh.topk, rh.det_masks, rows=sel.rep_list,
+                                   lds_reserve=rh.det_pass_lds_reserve, tag=("det", self._frame_no))
+        return rh.forward_mask(views, shapes, det_boxes, det_count, rh.topk, rh.det_masks, lds_reserve=rh.det_pass_lds_reserve,
+                               tag=("det", self._frame_no))
+
     def _postprocess_and_paste(self, det_boxes, det_scores, det_classes, det_count, image_hw, frame, P):
         H, W = image_hw
         out_h, out_w = int(frame.get("height", H)), int(frame.get("width", W))
         if (out_h, out_w) != (H, W):
             raise NotImplementedError("output size != input size is not used on this path (train_mp3d.py:487-490)")
+        D, dev = self.roi_heads.topk, self.device
+        # this frame's own result tensors, from the caching allocator on the stream that fills them; `_materialize` slices them
+        P["boxes"] = torch.empty((D, 4), dtype=torch.float32, device=dev)
+        P["scores"] = torch.empty((D,), dtype=torch.float32, device=dev)
+        P["classes"] = torch.empty((D,), dtype=torch.int32, device=dev)
+        P["masks"] = torch.empty((D, H, W), dtype=torch.uint8, device=dev)
         ops.detector_postprocess(det_boxes, det_scores, det_classes, det_count, self.roi_heads.topk, out_w / W, out_h / H,
-                                 float(out_w), float(out_h), P["boxes"], P["scores"], P["classes"], P["src"], P["count"])
+                                 float(out_w), float(out_h), P["boxes"], P["scores"], P["classes"], P["src"], P["count"],
+                                 remap=self.roi_heads.last_selector.rep_of if self.dedup_detection_masks else None)
         ops.paste_masks(self.roi_heads.det_masks, P["boxes"], P["src"], P["count"], self.roi_heads.topk, out_h, out_w,
                         self.mask_threshold, P["masks"])
 
@@ -597,7 +627,7 @@ class CustomRCNNRecurrent:
             ds.wait_event(after)
         with torch.cuda.stream(ds):
             self._mark("det_pass_begin", ds)
-            self.roi_heads.forward_mask(views, shapes, det_boxes, det_count, self.roi_heads.topk, self.roi_heads.det_masks)
+            self._detection_masks(views, shapes, det_boxes, det_count)
             self._postprocess_and_paste(det_boxes, det_scores, det_classes, det_count, image_hw, frame, self._post)
             self._ev_det[k].record(ds)
             self._mark("det_pass", ds)
@@ -608,7 +638,8 @@ class CustomRCNNRecurrent:
         MEMORY_CLS_SCORE_THRESH, per-class NMS 0.5, top 100 -> (proposal row of every kept detection, count)."""
         H, W = image_hw
         R = self.proposal_generator.cap
-        ops.memory_scores(self.roi_heads.featn0, self.zs_weight, prop_scores, self.mem_scores, prop_count, R, self.C1)
+        if self._mem_scores_frame != self._frame_no:        # not written by this frame's cascade (forward_box without mem_rescore)
+            ops.memory_scores(self.roi_heads.featn0, self.zs_weight, prop_scores, self.mem_scores, prop_count, R, self.C1)
         _, _, _, rows, cnt = self.mem_selector(prop_boxes, self.mem_scores, prop_count, float(W), float(H), self.cls_score_thresh, 0.5)
         return rows, cnt
 
@@ -645,10 +676,14 @@ class CustomRCNNRecurrent:
                 "(an index image written for another map size?); they were clamped, the frame's results are not trustworthy")
         n = int(P["count_host"][0])
         inst = Instances(P["hw"])
-        inst.pred_boxes = Boxes(P["boxes"][:n].clone())
-        inst.scores = P["scores"][:n].clone()
+        cur = torch.cuda.current_stream(self.device)
+        for k in ("boxes", "scores", "classes", "masks"):
+            P[k].record_stream(cur)           # allocated on the stream that filled them; the caller reads them on this one
+        inst.pred_boxes = Boxes(P["boxes"][:n])
+        inst.scores = P["scores"][:n]
         inst.pred_classes = P["classes"][:n].to(torch.int64)
-        inst.pred_masks = P["masks"][:n].view(torch.bool).clone()
+        inst.pred_masks = P["masks"][:n].view(torch.bool)       # the paste kernel writes 0/1 bytes: a view, no copy
+        P["boxes"] = P["scores"] = P["classes"] = P["masks"] = None
         return inst
 
     def semantic_map(self) -> torch.Tensor:

@@ -90,14 +90,19 @@ class DeticCascadeROIHeads:
         self.fuse_mask_tail = True
         # three detection-list sets: the detection mask pass of frame t may still read set t % 3 while the cascades of the next
         # frames write the others (meta_arch.py, pipeline_detection_pass / RESULT_SETS)
-        self.selectors = [ops.DetectionSelector(R, self.C1, self.topk, device) for _ in range(3)]
+        # LDS reserve of the DETECTION mask pass's launches (the pass that trails under the frame's / the next frame's latency-bound
+        # chains): see EodConvDesc.lds_reserve.  0 = the kernel's natural occupancy.
+        self.det_pass_lds_reserve = int(__import__("os").environ.get("EOD_DET_LDS_RESERVE", "0"))
+        self.prop_pass_lds_reserve = int(__import__("os").environ.get("EOD_PROP_LDS_RESERVE", "0"))
+        self.selectors = [ops.DetectionSelector(R, self.C1, self.topk, device, groups=True) for _ in range(3)]
         self.selector = self.selectors[0]
 
     # ---- cascade box heads ------------------------------------------------------------------------
     def forward_box(self, views: List[torch.Tensor], shapes, prop_boxes: torch.Tensor, prop_scores: torch.Tensor, count: torch.Tensor,
-                    image_hw: Tuple[int, int], sel: int = 0, stage0_event=None):
+                    image_hw: Tuple[int, int], sel: int = 0, stage0_event=None, mem_rescore=None):
         """`stage0_event` (optional torch.cuda.Event): recorded once stage 0 has produced `feat0` / `featn0` -- all that the memory
-        selection (custom_rcnn.py:825-875) needs from the cascade."""
+        selection (custom_rcnn.py:825-875) needs from the cascade.  `mem_rescore = (zs_weight of the meta-architecture, out [R, C1])`:
+        stage 0's classifier launch also writes the memory update's CLIP re-score of the proposals (custom_rcnn.py:838-861)."""
         h3, w3 = shapes[0]
         H, W = image_hw
         R = self.R
@@ -108,29 +113,37 @@ class DeticCascadeROIHeads:
             st["fc2"](self.h1, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h2)
             feat = self.feat0 if k == 0 else self.feat
             st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
-            ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp)
+            last = k == self.num_stages - 1
+            # the last stage's launch also fuses the cascade's scores: sqrt(mean_k(prob) * proposal score) (detic_roi_heads.py:164-173)
+            ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp,
+                            zs_mem=mem_rescore[0] if (k == 0 and mem_rescore is not None) else None,
+                            prop_scores=prop_scores if (last or (k == 0 and mem_rescore is not None)) else None,
+                            mem_scores_out=mem_rescore[1] if (k == 0 and mem_rescore is not None) else None,
+                            final_inv_stages=1.0 / self.num_stages if last else 0.0)
             if k == 0 and stage0_event is not None:
                 stage0_event.record(torch.cuda.current_stream(self.device))
             st["bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.hb)
             st["bb2"](self.hb, R, 1, 1, m_count=count, m_unit=1, out=self.deltas)
-            last = k == self.num_stages - 1
             # next-stage proposals are clipped to the image (detic_roi_heads.py:314); the final boxes are clipped by
             # fast_rcnn_inference itself
             ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
             boxes = self.boxes[k + 1]
-        ops.cascade_scores(self.prob, prop_scores, count, R, self.C1, 1.0 / self.num_stages)
+        self.last_selector = self.selectors[sel]
         return self.selectors[sel](boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
 
     # ---- mask head ----------------------------------------------------------------------------------
     def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor,
-                     rows: torch.Tensor = None, bufs=None):
+                     rows: torch.Tensor = None, bufs=None, lds_reserve: int = 0, tag=None):
         """Mask head on `count` ROIs.  With `rows` (a compact ascending list of box indices) ROI k pools `boxes[rows[k]]` and its
         28x28 mask is written to `out[rows[k]]`: only the listed boxes are computed, the output layout stays per-box."""
         h3, w3 = shapes[0]
         mpool, mbuf, mup = bufs if bufs is not None else (self.mpool, self.mbuf, self.mup)
         ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, cap, 14, out=mpool, box_rows=rows)
         src, dst = mpool, mbuf
+        self.deconv.lds_reserve = lds_reserve
         for conv in self.mask_convs:
+            conv.lds_reserve = lds_reserve          # occupancy cap of the dense launches (EodConvDesc.lds_reserve)
+            conv.event_tag = tag
             conv(src, cap, 14, 14, relu=True, m_count=count, m_unit=196, out=dst)
             src, dst = dst, src
         if self.fuse_mask_tail:
@@ -157,11 +170,13 @@ class DeticCascadeROIHeads:
         return self._prop_bufs
 
     def forward_mask_memory(self, views, shapes, prop_boxes, prop_count, rows: torch.Tensor = None, rows_count: torch.Tensor = None,
-                            bufs=None):
+                            bufs=None, tag=None):
         """`forward_mask_memory` + `mask_rcnn_inference` on ALL proposals (custom_rcnn.py:573-574).
 
         `rows` / `rows_count`: lazy variant -- only the proposals the memory update will read (custom_rcnn.py:875-880) get a
         mask; every other proposal's mask is dead in the reference (never read after `inference_with_proposals`)."""
         if rows is not None:
-            return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows, bufs=bufs)
-        return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks, bufs=bufs)
+            return self.forward_mask(views, shapes, prop_boxes, rows_count, min(self.R, 128), self.prop_masks, rows=rows, bufs=bufs,
+                                     lds_reserve=self.prop_pass_lds_reserve, tag=tag)
+        return self.forward_mask(views, shapes, prop_boxes, prop_count, self.R, self.prop_masks, bufs=bufs,
+                                 lds_reserve=self.prop_pass_lds_reserve, tag=tag)

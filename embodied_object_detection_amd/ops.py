@@ -126,7 +126,9 @@ class Conv:
         self.desc = EodConvDesc()
         self._lib = _lib.load()
         self.w_split = None     # bf16x3 pieces of the weights, made on first use in that arithmetic mode
-        self.event_log = None   # bench.py: list that receives (start_event, end_event, m_count) per launch
+        self.event_log = None   # bench.py: list that receives (start_event, end_event, event_tag) per launch
+        self.event_tag = None   # what the caller wants to know the launch by (no device work: a clone of m_count would be a launch)
+        self.lds_reserve = 0    # EodConvDesc.lds_reserve: caps this layer's workgroups per CU (see include/eod_hip.h)
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -165,6 +167,7 @@ class Conv:
             d.fuse_w, d.fuse_b, d.out_units = None, 0.0, None
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
         d.plan_rows = plan_rows
+        d.lds_reserve = self.lds_reserve
         if levels is not None:
             off, shapes = levels
             d.levels = len(shapes)
@@ -191,7 +194,7 @@ class Conv:
             e0.record()
             check(self._lib.eod_conv2d(C.byref(d), _stream()), f"eod_conv2d[{self.name}]")
             e1.record()
-            self.event_log.append((e0, e1, None if m_count is None else m_count.clone()))
+            self.event_log.append((e0, e1, self.event_tag))
             return out
         check(self._lib.eod_conv2d(C.byref(d), _stream()), f"eod_conv2d[{self.name}]")
         return out
@@ -299,9 +302,12 @@ class ProposalDecoder:
 
 
 class DetectionSelector:
-    """detectron2 fast_rcnn_inference (single image) on device."""
+    """detectron2 fast_rcnn_inference (single image) on device: ONE launch.  `unique=True`: the launch also writes torch.unique of
+    the kept proposal rows (`uniq_rows`, `uniq_count`; custom_rcnn.py:875).  `groups=True`: it also groups the detections by
+    proposal row -- detections of one row carry the same class-agnostic box: `rep_of[k]` = the first detection of k's group,
+    `rep_list` / `rep_count` = the group representatives."""
 
-    def __init__(self, R_cap: int, C1: int, topk: int, device):
+    def __init__(self, R_cap: int, C1: int, topk: int, device, unique: bool = False, groups: bool = False):
         self.lib = _lib.load()
         self.R_cap, self.C1, self.topk = R_cap, C1, topk
         nbytes = self.lib.eod_detections_workspace_bytes(R_cap, C1)
@@ -316,6 +322,17 @@ class DetectionSelector:
         d.out_boxes, d.out_scores, d.out_classes = self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr()
         d.out_rows, d.out_count = self.rows.data_ptr(), self.count.data_ptr()
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.uniq_rows = self.uniq_count = None
+        if unique:
+            self.uniq_rows = torch.zeros((R_cap,), dtype=torch.int32, device=device)
+            self.uniq_count = torch.zeros((1,), dtype=torch.int32, device=device)
+            d.out_unique_rows, d.out_unique_count, d.unique_cap = self.uniq_rows.data_ptr(), self.uniq_count.data_ptr(), R_cap
+        self.rep_of = self.rep_list = self.rep_count = None
+        if groups:
+            self.rep_of = torch.zeros((topk,), dtype=torch.int32, device=device)
+            self.rep_list = torch.zeros((topk,), dtype=torch.int32, device=device)
+            self.rep_count = torch.zeros((1,), dtype=torch.int32, device=device)
+            d.out_rep_of, d.out_rep_list, d.out_rep_count = self.rep_of.data_ptr(), self.rep_list.data_ptr(), self.rep_count.data_ptr()
         self.desc = d
 
     def __call__(self, boxes: torch.Tensor, scores: torch.Tensor, count: Optional[torch.Tensor], img_w: float, img_h: float,
@@ -327,9 +344,17 @@ class DetectionSelector:
         return self.boxes, self.scores, self.classes, self.rows, self.count
 
 
-def zs_classify(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: int, C1: int, temp: float = 50.0):
-    check(_lib.load().eod_zs_classify(feat.data_ptr(), zs.data_ptr(), prob_acc.data_ptr(), int(accumulate), _ptr(featn_out), _ptr(count),
-                                      R_cap, 512, C1, temp, _stream()), "eod_zs_classify")
+def zs_classify(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: int, C1: int, temp: float = 50.0, zs_mem=None,
+                prop_scores=None, mem_scores_out=None, final_inv_stages: float = 0.0):
+    """`zs_mem` + `prop_scores` + `mem_scores_out`: also the memory update's CLIP re-score (what `memory_scores` computes) in the same
+    launch; `final_inv_stages` > 0 (last cascade stage): also the cascade score fusion (what `cascade_scores` does)."""
+    st = _lib.load().eod_zs_classify(feat.data_ptr(), zs.data_ptr(), prob_acc.data_ptr(), int(accumulate), _ptr(featn_out), _ptr(count),
+                                     R_cap, 512, C1, temp, _ptr(zs_mem), _ptr(prop_scores), _ptr(mem_scores_out),
+                                     float(final_inv_stages), _stream())
+    if st == -5:
+        raise _lib.EodError(f"eod_zs_classify: {C1 - 1} classes + background do not fit the kernel's LDS-staged class matrix (at most 23 "
+                            "classes): a RESET_CLS_TESTS / TEST_NUM_CLASSES vocabulary of this size is not supported on the HIP path")
+    check(st, "eod_zs_classify")
 
 
 def apply_deltas(deltas, ld: int, boxes, out, count, R_cap: int, weights, clip: bool, img_w: float, img_h: float):
@@ -349,10 +374,11 @@ def memory_scores(featn, zs, prop_scores, scores_out, count, R_cap: int, C1: int
 
 
 def detector_postprocess(boxes, scores, classes, count, cap: int, sx: float, sy: float, out_w: float, out_h: float, ob, os_, oc, osrc,
-                         ocount):
+                         ocount, remap=None):
+    """`remap` (int32 [cap], optional): osrc[q] = remap[index of the kept detection] -- the detection whose mask stands for it."""
     check(_lib.load().eod_detector_postprocess(boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), _ptr(count), cap, sx, sy,
                                                out_w, out_h, ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), osrc.data_ptr(),
-                                               ocount.data_ptr(), _stream()), "eod_detector_postprocess")
+                                               ocount.data_ptr(), _ptr(remap), _stream()), "eod_detector_postprocess")
 
 
 def paste_masks(prob, boxes, rows, count, K_cap: int, H: int, W: int, thr: float, out: torch.Tensor):

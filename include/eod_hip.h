@@ -84,6 +84,11 @@ typedef struct EodConvDesc {
    * like ONE image walks K exactly as the single-image call does (same split-K slabs, same summation order), so its results
    * are bitwise those of N separate calls (modeling/batched.py). */
   int32_t plan_rows;
+  /* 0, or bytes of LDS the fp32 kernel's launch allocates on top of its tiles and never touches.  LDS is what bounds the
+   * kernel's workgroups per CU (18 KB tiles: 8 per 160 KB), so a reserve caps them (e.g. 8 KB -> 6 per CU) and leaves wave slots,
+   * registers and LDS on every CU for the small latency-bound kernels other streams launch meanwhile: a grid of thousands of
+   * ~150 us workgroups that fills every slot makes a concurrent one-workgroup kernel wait for a slot for ~100 us. */
+  int32_t lds_reserve;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
@@ -152,9 +157,16 @@ int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream);
 
 /* ---- cascade box head glue ---------------------------------------------------------------------------- */
 /* ZeroShotClassifier tail (zero_shot_classifier.py:86-106): x=50*feat/max(|feat|,1e-12); logits=x@zs [512,C1];
- * prob_acc (+)= sigmoid(logits) (predict_probs, detic_fast_rcnn.py:325-339). */
+ * prob_acc (+)= sigmoid(logits) (predict_probs, detic_fast_rcnn.py:325-339).
+ * Optional tails of the same launch (NULL / 0 = off):
+ *   zs_mem [512,C1] + prop_scores [R] + mem_scores_out [R,C1]: the memory update's CLIP re-score of the proposals on the normalised
+ *     feature this launch holds in registers: sqrt(sigmoid(featn . zs_mem) * prop_score), 0 for prop_score >= 1
+ *     (inference_with_proposals, custom_rcnn.py:838-861) -- what eod_memory_scores computes from feat_norm_out;
+ *   final_inv_stages > 0 (last cascade stage, with prop_scores): prob_acc = sqrt(prob_acc * final_inv_stages * prop_score)
+ *     (detic_roi_heads.py:164-173) -- what eod_cascade_scores does in place. */
 int eod_zs_classify(const float* feat /*[R,512]*/, const float* zs /*[512,C1]*/, float* prob_acc /*[R,C1]*/, int accumulate,
                     float* feat_norm_out /*[R,512] or NULL*/, const int32_t* count, int R_cap, int D, int C1, float temp,
+                    const float* zs_mem, const float* prop_scores, float* mem_scores_out, float final_inv_stages,
                     eod_stream_t stream);
 /* Box2BoxTransform.apply_deltas + optional clip (detic_roi_heads.py:121-122,314) */
 int eod_apply_deltas(const float* deltas /*[R,ld]*/, int ld, const float* boxes, float* out, const int32_t* count, int R_cap,
@@ -163,7 +175,9 @@ int eod_apply_deltas(const float* deltas /*[R,ld]*/, int ld, const float* boxes,
 int eod_cascade_scores(float* prob_acc, const float* prop_scores, const int32_t* count, int R_cap, int C1, float inv_stages,
                        eod_stream_t stream);
 
-/* d2 fast_rcnn_inference, single image (detic_roi_heads.py:214-221, custom_rcnn.py:862-869) */
+/* d2 fast_rcnn_inference, single image (detic_roi_heads.py:214-221, custom_rcnn.py:862-869): threshold, sort, per-class NMS,
+ * top-k and the gather of the kept rows in ONE launch (one workgroup: the sort is followed by a chunked greedy NMS that stops
+ * once topk boxes are kept).  topk <= 512. */
 typedef struct EodDetDesc {
   const float* boxes;     /* [R,4] class agnostic */
   const float* scores;    /* [R,C1] (last column = background) */
@@ -177,15 +191,28 @@ typedef struct EodDetDesc {
   int32_t* out_rows;      /* [topk] proposal row of each detection */
   int32_t* out_count;     /* [1] */
   void* workspace; size_t workspace_bytes;
+  /* optional (NULL = off): torch.unique of out_rows -- ascending, duplicates removed (custom_rcnn.py:875) -- written by the same
+   * launch; needs R_cap <= 512 */
+  int32_t* out_unique_rows;   /* [unique_cap] */
+  int32_t* out_unique_count;  /* [1] */
+  int32_t unique_cap;
+  /* optional (NULL = off): detections that come from one proposal row carry the same class-agnostic box (they differ in class and
+   * score only), so everything computed from the box alone -- the mask head (CLS_AGNOSTIC_MASK) -- is the same for all of them.
+   * out_rep_of[k] = first detection with the row of detection k; out_rep_list = the detections that represent their group,
+   * ascending; out_rep_count = their number.  Needs R_cap <= 512. */
+  int32_t* out_rep_of;     /* [topk] */
+  int32_t* out_rep_list;   /* [topk] */
+  int32_t* out_rep_count;  /* [1] */
 } EodDetDesc;
 size_t eod_detections_workspace_bytes(int R_cap, int C1);
 int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream);
 
 /* d2 detector_postprocess without the mask paste (custom_rcnn.py:579): scale, clip, drop empty boxes.
- * out_src[q] = index of the kept detection in the input list. cap <= 512. */
+ * out_src[q] = index of the kept detection in the input list, or remap[that index] when remap is given (EodDetDesc.out_rep_of:
+ * the detection whose mask stands for it). cap <= 512. */
 int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
                              float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
-                             int32_t* out_classes, int32_t* out_src, int32_t* out_count, eod_stream_t stream);
+                             int32_t* out_classes, int32_t* out_src, int32_t* out_count, const int32_t* remap, eod_stream_t stream);
 /* paste_masks_in_image (d2, inside detector_postprocess; custom_rcnn.py:579,880): out[k] = grid_sample(prob[rows[k]],
  * box k) >= threshold, u8 [K,H,W].  rows NULL = identity. */
 int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap,

@@ -129,6 +129,7 @@ class RecurrentOracle:
         self._snap_mem = None
         self._snap_obs = None
         self.last = {}
+        self.timings = None          # dict: seconds per stage are accumulated into it (bench.py's cpu_baseline leg)
 
     def reset(self, n_cells: int):
         self.semmap_features = None
@@ -157,13 +158,21 @@ class RecurrentOracle:
             proj = proj.squeeze(2)
         image = frame["image"]
         H, W = image.shape[1:]
+        import time as _t
+        t0 = _t.perf_counter()
         mem_f16 = None
         if cfg.memory_type == "implicit_memory":
             mem = create_implicit_memory(self._snap_mem, self._snap_obs)
             mem_f16 = mem.to(torch.half)                    # preprocess_spatial_memory :1036
-        proposals, result = M.inference(self.sd, cfg, image, mem_f16, proj,
-                                        (frame.get("height", H), frame.get("width", W)))
+        t1 = _t.perf_counter()
+        kw = {} if self.timings is None else {"timings": self.timings}
+        proposals, result = M.inference(self.sd, cfg, image, mem_f16, proj, (frame.get("height", H), frame.get("width", W)), **kw)
+        t2 = _t.perf_counter()
         self.update_implicit_memory(proposals, proj, n_cells, (H, W))
+        if self.timings is not None:
+            self.timings["create_implicit_memory + fp16 cast"] = self.timings.get("create_implicit_memory + fp16 cast", 0.0) + (t1 - t0)
+            self.timings["memory write (update_implicit_memory)"] = (self.timings.get("memory write (update_implicit_memory)", 0.0)
+                                                                      + (_t.perf_counter() - t2))
         return {"instances": result, "proposals": proposals}
 
     def update_implicit_memory(self, proposals, proj, n_cells, image_hw):

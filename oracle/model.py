@@ -307,20 +307,37 @@ def detector_postprocess(boxes, scores, classes, masks28, image_hw, out_hw, cfg:
 # `CustomRCNNRecurrent.inference` (`custom_rcnn.py:548-582`)
 # ----------------------------------------------------------------------------------------------
 def inference(sd, cfg: OracleCfg, image_u8: torch.Tensor, memory_f16: Optional[torch.Tensor],
-              proj: Optional[torch.Tensor], out_hw: Optional[Tuple[int, int]] = None, want_intermediates: bool = False):
+              proj: Optional[torch.Tensor], out_hw: Optional[Tuple[int, int]] = None, want_intermediates: bool = False,
+              timings: Optional[dict] = None):
+    """`timings` (optional dict): seconds per stage are ADDED to it (bench.py's cpu_baseline leg: SURVEY 8d per-stage breakdown)."""
+    import time as _t
+    t_last = [_t.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = _t.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0])
+            t_last[0] = now
+
     H, W = image_u8.shape[1:]
     image_hw = (H, W)
     x = preprocess_image(image_u8, cfg)
     feats = backbone_forward(x, sd, cfg, memory_f16, proj)
+    lap("preprocess + backbone + FPN + memory read/fusion")
     agn, reg = centernet_head(feats, sd)
     prop_boxes, prop_scores = centernet_proposals(agn, reg, cfg)
+    lap("CenterNet head + proposal decoding")
     cas = cascade_box_heads(feats, prop_boxes, prop_scores, sd, cfg, image_hw)
     det_boxes, det_scores, det_classes, _ = ops.fast_rcnn_inference_single(
         cas["final_boxes"], cas["final_scores"], image_hw, cfg.score_thresh_test, cfg.nms_thresh_test,
         cfg.detections_per_image)
+    lap("cascade box heads + fast_rcnn_inference")
     det_masks = mask_head(feats, det_boxes, sd)                 # forward_with_given_boxes
+    lap("mask head (detections)")
     prop_masks = mask_head(feats, prop_boxes, sd)               # forward_mask_memory `:573-574`
+    lap("mask head (proposals)")
     result = detector_postprocess(det_boxes, det_scores, det_classes, det_masks, image_hw, out_hw or image_hw, cfg)
+    lap("detector_postprocess + paste")
     proposals = dict(proposal_boxes=prop_boxes, scores=prop_scores, feat=cas["feat0"], pred_masks=prop_masks)
     if want_intermediates:
         inter = dict(feats=feats, agn=agn, reg=reg, cascade=cas, det_boxes=det_boxes, det_scores=det_scores,

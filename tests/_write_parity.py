@@ -64,8 +64,8 @@ def check_write_against_oracle(model, mem_before: torch.Tensor, obs_before: torc
                 cells_over_tol=int((cell_rel > rel).sum()), observations_exact=bool(torch.equal(got_obs, exp_obs)), evidence=ev)
 
 
-def mask_flip_attribution(ev: Dict[str, torch.Tensor], oracle_last: dict, H: int, W: int) -> dict:
-    """Statement 2.  Pairs the HIP frame's memory instances with the oracle frame's (same box to 1e-3 px) and classifies every
+def mask_flip_attribution(ev: Dict[str, torch.Tensor], oracle_last: dict, H: int, W: int, band: float = FLIP_BAND) -> dict:
+    """Statement 2.  Pairs the HIP frame's memory instances with the oracle frame's (same box to 1e-2 px) and classifies every
     pasted-mask pixel on which the two disagree by the oracle's own pre-threshold sample."""
     out = dict(instances_hip=ev["K"], instances_oracle=int(oracle_last.get("K", 0)), paired=0, unpaired=0, flipped_pixels=0,
                flips_outside_band=0, max_flip_distance=0.0, masks_identical=False)
@@ -78,7 +78,7 @@ def mask_flip_attribution(ev: Dict[str, torch.Tensor], oracle_last: dict, H: int
     for i in range(ev["K"]):
         d = (ob - ev["boxes"][i][None]).abs().max(dim=1).values
         j = int(d.argmin())
-        if float(d[j]) > 1e-3:
+        if float(d[j]) > 1e-2:        # the same proposal: its box agrees to the proposal tolerance (unclipped boxes, up to ~1e3 px)
             out["unpaired"] += 1
             identical = False
             continue
@@ -93,7 +93,7 @@ def mask_flip_attribution(ev: Dict[str, torch.Tensor], oracle_last: dict, H: int
                 prob[j] = OO.paste_masks_prob(om28[j:j + 1], ob[j:j + 1], (H, W))[0]
             dist = (prob[j][diff] - 0.5).abs()
             out["flipped_pixels"] += n
-            out["flips_outside_band"] += int((dist >= FLIP_BAND).sum())
+            out["flips_outside_band"] += int((dist >= band).sum())
             out["max_flip_distance"] = max(out["max_flip_distance"], float(dist.max()))
     out["masks_identical"] = bool(identical and out["unpaired"] == 0 and out["paired"] == out["instances_oracle"])
     return out

@@ -202,6 +202,71 @@ def test_conv_epilogues(dev):
     close(nchw(y), F.conv2d(F.relu(x), w, b, padding=1))
 
 
+@pytest.mark.parametrize("case", [
+    (1, 20, 20, 1024, 256, 1, 1, 0),     # layer3 conv1 / FPN lateral: 32 chunks -> 4 waves
+    (1, 20, 20, 256, 256, 3, 2, 1),      # stride-2 3x3 (layer4 conv2 / P6): 72 chunks -> 8 waves
+    (1, 10, 10, 512, 2048, 1, 1, 0),     # layer4 conv3
+    (1, 5, 5, 256, 256, 3, 2, 1),        # P7: 9 output rows
+    (3, 10, 14, 512, 96, 3, 1, 1),       # a batch, Cout not a multiple of 32, 144 chunks
+    (37, 1, 1, 1024, 4, 1, 1, 0),        # bbox_pred.2: four output channels
+])
+def test_conv_wavek_few_rows_deep_k(dev, case):
+    """Layers with fewer than 256 tiles of 64x64 and 8 <= K/32 <= 192 split K over the WAVES of a workgroup (conv_wavek_kernel):
+    no slabs, no reduce launch.  Against F.conv2d, with every epilogue; a batch gives bitwise the rows of the single-image calls."""
+    from embodied_object_detection_amd import ops
+    N, H, W, Cin, Cout, k, stride, pad = case
+    x = rnd(N, Cin, H, W, seed=51)
+    w = rnd(Cout, Cin, k, k, seed=52, scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=53)
+    conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
+    xd = nhwc(x).to(dev)
+    assert ops._lib.load().eod_conv2d_workspace_bytes is not None
+    y = conv(xd, N, H, W)
+    assert conv.desc.workspace_bytes == 0, "the wave-split-K plan needs no slab workspace"
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    close(nchw(y), ref)
+    OH, OW = ref.shape[2:]
+    res = rnd(N, Cout, OH, OW, seed=54)
+    y = conv(xd, N, H, W, res=nhwc(res).to(dev), res_mode=1, relu=True, in_relu=True, out_scale=2.0)
+    close(nchw(y), F.relu(F.conv2d(F.relu(x), w, b, stride=stride, padding=pad) * 2.0 + res), rtol=3e-4, atol=3e-4)
+    # the slab path on the same problem agrees to fp32 noise (another summation order)
+    y_slab = conv(xd, N, H, W, force_tile=3, force_splitk=3)
+    close(y_slab, conv(xd, N, H, W), rtol=1e-5, atol=1e-5)
+    if N > 1:
+        yb = conv(xd, N, H, W, plan_rows=OH * OW).clone()
+        for n in range(N):
+            y1 = conv(xd[n:n + 1].contiguous(), 1, H, W)
+            assert torch.equal(yb[n:n + 1], y1), "batched rows must be bitwise those of the single-image call"
+    if H == 1 and W == 1:
+        # a device-side row count: rows beyond it are left untouched
+        cnt = torch.tensor([20], dtype=torch.int32, device=dev)
+        out = torch.full((N, 1, 1, Cout), 7.0, device=dev)
+        conv(xd, N, 1, 1, m_count=cnt, m_unit=1, out=out)
+        close(nchw(out)[:20], ref[:20])
+        assert float((out[20:] - 7.0).abs().max()) == 0.0
+
+
+def test_conv_wavek_pyramid_mode(dev):
+    """The shared-weight head over a small pyramid (one row list, per-level zero padding) also takes the wave-split-K path."""
+    from embodied_object_detection_amd import ops
+    shapes = [(12, 16), (6, 8), (3, 4)]
+    Cin, Cout = 256, 5
+    w = rnd(Cout, Cin, 3, 3, seed=61, scale=0.02)
+    b = rnd(Cout, seed=62)
+    xs = [rnd(1, Cin, h, ww, seed=63 + i) for i, (h, ww) in enumerate(shapes)]
+    off = [0]
+    for (h, ww) in shapes:
+        off.append(off[-1] + h * ww)
+    rows = torch.cat([nhwc(x).reshape(-1, Cin) for x in xs]).contiguous().to(dev)
+    conv = ops.Conv(w, b, pad=1, device=dev)
+    out = torch.zeros((off[-1], Cout), device=dev)
+    conv(rows, 1, 0, 0, out=out, levels=(off, shapes))
+    assert conv.desc.workspace_bytes == 0
+    for i, (h, ww) in enumerate(shapes):
+        ref = F.conv2d(xs[i], w, b, padding=1)
+        close(out[off[i]:off[i + 1]].view(1, h, ww, Cout).permute(0, 3, 1, 2), ref)
+
+
 def test_conv_stem_tap4_with_bn_fold(dev):
     from embodied_object_detection_amd import ops
     H, W = 64, 96
@@ -399,6 +464,13 @@ def test_fast_rcnn_inference_matches_oracle(dev, thresh, topk, R):
         close(b[:n], rb, rtol=0, atol=0)
         assert torch.equal(c[:n].cpu().long(), rc.long())
         assert torch.equal(r[:n].cpu().long(), rr.long())
+    # the same launch can also write torch.unique of the kept rows (custom_rcnn.py:875); a second call reuses the buffers
+    selu = ops.DetectionSelector(cap, 21, topk, dev, unique=True)
+    for _ in range(2):
+        b2, s2, c2, r2, n2 = selu(bp.to(dev), sp.to(dev), cnt, 200.0, 150.0, thresh, 0.5)
+        assert int(n2.item()) == n and torch.equal(r2[:n], r[:n]) and torch.equal(b2[:n], b[:n])
+        u = torch.unique(rr.long())
+        assert int(selu.uniq_count.item()) == u.numel() and torch.equal(selu.uniq_rows[:u.numel()].cpu().long(), u)
 
 
 def test_box_head_glue(dev):
@@ -425,6 +497,26 @@ def test_box_head_glue(dev):
     ref_ms = (torch.sigmoid(xn @ zs) * ps[:, None]) ** 0.5
     ref_ms[4] = 0
     close(ms[:R], ref_ms[:R], rtol=1e-5, atol=1e-6)
+    # the same two tails fused into the classifier launch (stage 0: memory re-score; last stage: cascade score fusion): bitwise
+    # what the separate launches give
+    zs2 = (zs * 0.5 + 0.01).contiguous()                               # a second class matrix (the meta-architecture's own)
+    prob_f = torch.zeros((cap, 21), device=dev)
+    featn_f = torch.zeros((cap, 512), device=dev)
+    ms_f = torch.zeros((cap, 21), device=dev)
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob_f, False, featn_f, cnt, cap, 21, zs_mem=zs2.to(dev), prop_scores=ps.to(dev),
+                    mem_scores_out=ms_f)
+    ms_s = torch.zeros((cap, 21), device=dev)
+    ops.memory_scores(featn_f, zs2.to(dev), ps.to(dev), ms_s, cnt, cap, 21)
+    assert torch.equal(featn_f, featn) and torch.equal(ms_f[:R], ms_s[:R]) and float(ms_f[4].abs().max()) == 0.0
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob_f, True, None, cnt, cap, 21, prop_scores=ps.to(dev), final_inv_stages=0.5)
+    prob_s = torch.zeros((cap, 21), device=dev)
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob_s, False, None, cnt, cap, 21)
+    ops.zs_classify(feat.to(dev), zs.to(dev), prob_s, True, None, cnt, cap, 21)
+    ops.cascade_scores(prob_s, ps.to(dev), cnt, cap, 21, 0.5)
+    assert torch.equal(prob_f[:R], prob_s[:R])
+    from embodied_object_detection_amd._lib import EodError
+    with pytest.raises(EodError, match="classes"):                     # a vocabulary the LDS-staged class matrix cannot hold
+        ops.zs_classify(feat.to(dev), torch.zeros((512, 30), device=dev), torch.zeros((cap, 30), device=dev), False, None, cnt, cap, 30)
     # apply_deltas + clip
     boxes = torch.rand((cap, 4)) * 100
     boxes[:, 2:] += boxes[:, :2] + 1

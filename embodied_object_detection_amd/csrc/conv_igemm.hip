@@ -134,12 +134,15 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     splitk = 1;
   } else if (d->force_splitk > 0) {
     splitk = d->force_splitk;
-  } else if (tiles < 256 && nchunks >= 8 && nchunks <= 192 && pl.glds == 0 && pl.bk == 32 && !d->tap4 && d->force_tile == 0 &&
-             wavek_env()) {
+  } else if (pl.glds == 0 && !d->tap4 && nchunks >= 8 &&
+             ((d->force_tile == 6 || d->force_tile == 7) ||
+              (tiles < 256 && nchunks <= 192 && pl.bk == 32 && d->force_tile == 0 && wavek_env()))) {
     // Few rows, K up to 6144 (ResNet layer3/4 at batch 1, FPN laterals / outputs 4-5, P6/P7, the box heads' 1024-wide FC layers):
     // K is split over the waves of a workgroup that owns a 32x32 tile (conv_wavek_kernel) -- no slabs, no reduce launch.  Eight
     // waves once a wave's share would exceed 16 chunks.
-    pl.wavek = nchunks >= 64 ? 8 : 4;
+    pl.wavek = d->force_tile == 6 ? 4 : (d->force_tile == 7 ? 8 : (nchunks >= 64 ? 8 : 4));     // force_tile 6 / 7: benchmarks, tests
+    pl.bk = 32;
+    pl.nchunks = d->Kpad / 32;
     pl.bm = pl.bn = 32;
     pl.tiles_m = (M + 31) / 32;
     pl.tiles_n = (d->Cout + 31) / 32;

@@ -1,0 +1,172 @@
+// Backward of the memory READ (first slice): gradients of the three `map_merge_projection` 1x1 convolutions and of
+// the cascaded average pools of `CustomRecurrentFPN.forward` (Detic/detic/modeling/backbone/timm.py:142-192), the part of
+// `forward_model` (custom_rcnn.py:584-679) that is specific to the spatial memory.  Forward, per level l = 3, 4, 5:
+//
+//   E_l = half(avg_pool2(float(E_{l-1})))          E_2 := avg_pool4(float(memory[proj]))  (fp32)
+//   out_l = (conv1x1(float(E_l); W_l, b_l) * weight) + P_l
+//
+// Given G_l = dL/d out_l ([P_l, 256] rows, NHWC):
+//   dW_l[co][ci] = weight * sum_pos G_l[pos][co] * E_l[pos][ci]      db_l[co] = weight * sum_pos G_l[pos][co]         (kernel 1)
+//   dEc_l[pos][ci] = weight * sum_co G_l[pos][co] * W_l[co][ci]       a 1x1 convolution with the transposed weights: eod_conv2d
+//   pools (autograd semantics of the fp16 casts: a gradient that flows into a half tensor is rounded to half, two contributions
+//   to one half tensor are added in half):                                                                              (kernel 2)
+//     gE_5 = half(dEc_5)
+//     gE_4 = half(dEc_4) +h half(up2(float(gE_5)) / 4)
+//     gE_3 = half(dEc_3) +h half(up2(float(gE_4)) / 4)
+//     gE_2 = up2(float(gE_3)) / 4                                    (fp32, [H/4 * W/4, 512])
+// The memory table itself is an input of the reference's training step (loaded from disk, loader.py:199-223), not a parameter: no
+// gradient flows below E_2.
+//
+// Kernel 1 needs no LDS staging: the MFMA operand layout of v_mfma_f32_32x32x2_f32 (lane l supplies row l % 32, k = l / 32) reads
+// 32 consecutive channels of one position per half wave -- coalesced as the rows lie in memory.  A workgroup owns one 32x32 tile
+// of dW_l; its four waves take a quarter of the positions each and are added in wave order (deterministic).
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+// pooled rows in the operand-fragment order eod_memory_gather_pool writes (include/eod_hip.h):
+// [32-row tile][k-step s<32][hi<2][r<32][8] halves = element (row 32*tile + r, channel 16 s + 8 hi + j)
+__device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
+  return ((((size_t)tile32 * 32 + (c8 >> 1)) * 2 + (c8 & 1)) * 32 + r) * 8;
+}
+
+struct BwdArgs {
+  const float* g[3];        // G_l [P_l, 256]
+  const __half* pooled;     // E_3..E_5, fragment order, each level on a tile boundary
+  float* dw[3];             // [256, 512]
+  float* db[3];             // [256]
+  int rows[3];              // P_l
+  int tile_base[3];         // first 32-row tile of level l in `pooled`
+  float weight;
+};
+
+__global__ __launch_bounds__(256) void proj_backward_weights_kernel(BwdArgs a) {
+  const int level = blockIdx.y;
+  const int tile = blockIdx.x;              // 8 (co) x 16 (ci) tiles of 32x32
+  const int co0 = (tile >> 4) * 32, ci0 = (tile & 15) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = a.rows[level];
+  const float* __restrict__ G = a.g[level];
+  const int col = lane & 31, kh = lane >> 5;
+  // positions of this wave: a contiguous quarter, rounded to whole k-steps of 8 positions
+  const int steps = (P + 7) / 8;
+  const int spw = (steps + 3) / 4;
+  const int s_begin = wave * spw;
+  int s_end = s_begin + spw;
+  if (s_end > steps) s_end = steps;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int ci = ci0 + col;
+  for (int s = s_begin; s < s_end; ++s) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = s * 8 + 2 * t + kh;       // instruction t contracts positions 8 s + 2 t and 8 s + 2 t + 1
+      const bool ok = pos < P;
+      av[t] = ok ? G[(size_t)pos * 256 + co0 + col] : 0.f;
+      bv[t] = ok ? __half2float(a.pooled[frag_half_offset(a.tile_base[level] + (pos >> 5), pos & 31, ci >> 3) + (ci & 7)]) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      bsum += av[t];
+    }
+  }
+  __shared__ float red[3 * 16 * 64];
+  __shared__ float bred[4 * 64];
+  bred[wave * 64 + lane] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
+  // C/D layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    a.dw[level][(size_t)co * 512 + ci] = acc[r] * a.weight;
+  }
+  if ((tile & 15) == 0 && lane < 32) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += bred[w * 64 + lane] + bred[w * 64 + 32 + lane];    // even + odd positions, wave order
+    a.db[level][co0 + lane] = v * a.weight;
+  }
+}
+
+struct PoolBwdArgs {
+  const float* dec[3];      // dEc_3, dEc_4, dEc_5: [P_l, 512] fp32 rows
+  __half* ge[3];            // gE_3, gE_4, gE_5: [P_l, 512] half rows
+  float* ge2;               // [(H/4) * (W/4), 512] fp32
+  int h2, w2;               // H / 4, W / 4
+};
+
+__device__ __forceinline__ float round_half(float v) { return __half2float(__float2half_rn(v)); }
+
+// one thread per (position of the H/4 x W/4 grid, channel): it recomputes the chain of its P5 / P4 / P3 ancestors (pointwise) and
+// stores the levels whose top-left corner it is
+__global__ __launch_bounds__(256) void pool_backward_kernel(PoolBwdArgs a) {
+  const size_t total = (size_t)a.h2 * a.w2 * 512;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 511);
+    const int p = (int)(i >> 9);
+    const int y = p / a.w2, x = p - y * a.w2;
+    const int w3 = a.w2 >> 1, w4 = a.w2 >> 2, w5 = a.w2 >> 3;
+    const size_t p3 = (size_t)(y >> 1) * w3 + (x >> 1), p4 = (size_t)(y >> 2) * w4 + (x >> 2), p5 = (size_t)(y >> 3) * w5 + (x >> 3);
+    const float g5 = round_half(a.dec[2][p5 * 512 + c]);
+    const float g4 = round_half(round_half(a.dec[1][p4 * 512 + c]) + round_half(g5 * 0.25f));
+    const float g3 = round_half(round_half(a.dec[0][p3 * 512 + c]) + round_half(g4 * 0.25f));
+    a.ge2[i] = g3 * 0.25f;
+    if (((y | x) & 1) == 0) a.ge[0][p3 * 512 + c] = __float2half_rn(g3);
+    if (((y | x) & 3) == 0) a.ge[1][p4 * 512 + c] = __float2half_rn(g4);
+    if (((y | x) & 7) == 0) a.ge[2][p5 * 512 + c] = __float2half_rn(g5);
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_memory_project_backward_weights(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
+                                                   int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,
+                                                   float* db5, eod_stream_t stream) {
+  if (!g3 || !g4 || !g5 || !pooled_f16 || !dw3 || !db3 || !dw4 || !db4 || !dw5 || !db5) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31)) return EOD_ERR_BAD_DIMS;
+  BwdArgs a{};
+  a.g[0] = g3; a.g[1] = g4; a.g[2] = g5;
+  a.pooled = reinterpret_cast<const __half*>(pooled_f16);
+  a.dw[0] = dw3; a.dw[1] = dw4; a.dw[2] = dw5;
+  a.db[0] = db3; a.db[1] = db4; a.db[2] = db5;
+  int base = 0;
+  for (int l = 0; l < 3; ++l) {
+    a.rows[l] = (H >> (3 + l)) * (W >> (3 + l));
+    a.tile_base[l] = base;
+    base += (a.rows[l] + 31) / 32;
+  }
+  a.weight = weight;
+  hipLaunchKernelGGL(proj_backward_weights_kernel, dim3(128, 3), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* dec5, int H, int W, uint16_t* ge3_f16,
+                                        uint16_t* ge4_f16, uint16_t* ge5_f16, float* ge2, eod_stream_t stream) {
+  if (!dec3 || !dec4 || !dec5 || !ge3_f16 || !ge4_f16 || !ge5_f16 || !ge2) return EOD_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31)) return EOD_ERR_BAD_DIMS;
+  PoolBwdArgs a{};
+  a.dec[0] = dec3; a.dec[1] = dec4; a.dec[2] = dec5;
+  a.ge[0] = reinterpret_cast<__half*>(ge3_f16); a.ge[1] = reinterpret_cast<__half*>(ge4_f16); a.ge[2] = reinterpret_cast<__half*>(ge5_f16);
+  a.ge2 = ge2;
+  a.h2 = H >> 2; a.w2 = W >> 2;
+  const size_t total = (size_t)a.h2 * a.w2 * 512;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}

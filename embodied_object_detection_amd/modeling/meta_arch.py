@@ -116,6 +116,9 @@ class CustomRCNNRecurrent:
         # latency-bound chains that leave most of the chip idle).  Three pyramid sets and two detection-list sets make the
         # overlap hazard free; results are bitwise those of the in-order schedule.
         self.pipeline_detection_pass = True
+        # may the detection pass of frame t still run when frame t+1 starts?  (False: the frame's chain joins it at the end of the frame)
+        self.trail_detection_pass = True
+        self.det_stream_priority = 0         # 0 = normal, -1 = high (like the chains)
         # Memory selection right after cascade stage 0 on its own stream (it needs only the stage-0 features) instead of after the
         # cascade.  Measured (tools/frame_schedule.py, same box): True lets the proposal-mask pass and the memory write finish
         # early, the next frame then starts while the detection pass still runs and its latency-bound chain is slowed 3x by the
@@ -295,7 +298,7 @@ class CustomRCNNRecurrent:
                 last = nxt is None and input_seq is batched_inputs[-1]
                 t0 = _time.perf_counter()
                 self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
-                                     trailing_detection_pass=not last)
+                                     trailing_detection_pass=(not last) and self.trail_detection_pass)
                 pending.append(self._post_ticket())
                 t1 = _time.perf_counter()
                 if len(pending) == RESULT_SETS:
@@ -617,7 +620,7 @@ class CustomRCNNRecurrent:
         frame on the detection stream (lowest priority: its GEMMs fill whatever the latency-bound chains of the frame -- and of
         the next frame -- leave idle)."""
         if self._det_stream is None:
-            self._det_stream = torch.cuda.Stream(device=self.device, priority=0)
+            self._det_stream = torch.cuda.Stream(device=self.device, priority=int(self.det_stream_priority))
             self._ev_det = [torch.cuda.Event() for _ in range(RESULT_SETS)]
         ds = self._det_stream
         det_boxes, det_scores, det_classes, det_rows, det_count = det

@@ -458,6 +458,39 @@ class MemoryProjector:
         return feats
 
 
+class MemoryProjectorBackward:
+    """Backward of `MemoryProjector` + the cascaded pools (timm.py:142-192): the memory-specific part of the training forward
+    (first slice).  `__call__(grads, pooled_f16, H, W, weight)` with `grads` = dL/d(fused P3, P4, P5) as [P_l,256]
+    fp32 rows -> dict(dW=[3 x [256,512]], db=[3 x [256]], gE=[3 x half [P_l,512]], gE2=fp32 [(H/4)(W/4),512])."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], device):
+        self.lib = _lib.load()
+        self.device = device
+        # d(pooled) = weight * G . W: a 1x1 convolution whose [Cout=512][K=256] matrix is W^T
+        self.convs = [Conv(w.detach().to(torch.float32).reshape(256, 512).t().contiguous().reshape(512, 256, 1, 1), None, device=device,
+                           name=f"map_merge_projection{i + 1}^T") for i, w in enumerate(weights)]
+
+    def __call__(self, grads: Sequence[torch.Tensor], pooled_f16: torch.Tensor, H: int, W: int, weight: float):
+        _need_cuda(pooled_f16, *grads)
+        dev = self.device
+        rows = [(H >> (3 + l)) * (W >> (3 + l)) for l in range(3)]
+        for g, r in zip(grads, rows):
+            assert tuple(g.shape) == (r, 256) and g.dtype == torch.float32 and g.is_contiguous()
+        dW = [torch.empty((256, 512), dtype=torch.float32, device=dev) for _ in range(3)]
+        db = [torch.empty((256,), dtype=torch.float32, device=dev) for _ in range(3)]
+        check(self.lib.eod_memory_project_backward_weights(grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(),
+                                                           pooled_f16.data_ptr(), H, W, float(weight), dW[0].data_ptr(), db[0].data_ptr(),
+                                                           dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), _stream()),
+              "eod_memory_project_backward_weights")
+        dec = [self.convs[l](grads[l].view(1, H >> (3 + l), W >> (3 + l), 256), 1, H >> (3 + l), W >> (3 + l), out_scale=float(weight))
+               .view(rows[l], 512) for l in range(3)]
+        gE = [torch.empty((rows[l], 512), dtype=torch.float16, device=dev) for l in range(3)]
+        gE2 = torch.empty(((H >> 2) * (W >> 2), 512), dtype=torch.float32, device=dev)
+        check(self.lib.eod_memory_pool_backward(dec[0].data_ptr(), dec[1].data_ptr(), dec[2].data_ptr(), H, W, gE[0].data_ptr(),
+                                                gE[1].data_ptr(), gE[2].data_ptr(), gE2.data_ptr(), _stream()), "eod_memory_pool_backward")
+        return dict(dW=dW, db=db, gE=gE, gE2=gE2, dEc=dec)
+
+
 class MemoryWriter:
     """a16-a19 write path (custom_rcnn.py:681-760) on device."""
 

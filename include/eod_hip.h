@@ -60,7 +60,7 @@ typedef struct EodConvDesc {
                         predictor (see fuse_w below) */
   int32_t tap4;      /* 1: Cin == 4 (stem, RGB padded to 4): one float4 per tap */
   int32_t force_tile; /* 0 auto, else tile + 10 * variant: tile 1=128x128 2=128x64 3=64x64; variant 0 default, 1 BK=32, 2 BK=64,
-                         5 bf16x3 split math (benchmarks/tests) */
+                         5 bf16x3 split math; 6 / 7: the 32x32-tile kernel that splits K over 4 / 8 waves (benchmarks/tests) */
   int32_t force_splitk; /* 0 auto */
   float out_scale;
   /* pyramid mode (levels > 0): x / y are [level_off[levels], C] row lists, level l is a level_h[l] x level_w[l] image;
@@ -258,6 +258,19 @@ int eod_memory_scores(const float* featn /*[R,512]*/, const float* zs, const flo
 /* torch.unique of the kept proposal rows (custom_rcnn.py:875): ascending, duplicates removed. R_cap <= 512. */
 int eod_unique_rows(const int32_t* rows, const int32_t* count, int K_cap, int R_cap, int32_t* out_rows, int32_t* out_count,
                     eod_stream_t stream);
+/* ---- training forward, first slice: backward of the memory read (timm.py:142-192) ------------------------------
+ * g3 / g4 / g5: dL/d(fused P3 / P4 / P5), [P_l, 256] fp32 rows; pooled_f16: the buffer eod_memory_gather_pool wrote in the forward.
+ * dW_l [256,512] = weight * G_l^T . E_l, db_l [256] = weight * column sums of G_l (fp32 MFMA, deterministic summation order).
+ * The gradient with respect to the pooled operand, weight * G_l . W_l, is a 1x1 convolution with the transposed weights: eod_conv2d. */
+int eod_memory_project_backward_weights(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H, int W,
+                                        float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5, float* db5,
+                                        eod_stream_t stream);
+/* Backward of the cascaded pools avg_pool2 -> half (timm.py:163-168) with autograd's rounding of gradients that enter half tensors:
+ * dec3..5 = weight * G_l . W_l ([P_l,512] fp32 rows) -> ge3..5 (gradients of the half tensors E_3..E_5, [P_l,512] half rows) and
+ * ge2 (gradient of the fp32 avg_pool4 output, [(H/4)*(W/4), 512]). */
+int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* dec5, int H, int W, uint16_t* ge3_f16, uint16_t* ge4_f16,
+                             uint16_t* ge5_f16, float* ge2, eod_stream_t stream);
+
 /* a16-a19 write path (custom_rcnn.py:681-760,875-936) */
 typedef struct EodMemWriteDesc {
   const float* featn;       /* [R,512] normalised x50 proposal features */

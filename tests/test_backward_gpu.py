@@ -1,0 +1,62 @@
+"""Training forward, first slice: backward of the memory READ (timm.py:142-192) on HIP against torch autograd
+on the oracle's own forward (`oracle/model.py::memory_read_pooled` / `fuse_memory`, run on the CPU in fp32 with the reference's
+fp16 casts): dW / db of the three `map_merge_projection` 1x1 convolutions and the gradients of the cascaded pools."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as M
+
+
+@pytest.mark.parametrize("H,W,n_cells", [(64, 96, 300), (128, 160, 576)])
+def test_memory_read_backward_matches_autograd(H, W, n_cells):
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    weight = 5.0
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 3).half()
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    Ws = [(torch.randn((256, 512, 1, 1), generator=g) * 0.05).requires_grad_() for _ in range(3)]
+    bs = [(torch.randn((256,), generator=g) * 0.1).requires_grad_() for _ in range(3)]
+    # ---- oracle forward with autograd (memory_read_pooled + fuse_memory, written out so that the pooled tensors keep their grads)
+    ego = mem16[proj].permute(2, 0, 1).unsqueeze(0)
+    e2 = F.avg_pool2d(ego.to(torch.float32), kernel_size=4, stride=4).detach().requires_grad_()       # E_2: fp32 leaf
+    pooled, cur = [], e2
+    for _ in range(3):
+        cur = F.avg_pool2d(cur.to(torch.float32), kernel_size=2, stride=2).to(torch.half)
+        cur.retain_grad()
+        pooled.append(cur)
+    ref_pooled = M.memory_read_pooled(mem16, proj)
+    assert all(torch.equal(a.detach(), b) for a, b in zip(pooled, ref_pooled)), "the test's forward is the oracle's forward"
+    res = [torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) for l in range(3)]
+    G = [torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) for l in range(3)]
+    loss = 0.0
+    for l in range(3):
+        out = F.conv2d(pooled[l].to(torch.float32), Ws[l], bs[l]) * weight + res[l]
+        loss = loss + (out * G[l]).sum()
+    loss.backward()
+    # ---- HIP: forward's pooled buffer (fragment order) from the product's gather, then the backward kernels
+    pooled_d = ops.memory_gather_pool(mem16.to(dev), proj.int().to(dev), H, W, torch_order=True)
+    bwd = ops.MemoryProjectorBackward([w.detach() for w in Ws], dev)
+    grads = [G[l][0].permute(1, 2, 0).reshape(-1, 256).contiguous().to(dev) for l in range(3)]
+    out = bwd(grads, pooled_d, H, W, weight)
+    for l in range(3):
+        ref_dw = Ws[l].grad.reshape(256, 512)
+        scale = ref_dw.abs().max().item()
+        err = (out["dW"][l].cpu() - ref_dw).abs().max().item()
+        assert err <= 2e-5 * scale, f"dW{l + 3}: {err:.3e} at scale {scale:.3e}"
+        ref_db = bs[l].grad
+        assert (out["db"][l].cpu() - ref_db).abs().max().item() <= 2e-5 * ref_db.abs().max().item(), f"db{l + 3}"
+        # gradients of the half tensors: autograd rounds them to half on the way; identical up to one half ulp where the fp32
+        # convolution's summation order moved a value across a rounding boundary
+        ref_g = pooled[l].grad[0].permute(1, 2, 0).reshape(-1, 512).float()
+        got_g = out["gE"][l].cpu().float()
+        tol = 2.0 ** -10 * ref_g.abs().clamp_min(1e-3)
+        assert bool(((got_g - ref_g).abs() <= tol).all()), f"gE{l + 3}"
+        assert float((got_g == ref_g).float().mean()) > 0.99, f"gE{l + 3}: mostly bit-identical halves"
+    ref_g2 = e2.grad[0].permute(1, 2, 0).reshape(-1, 512)
+    got_g2 = out["gE2"].cpu()
+    assert bool(((got_g2 - ref_g2).abs() <= 2.0 ** -10 * ref_g2.abs().clamp_min(1e-3)).all())
+    assert float((got_g2 == ref_g2).float().mean()) > 0.99

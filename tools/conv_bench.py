@@ -36,6 +36,11 @@ def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=
                 print(name, t, sk, "ERR", ex)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "propmask":
+    # the proposal-mask pass (~43 ROIs) and the de-duplicated detection pass (~100 ROIs): 64x64 tiles against the wave-split-K kernel
+    for rois in (43, 100, 300):
+        bench(f"mask_fcn {rois} rois", rois, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 6, 7), iters=30)
+    sys.exit(0)
 if which == "masktiles":
     bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 11, 13, 12), iters=30)
     bench("mask_fcn 45 rois", 45, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 11), iters=30)

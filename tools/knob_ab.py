@@ -46,16 +46,19 @@ def apply(model, spec):
 def run(model):
     model([frames[:20]])
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    model([frames[20:40]])
-    model([frames[40:60]])
-    torch.cuda.synchronize()
-    return 40 / (time.perf_counter() - t)
+    out = []
+    for _ in range(int(os.environ.get("AB_PASSES", 2))):      # consecutive 40-frame passes of the same model: does the rate hold?
+        t = time.perf_counter()
+        model([frames[20:40]])
+        model([frames[40:60]])
+        torch.cuda.synchronize()
+        out.append(40 / (time.perf_counter() - t))
+    return out
 
 
 specs = sys.argv[1:] or [""]
 res = {s: [] for s in specs}
-for rep in range(2):
+for rep in range(int(os.environ.get("AB_REPS", 3))):
     for s in specs:
         m = build_model(cfg, sd)
         apply(m, s)
@@ -63,4 +66,4 @@ for rep in range(2):
         del m
         torch.cuda.empty_cache()
 for s in specs:
-    print(f"{s or '(default)':70s} " + "  ".join(f"{v:7.1f}" for v in res[s]) + " frames/s", flush=True)
+    print(f"{s or '(default)':70s} " + "  ".join("/".join(f"{v:.1f}" for v in r) for r in res[s]) + " frames/s", flush=True)

@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 //   mw_commit_kernel   per hit cell: mean of the per-pixel means from the weight table (f64, instance order), accumulate into the
 //                      memory, observation counter, fp16 snapshot row (or dirty mark); leaves every per-frame table zero again
 // ------------------------------------------------------------------------------------------------------
+#define SCAN_ELEMS 1024        // pixels per workgroup of the two pixel passes: 256 threads x 4 consecutive pixels of one image row
+
 struct MwWs {
   int* inst_rows;   // [R_cap] unique proposal rows, ascending
   int* k_u;         // [1]
@@ -130,7 +132,7 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap
   w.cell_flag = (int*)take((size_t)n_cells * 4);
   w.cell_cnt = (int*)take((size_t)n_cells * 4);
   w.wtab = (long long*)take((size_t)n_cells * (size_t)K_cap * 8);
-  w.blk_pix = (int*)take(((P + 4095) / 4096 + 1) * 4);
+  w.blk_pix = (int*)take(((P + SCAN_ELEMS - 1) / SCAN_ELEMS + 1) * 4);
   w.bytes = off;
   return w;
 }
@@ -138,12 +140,12 @@ MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap
 #define MW_MAX_R 512
 #define MW_MAX_K 128
 
-// unique(det_rows) ascending (custom_rcnn.py:875) by all 512 threads of the calling block's first 8 waves: flags in LDS, ballot
+// unique(det_rows) ascending (custom_rcnn.py:875) by the whole workgroup (any multiple of 64 threads): flags in LDS, ballot
 // compaction.  Returns the count; `rows_s[0..count)` holds the rows.  Every thread of the block must call it.
 __device__ __forceinline__ int block_unique_rows(const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap, int R_cap,
                                                  int* flag_s /*[512]*/, int* wcnt_s /*[8]*/, int* rows_s /*[MW_MAX_K]*/) {
   const int t = threadIdx.x;
-  if (t < MW_MAX_R) flag_s[t] = 0;
+  for (int i = t; i < MW_MAX_R; i += blockDim.x) flag_s[i] = 0;
   __syncthreads();
   int K = *det_count;
   K = K < K_cap ? K : K_cap;
@@ -152,25 +154,24 @@ __device__ __forceinline__ int block_unique_rows(const int* __restrict__ det_row
     if (r >= 0 && r < R_cap) flag_s[r] = 1;
   }
   __syncthreads();
-  const int lane = t & 63, wave = t >> 6;
-  int f = 0;
-  unsigned long long bal = 0;
-  if (t < MW_MAX_R) {
-    f = flag_s[t];
-    bal = __ballot(f != 0);
-    if (lane == 0) wcnt_s[wave] = __popcll(bal);
+  const int lane = t & 63;
+  for (int i = t; i < MW_MAX_R; i += blockDim.x) {        // i >> 6 is wave-uniform
+    const unsigned long long bal = __ballot(flag_s[i] != 0);
+    if (lane == 0) wcnt_s[i >> 6] = __popcll(bal);
   }
   __syncthreads();
-  int total = 0, before = 0;
+  int total = 0;
 #pragma unroll
-  for (int w = 0; w < MW_MAX_R / 64; ++w) {
-    const int c = wcnt_s[w];
-    if (w < wave) before += c;
-    total += c;
-  }
-  if (t < MW_MAX_R && f) {
-    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pos < MW_MAX_K) rows_s[pos] = t;
+  for (int w = 0; w < MW_MAX_R / 64; ++w) total += wcnt_s[w];
+  for (int i = t; i < MW_MAX_R; i += blockDim.x) {
+    const int f = flag_s[i];
+    const unsigned long long bal = __ballot(f != 0);
+    if (f) {
+      int before = 0;
+      for (int w = 0; w < (i >> 6); ++w) before += wcnt_s[w];
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < MW_MAX_K) rows_s[pos] = i;
+    }
   }
   __syncthreads();
   return total < MW_MAX_K ? total : MW_MAX_K;
@@ -185,32 +186,8 @@ __global__ __launch_bounds__(512) void mw_unique_rows_kernel(const int* __restri
   if (threadIdx.x == 0) *k_u = n;
 }
 
-// mask test of one instance at pixel centre (x+0.5, y+0.5): same arithmetic as paste_masks_kernel
-__device__ __forceinline__ bool mask_hit(const float* __restrict__ m, float x0, float y0, float x1, float y1, int x, int y, float thr) {
-  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
-  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
-  const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-  const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
-  if (!(ix > -1.0f && ix < 28.0f && iy > -1.0f && iy < 28.0f)) return false;
-  const float fx = floorf(ix), fy = floorf(iy);
-  const int xw = (int)fx, yn = (int)fy;
-  const int xe = xw + 1, ys = yn + 1;
-  const float nw = ((float)xe - ix) * ((float)ys - iy);
-  const float ne = (ix - (float)xw) * ((float)ys - iy);
-  const float sw = ((float)xe - ix) * (iy - (float)yn);
-  const float se = (ix - (float)xw) * (iy - (float)yn);
-  const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u, ynv = (unsigned)yn < 28u, ysv = (unsigned)ys < 28u;
-  float v = 0.f;
-  if (xwv && ynv) v += m[yn * 28 + xw] * nw;
-  if (xev && ynv) v += m[yn * 28 + xe] * ne;
-  if (xwv && ysv) v += m[ys * 28 + xw] * sw;
-  if (xev && ysv) v += m[ys * 28 + xe] * se;
-  return v >= thr;
-}
-
 __device__ __forceinline__ int clamp_cell(int cell, int n_cells) { return cell < 0 ? 0 : (cell >= n_cells ? n_cells - 1 : cell); }
 
-#define SCAN_ELEMS 4096
 
 // The instances whose box (grown by one mask pixel: a sample further out is exactly zero) reaches the image rows of this block's
 // 4096 pixels, in instance order: cand_s[i] = index k into the unique list, box_s[i] = its box.  Returns their number.
@@ -248,9 +225,9 @@ __device__ __forceinline__ int block_band_candidates(const float* __restrict__ b
   return *ncand_s;
 }
 
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
-  __shared__ int wsum[16];
-  __shared__ int wtot;
+// exclusive scan over the 256 threads of a workgroup (4 waves)
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
+  __shared__ int wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -260,27 +237,66 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   }
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int i = 0; i < 16; ++i) {
-      const int t = wsum[i];
-      wsum[i] = run;
-      run += t;
-    }
-    wtot = run;
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int c = wsum[w];
+    if (w < wave) before += c;
+    all += c;
   }
-  __syncthreads();
-  *total = wtot;
-  return wsum[wave] + inc - v;
+  *total = all;
+  return before + inc - v;
 }
 
-// Launch 1.  Block = 1024 threads x 4 consecutive pixels.
-__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                         const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
-                                                         int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
-                                                         unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
-                                                         int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
-                                                         int* __restrict__ k_out, int* __restrict__ err) {
+// Mask test of one instance at pixel centre (x + 0.5, y + 0.5), the arithmetic of paste_masks_kernel (heads.hip), split into the part
+// that depends on the image row only (shared by the 4 pixels of a thread) and the per-pixel part
+struct RowSample {
+  bool ok;
+  int yn, ys;
+  float wy_n, wy_s;        // (ys - iy), (iy - yn)
+  bool ynv, ysv;
+};
+__device__ __forceinline__ RowSample row_sample(float y0, float y1, int y) {
+  RowSample r;
+  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+  const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+  r.ok = iy > -1.0f && iy < 28.0f;
+  const float fy = floorf(iy);
+  r.yn = (int)fy;
+  r.ys = r.yn + 1;
+  r.wy_n = (float)r.ys - iy;
+  r.wy_s = iy - (float)r.yn;
+  r.ynv = (unsigned)r.yn < 28u;
+  r.ysv = (unsigned)r.ys < 28u;
+  return r;
+}
+__device__ __forceinline__ bool mask_hit_row(const float* __restrict__ m, const RowSample& r, float x0, float x1, int x, float thr) {
+  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+  if (!(ix > -1.0f && ix < 28.0f && r.ok)) return false;
+  const float fx = floorf(ix);
+  const int xw = (int)fx;
+  const int xe = xw + 1;
+  const float nw = ((float)xe - ix) * r.wy_n;
+  const float ne = (ix - (float)xw) * r.wy_n;
+  const float sw = ((float)xe - ix) * r.wy_s;
+  const float se = (ix - (float)xw) * r.wy_s;
+  const bool xwv = (unsigned)xw < 28u, xev = (unsigned)xe < 28u;
+  float v = 0.f;
+  if (xwv && r.ynv) v += m[r.yn * 28 + xw] * nw;
+  if (xev && r.ynv) v += m[r.yn * 28 + xe] * ne;
+  if (xwv && r.ysv) v += m[r.ys * 28 + xw] * sw;
+  if (xev && r.ysv) v += m[r.ys * 28 + xe] * se;
+  return v >= thr;
+}
+
+// Launch 1.  Block = 256 threads x 4 consecutive pixels of one image row (W % 4 == 0).
+__global__ __launch_bounds__(256) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                        const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
+                                                        int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
+                                                        unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
+                                                        int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
+                                                        int* __restrict__ k_out, int* __restrict__ err) {
   EOD_CHAIN_PRIO();
   __shared__ int flag_s[MW_MAX_R], wcnt_s[8], rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s;
   __shared__ float box_s[MW_MAX_K * 4];
@@ -299,36 +315,40 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict_
   bool bad = false;
   int observed = 0;
   unsigned pk = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = base + j;
-    if (p >= P) break;
-    const int y = p / W, x = p - y * W;
-    const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
-    int cnt = 0;
+  if (base < P) {
+    const int y = base / W, xb = base - y * W;
+    const float fyp = (float)y + 0.5f;
+    int cnt[4] = {0, 0, 0, 0};
     for (int i = 0; i < nc; ++i) {
       const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
       // quick reject: a sample more than one mask pixel outside the box is zero
       const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
-      if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
-      if (mask_hit(masks + (size_t)rows_s[cand_s[i]] * 784, x0, y0, x1, y1, x, y, thr)) ++cnt;
+      if (fyp < y0 - my || fyp > y1 + my) continue;
+      if ((float)xb + 3.5f < x0 - mx || (float)xb + 0.5f > x1 + mx) continue;
+      const RowSample rs = row_sample(y0, y1, y);
+      const float* m = masks + (size_t)rows_s[cand_s[i]] * 784;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float fxp = (float)(xb + j) + 0.5f;
+        if (fxp < x0 - mx || fxp > x1 + mx) continue;
+        cnt[j] += mask_hit_row(m, rs, x0, x1, xb + j, thr) ? 1 : 0;
+      }
     }
-    pk |= (unsigned)(cnt & 0xFF) << (8 * j);
-    observed += cnt > 0;
-    int cell = proj[p];
-    if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
-      bad = true;
-      cell = cell < 0 ? 0 : n_cells - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pk |= (unsigned)(cnt[j] & 0xFF) << (8 * j);
+      observed += cnt[j] > 0;
+      int cell = proj[base + j];
+      if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
+        bad = true;
+        cell = cell < 0 ? 0 : n_cells - 1;
+      }
+      cell_flag[cell] = 1;
     }
-    cell_flag[cell] = 1;
-  }
-  if (base + 3 < P) {
-    *reinterpret_cast<unsigned*>(cover + base) = pk;              // P % 4 == 0 on this path (H, W multiples of 32)
-  } else {
-    for (int j = 0; j < 4 && base + j < P; ++j) cover[base + j] = (unsigned char)((pk >> (8 * j)) & 0xFF);
+    *reinterpret_cast<unsigned*>(cover + base) = pk;              // P % 4 == 0 (H, W multiples of 32)
   }
   int total;
-  block_exclusive_scan_1024(observed, &total);
+  block_exclusive_scan_256(observed, &total);
   if (threadIdx.x == 0) blk_pix[blockIdx.x] = total;
   if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
 }
@@ -337,46 +357,51 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict_
 //   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
 // so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
 // bitwise reproducible) instead of 512 channel atomics.
-__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                           const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
-                                                           const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
-                                                           long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
+__global__ __launch_bounds__(256) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                          const int* __restrict__ inst_rows, const int* __restrict__ k_u,
+                                                          const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
+                                                          const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
+                                                          long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
   EOD_CHAIN_PRIO();
   const int K = *k_u;
   if (K == 0) return;
   __shared__ int rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s, sh_off;
   __shared__ float box_s[MW_MAX_K * 4];
   const int P = H * W;
-  for (int i = threadIdx.x; i < K; i += blockDim.x) rows_s[i] = inst_rows[i];
-  if (threadIdx.x >= 64 && threadIdx.x < 128) {       // second wave: observed pixels in the blocks before this one
-    int s = 0;
-    for (int b = threadIdx.x - 64; b < (int)blockIdx.x; b += 64) s += blk_pix[b];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 64) sh_off = s;
-  }
-  __syncthreads();
-  const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
   const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
   unsigned pk = 0;
-  if (base + 3 < P) {
-    pk = *reinterpret_cast<const unsigned*>(cover + base);
-  } else {
-    for (int j = 0; j < 4 && base + j < P; ++j) pk |= (unsigned)cover[base + j] << (8 * j);
-  }
+  if (base < P) pk = *reinterpret_cast<const unsigned*>(cover + base);
   int c = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) c += ((pk >> (8 * j)) & 0xFF) != 0;
   int total;
-  int rank = block_exclusive_scan_1024(c, &total) + sh_off;
+  const int local = block_exclusive_scan_256(c, &total);
+  if (total == 0) return;                                    // no observed pixel in this block (block-uniform)
+  // observed pixels in the blocks before this one (one wave; its barrier follows)
+  if (threadIdx.x < 64) {
+    int sum = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) sum += blk_pix[b];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (threadIdx.x == 0) sh_off = sum;
+  }
+  for (int i = threadIdx.x; i < K; i += blockDim.x) rows_s[i] = inst_rows[i];
+  __syncthreads();
+  // does any pixel of this block get sampled?  ranks sh_off .. sh_off + total - 1 contain a multiple of 8?
+  const int first = sh_off;
+  if (((first + 7) & ~7) >= first + total) return;           // block-uniform
+  const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
+  int rank = first + local;
+  if (c == 0) return;
+  const int y = base / W, xb = base - y * W;
+  const float fyp = (float)y + 0.5f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int cv = (int)((pk >> (8 * j)) & 0xFF);
     if (cv == 0) continue;
     if ((rank & 7) == 0) {                           // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
       const int p = base + j;
-      const int y = p / W, x = p - y * W;
-      const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+      const int x = xb + j;
+      const float fxp = (float)x + 0.5f;
       const int cell = clamp_cell(proj[p], n_cells);
       const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)cv);
       long long* dst = wtab + (size_t)cell * K_cap;
@@ -385,7 +410,8 @@ __global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restric
         const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
         const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
         if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
-        if (mask_hit(masks + (size_t)rows_s[cand_s[i]] * 784, x0, y0, x1, y1, x, y, thr))
+        const RowSample rs = row_sample(y0, y1, y);
+        if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr))
           atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
       }
     }
@@ -561,10 +587,10 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
   const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS;
-  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
+  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(256), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
                      d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, w.blk_pix, w.inst_rows, w.k_u, d->k_out,
                      d->err_flags);
-  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
+  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
                      d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt);
   int groups = (d->n_cells + 63) / 64;
   if (groups > 4096) groups = 4096;

@@ -48,6 +48,21 @@ def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
     return _SCHED_STREAMS[idx]
 
 
+_DET_STREAMS: Dict[Tuple[int, int], torch.cuda.Stream] = {}
+
+
+def _det_stream(device: torch.device, priority: int) -> torch.cuda.Stream:
+    """The detection-pass stream, also ONE per device and process.  A stream per model instance made the frame rate of otherwise
+    identical models bimodal (270 or 200-220 frames/s at 640x640, tools/knob_ab.py): the runtime hands hardware queues out round
+    robin (GPU_MAX_HW_QUEUES), and a later model's stream could land on the queue of one of the chain streams, which serialises
+    the detection pass with that chain."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, int(priority))
+    if key not in _DET_STREAMS:
+        _DET_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(priority))
+    return _DET_STREAMS[key]
+
+
 @META_ARCH_REGISTRY.register()
 class CustomRCNNRecurrent:
     def __init__(self, cfg, state_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -620,7 +635,7 @@ class CustomRCNNRecurrent:
         frame on the detection stream (lowest priority: its GEMMs fill whatever the latency-bound chains of the frame -- and of
         the next frame -- leave idle)."""
         if self._det_stream is None:
-            self._det_stream = torch.cuda.Stream(device=self.device, priority=int(self.det_stream_priority))
+            self._det_stream = _det_stream(self.device, self.det_stream_priority)
             self._ev_det = [torch.cuda.Event() for _ in range(RESULT_SETS)]
         ds = self._det_stream
         det_boxes, det_scores, det_classes, det_rows, det_count = det

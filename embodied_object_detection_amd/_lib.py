@@ -33,7 +33,8 @@ class EodConvDesc(C.Structure):
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
         ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
-        ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32),
+        ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32), ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
+        ("y2", C.c_void_p), ("split_n", C.c_int32),
     ]
 
 
@@ -73,6 +74,8 @@ SIGNATURES = {
     "eod_abi_version": (C.c_int, []),
     "eod_conv2d": (C.c_int, [C.POINTER(EodConvDesc), C.c_void_p]),
     "eod_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(EodConvDesc)]),
+    "eod_conv2d_gn_fused": (C.c_int, [C.POINTER(EodConvDesc)]),
+    "eod_groupnorm_partial_offset": (C.c_size_t, [C.c_int, C.c_int]),
     "eod_set_conv_math": (C.c_int, [C.c_int]),
     "eod_get_conv_math": (C.c_int, []),
     "eod_conv_split_weights_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -82,7 +85,7 @@ SIGNATURES = {
     "eod_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "eod_groupnorm_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "eod_groupnorm_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int,
-                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+                                     C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "eod_roi_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

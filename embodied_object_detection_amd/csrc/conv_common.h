@@ -30,10 +30,14 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
   const void* w3;              // optional pre-split weights of the bf16x3 kernels (eod_conv_split_weights_bf16x3)
   unsigned w3_bytes;
+  double* gn_partial;          // optional (pyramid mode + split-K): GroupNorm partial sums written by the slab reduce (EodConvDesc)
+  int gn_groups;
+  float* y2;                   // optional second output: columns [split_n, Cout) go to y2 [M, Cout - split_n] (with the ReLU), columns
+  int split_n;                 // [0, split_n) to y [M, split_n] (never with the ReLU): two linear layers on one input as one GEMM
   FastDiv div_ow, div_oh, div_cd, div_row;
 };
 
-__device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m, int n) {
+__device__ __forceinline__ float epilogue_store(const ConvArgs& p, float v, int m, int n) {
   int co = n;
   size_t oidx;
   if (p.out_mode == 1) {
@@ -61,8 +65,18 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, float v, int m
     const int rh = p.OH >> 1, rw = p.OW >> 1;
     v += p.res[((size_t)(img * rh + (oy >> 1)) * rw + (ox >> 1)) * p.Cout + n];
   }
+  if (p.split_n > 0) {
+    if (n >= p.split_n) {
+      if (p.relu) v = fmaxf(v, 0.0f);
+      p.y2[(size_t)m * (p.Cout - p.split_n) + (n - p.split_n)] = v;
+    } else {
+      p.y[(size_t)m * p.split_n + n] = v;
+    }
+    return v;
+  }
   if (p.relu) v = fmaxf(v, 0.0f);
   p.y[oidx] = v;
+  return v;
 }
 
 // Bit tp = ky * KW + kx is set when tap (ky, kx) of the window anchored at (iy0, ix0) falls inside an hh x ww image.

@@ -377,7 +377,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
-  f32x4 ar[AR], br[AR];
+  // two operand sets in registers: while chunk c is multiplied, chunks c+1 and c+2 are in flight (a wave walks its K share alone:
+  // with 1-2 waves per SIMD the global-load latency is hidden by prefetch depth, not by occupancy)
+  f32x4 ar0[AR], br0[AR], ar1[AR], br1[AR];
   int nx_tap, nx_c0, nx_ky, nx_kx;
   {
     const int k0 = c_begin * BK;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
     nx_ky = nx_tap / p.KW;
     nx_kx = nx_tap - nx_ky * p.KW;
   }
-  auto load_chunk = [&](int chunk) {
+  auto load_chunk = [&](int chunk, f32x4 (&ar)[AR], f32x4 (&br)[AR]) {
     const int k0 = chunk * BK;
     const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
     nx_c0 += BK;
@@ -432,18 +434,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
   const float* a_base = As + frag_row * LS + frag_k;
   const float* b_base = Bs + frag_row * LS + frag_k;
 
-  if (c_begin < c_end) load_chunk(c_begin);
-  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+  // wave-private staging: the wave's own LDS writes are ordered before its reads by the waitcnt the compiler inserts; the fences
+  // keep the compiler from moving accesses across the hand-over
+  auto stage_and_multiply = [&](f32x4 (&ar)[AR], f32x4 (&br)[AR], int next_chunk) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + 8 * i) * LS + 4 * lq) = ar[i];
 #pragma unroll
     for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + 8 * j) * LS + 4 * lq) = br[j];
-    // wave-private staging: the wave's own LDS writes are ordered before its reads by the waitcnt the compiler inserts; the
-    // fence keeps the compiler from moving the reads above the writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+    if (next_chunk < c_end) load_chunk(next_chunk, ar, br);       // this set's registers are free again: two chunks ahead
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       const f32x4 af = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
@@ -456,6 +457,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  if (c_begin < c_end) load_chunk(c_begin, ar0, br0);
+  if (c_begin + 1 < c_end) load_chunk(c_begin + 1, ar1, br1);
+  for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+    stage_and_multiply(ar0, br0, chunk + 2);
+    if (chunk + 1 < c_end) stage_and_multiply(ar1, br1, chunk + 3);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc_b[r];

@@ -47,6 +47,48 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
+// The slab reduce of a pyramid-mode layer that is followed by GroupNorm (CenterNet tower, centernet_head.py:76-79): the same sums
+// in slab order + epilogue, organised like eod_groupnorm_relu's statistics pass -- one workgroup per 32-row chunk of one level,
+// thread = channel, double accumulation of sum / sum of squares over the chunk's rows in row order, shuffle reduce to the group
+// -> partial[chunk][group][2] -- so that the statistics launch is not needed (bitwise the partial sums it would write).
+#define EOD_GN_ROWS 32
+__global__ __launch_bounds__(256) void conv_splitk_reduce_gn_kernel(ConvArgs p) {
+  EOD_CHAIN_PRIO();
+  int level = 0, first_chunk = 0;
+  for (;;) {
+    const int rows = p.lv_off[level + 1] - p.lv_off[level];
+    const int nch = (rows + EOD_GN_ROWS - 1) / EOD_GN_ROWS;
+    if ((int)blockIdx.x < first_chunk + nch || level + 1 >= p.nlv) break;
+    first_chunk += nch;
+    ++level;
+  }
+  const int r0 = p.lv_off[level] + ((int)blockIdx.x - first_chunk) * EOD_GN_ROWS;
+  const int r1 = min(r0 + EOD_GN_ROWS, p.lv_off[level + 1]);
+  const int C = p.Cout;
+  const int cpg = C / p.gn_groups;
+  const size_t slab = (size_t)p.M * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const float* src = p.partial + (size_t)r * C + c;
+      float v = 0.f;
+      for (int z = 0; z < p.splitk; ++z) v += src[z * slab];
+      const double o = (double)epilogue_store(p, v, r, c);
+      s += o;
+      q += o * o;
+    }
+    for (int off = 1; off < cpg; off <<= 1) {
+      s += __shfl_xor(s, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    if ((c % cpg) == 0) {
+      const int g = c / cpg;
+      p.gn_partial[((size_t)blockIdx.x * p.gn_groups + g) * 2 + 0] = s;
+      p.gn_partial[((size_t)blockIdx.x * p.gn_groups + g) * 2 + 1] = q;
+    }
+  }
+}
+
 inline int big_tile_env() {
   static const int v = [] {
     const char* e = getenv("EOD_CONV_BIG_TILE");
@@ -220,6 +262,18 @@ int check_desc(const EodConvDesc* d) {
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
   if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;
+  if (d->split_n != 0) {
+    if (!d->y2) return EOD_ERR_NULL;
+    if (d->split_n < 0 || d->split_n >= d->Cout || d->out_mode != 0 || d->res_mode != 0 || d->levels > 0 || d->gn_partial)
+      return EOD_ERR_BAD_DIMS;
+  }
+  if (d->gn_partial) {
+    // statistics for a following GroupNorm: pyramid mode, static row count, plain epilogue, channel groups of a power of two <= 64
+    const int cpg = d->gn_groups > 0 ? d->Cout / d->gn_groups : 0;
+    if (d->levels <= 0 || d->m_count || d->out_mode != 0 || d->gn_groups <= 0 || d->Cout % d->gn_groups != 0 || cpg > 64 ||
+        (cpg & (cpg - 1)) != 0 || 256 % cpg != 0 || d->Cout % 4 != 0)
+      return EOD_ERR_BAD_DIMS;
+  }
   if (!eod_aligned16(d->x) || !eod_aligned16(d->w) || !eod_aligned16(d->w_split)) return EOD_ERR_ALIGN;
   return EOD_OK;
 }
@@ -243,6 +297,13 @@ extern "C" int eod_conv_split_weights_bf16x3(const float* w, int Cout, int Kpad,
   if (!eod_aligned16(w) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
   launch_split_weights(w, out, Cout, Kpad, static_cast<hipStream_t>(stream));
   return eod_launch_status();
+}
+
+extern "C" int eod_conv2d_gn_fused(const EodConvDesc* d) {
+  EodConvDesc t = *d;
+  t.gn_partial = nullptr;
+  if (check_desc(&t) != EOD_OK) return 0;
+  return make_plan(&t, total_rows(&t), t.Kpad / 32).splitk > 1 ? 1 : 0;
 }
 
 extern "C" size_t eod_conv2d_workspace_bytes(const EodConvDesc* d) {
@@ -286,7 +347,12 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   if (a.nlv) a.lv_off[a.nlv] = d->level_off[a.nlv];
   a.relu = d->relu; a.res_mode = d->res_mode; a.in_relu = d->in_relu; a.out_mode = d->out_mode;
   a.out_scale = d->out_scale;
+  a.gn_partial = d->gn_partial;
+  a.gn_groups = d->gn_groups;
+  a.y2 = d->y2;
+  a.split_n = d->split_n;
   const Plan pl = make_plan(d, a.M, d->Kpad / 32);
+  if (d->gn_partial && pl.splitk <= 1) return EOD_ERR_BAD_DIMS;      // the statistics ride on the slab reduce (see eod_conv2d_gn_fused)
   a.nchunks = pl.nchunks;
   a.splitk = pl.splitk; a.cps = pl.cps; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   if (pl.splitk > 1) {
@@ -303,7 +369,11 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
     int blocks = (int)((total / (vec ? 4 : 1) + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (vec) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    if (a.gn_partial) {
+      int chunks = 0;
+      for (int l = 0; l < a.nlv; ++l) chunks += (a.lv_off[l + 1] - a.lv_off[l] + EOD_GN_ROWS - 1) / EOD_GN_ROWS;
+      hipLaunchKernelGGL(conv_splitk_reduce_gn_kernel, dim3(chunks), dim3(256), 0, s, a);
+    } else if (vec) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
   }
   return eod_launch_status();

@@ -294,8 +294,12 @@ extern "C" size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, i
   return ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8 + chunks * groups * 2 * sizeof(double);
 }
 
+extern "C" size_t eod_groupnorm_partial_offset(int levels, int groups) {
+  return ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8;
+}
+
 extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
-                                  int levels, int C, int groups, float eps, float* stats, eod_stream_t stream) {
+                                  int levels, int C, int groups, float eps, float* stats, int partial_ready, eod_stream_t stream) {
   if (!x || !y || !gamma || !beta || !level_off_host || !stats) return EOD_ERR_NULL;
   if (levels < 1 || levels > 8 || C % groups != 0 || C % 4 != 0 || (C / groups) % 4 != 0) return EOD_ERR_BAD_DIMS;
   LevelOff lo{};
@@ -309,7 +313,8 @@ extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, 
   double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8);
   const int cpg = C / groups;
   if (cpg > 64 || (cpg & (cpg - 1)) != 0 || 256 % cpg != 0) return EOD_ERR_BAD_DIMS;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, partial);
+  if (!partial_ready)
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, lo, C, groups, partial);
   if (groups <= 64) {
     hipLaunchKernelGGL(gn_finalize_apply_relu_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, lo, C, groups,
                        eps, partial);

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 //   mw_commit_kernel   per hit cell: mean of the per-pixel means from the weight table (f64, instance order), accumulate into the
 //                      memory, observation counter, fp16 snapshot row (or dirty mark); leaves every per-frame table zero again
 // ------------------------------------------------------------------------------------------------------
-#define SCAN_ELEMS 1024        // pixels per workgroup of the two pixel passes: 256 threads x 4 consecutive pixels of one image row
+#define SCAN_ELEMS 1024        // pixels per workgroup of the two pixel passes: one pixel per thread (the mask gathers of a pixel are a
+                               // dependent chain: occupancy, not instruction count, is what hides it)
 
 struct MwWs {
   int* inst_rows;   // [R_cap] unique proposal rows, ascending
@@ -225,9 +226,9 @@ __device__ __forceinline__ int block_band_candidates(const float* __restrict__ b
   return *ncand_s;
 }
 
-// exclusive scan over the 256 threads of a workgroup (4 waves)
-__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
-  __shared__ int wsum[4];
+// exclusive scan over the 1024 threads of a workgroup (16 waves)
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
+  __shared__ int wsum[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -239,7 +240,7 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
   __syncthreads();
   int before = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < 16; ++w) {
     const int c = wsum[w];
     if (w < wave) before += c;
     all += c;
@@ -249,7 +250,7 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
 }
 
 // Mask test of one instance at pixel centre (x + 0.5, y + 0.5), the arithmetic of paste_masks_kernel (heads.hip), split into the part
-// that depends on the image row only (shared by the 4 pixels of a thread) and the per-pixel part
+// that depends on the image row only and the per-pixel part
 struct RowSample {
   bool ok;
   int yn, ys;
@@ -290,13 +291,13 @@ __device__ __forceinline__ bool mask_hit_row(const float* __restrict__ m, const 
   return v >= thr;
 }
 
-// Launch 1.  Block = 256 threads x 4 consecutive pixels of one image row (W % 4 == 0).
-__global__ __launch_bounds__(256) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                        const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
-                                                        int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
-                                                        unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
-                                                        int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
-                                                        int* __restrict__ k_out, int* __restrict__ err) {
+// Launch 1.  Block = 1024 threads = 1024 consecutive pixels.
+__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                         const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
+                                                         int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
+                                                         unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
+                                                         int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
+                                                         int* __restrict__ k_out, int* __restrict__ err) {
   EOD_CHAIN_PRIO();
   __shared__ int flag_s[MW_MAX_R], wcnt_s[8], rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s;
   __shared__ float box_s[MW_MAX_K * 4];
@@ -311,44 +312,30 @@ __global__ __launch_bounds__(256) void mw_cover_kernel(const float* __restrict__
   if (K == 0) return;                      // update_implicit_memory returns before touching the state (custom_rcnn.py:689-690)
   const int P = H * W;
   const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
-  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+  const int p = blockIdx.x * SCAN_ELEMS + threadIdx.x;
   bool bad = false;
-  int observed = 0;
-  unsigned pk = 0;
-  if (base < P) {
-    const int y = base / W, xb = base - y * W;
-    const float fyp = (float)y + 0.5f;
-    int cnt[4] = {0, 0, 0, 0};
+  int cnt = 0;
+  if (p < P) {
+    const int y = p / W, x = p - y * W;
+    const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
     for (int i = 0; i < nc; ++i) {
       const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
       // quick reject: a sample more than one mask pixel outside the box is zero
       const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
-      if (fyp < y0 - my || fyp > y1 + my) continue;
-      if ((float)xb + 3.5f < x0 - mx || (float)xb + 0.5f > x1 + mx) continue;
+      if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
       const RowSample rs = row_sample(y0, y1, y);
-      const float* m = masks + (size_t)rows_s[cand_s[i]] * 784;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float fxp = (float)(xb + j) + 0.5f;
-        if (fxp < x0 - mx || fxp > x1 + mx) continue;
-        cnt[j] += mask_hit_row(m, rs, x0, x1, xb + j, thr) ? 1 : 0;
-      }
+      cnt += mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr) ? 1 : 0;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pk |= (unsigned)(cnt[j] & 0xFF) << (8 * j);
-      observed += cnt[j] > 0;
-      int cell = proj[base + j];
-      if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
-        bad = true;
-        cell = cell < 0 ? 0 : n_cells - 1;
-      }
-      cell_flag[cell] = 1;
+    cover[p] = (unsigned char)cnt;
+    int cell = proj[p];
+    if ((unsigned)cell >= (unsigned)n_cells) {      // an index image written for another map size: clamp and flag, never fault
+      bad = true;
+      cell = cell < 0 ? 0 : n_cells - 1;
     }
-    *reinterpret_cast<unsigned*>(cover + base) = pk;              // P % 4 == 0 (H, W multiples of 32)
+    cell_flag[cell] = 1;
   }
   int total;
-  block_exclusive_scan_256(observed, &total);
+  block_exclusive_scan_1024(cnt > 0 ? 1 : 0, &total);
   if (threadIdx.x == 0) blk_pix[blockIdx.x] = total;
   if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
 }
@@ -357,25 +344,21 @@ __global__ __launch_bounds__(256) void mw_cover_kernel(const float* __restrict__
 //   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
 // so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
 // bitwise reproducible) instead of 512 channel atomics.
-__global__ __launch_bounds__(256) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                          const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                          const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
-                                                          const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
-                                                          long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
+__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
+                                                           const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
+                                                           const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
+                                                           long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
   EOD_CHAIN_PRIO();
   const int K = *k_u;
   if (K == 0) return;
   __shared__ int rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s, sh_off;
   __shared__ float box_s[MW_MAX_K * 4];
   const int P = H * W;
-  const int base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-  unsigned pk = 0;
-  if (base < P) pk = *reinterpret_cast<const unsigned*>(cover + base);
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c += ((pk >> (8 * j)) & 0xFF) != 0;
+  const int p = blockIdx.x * SCAN_ELEMS + threadIdx.x;
+  const int cv = p < P ? (int)cover[p] : 0;
   int total;
-  const int local = block_exclusive_scan_256(c, &total);
+  const int local = block_exclusive_scan_1024(cv != 0 ? 1 : 0, &total);
   if (total == 0) return;                                    // no observed pixel in this block (block-uniform)
   // observed pixels in the blocks before this one (one wave; its barrier follows)
   if (threadIdx.x < 64) {
@@ -390,32 +373,21 @@ __global__ __launch_bounds__(256) void mw_scatter_kernel(const float* __restrict
   const int first = sh_off;
   if (((first + 7) & ~7) >= first + total) return;           // block-uniform
   const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
-  int rank = first + local;
-  if (c == 0) return;
-  const int y = base / W, xb = base - y * W;
-  const float fyp = (float)y + 0.5f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int cv = (int)((pk >> (8 * j)) & 0xFF);
-    if (cv == 0) continue;
-    if ((rank & 7) == 0) {                           // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
-      const int p = base + j;
-      const int x = xb + j;
-      const float fxp = (float)x + 0.5f;
-      const int cell = clamp_cell(proj[p], n_cells);
-      const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)cv);
-      long long* dst = wtab + (size_t)cell * K_cap;
-      atomicAdd(cell_cnt + cell, 1);
-      for (int i = 0; i < nc; ++i) {
-        const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
-        const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
-        if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
-        const RowSample rs = row_sample(y0, y1, y);
-        if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr))
-          atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
-      }
-    }
-    ++rank;
+  const int rank = first + local;
+  if (cv == 0 || (rank & 7) != 0) return;                    // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
+  const int y = p / W, x = p - y * W;
+  const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+  const int cell = clamp_cell(proj[p], n_cells);
+  const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)cv);
+  long long* dst = wtab + (size_t)cell * K_cap;
+  atomicAdd(cell_cnt + cell, 1);
+  for (int i = 0; i < nc; ++i) {
+    const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
+    const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
+    if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
+    const RowSample rs = row_sample(y0, y1, y);
+    if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr))
+      atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
   }
 }
 
@@ -587,10 +559,10 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
   const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS;
-  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(256), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
+  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
                      d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, w.blk_pix, w.inst_rows, w.k_u, d->k_out,
                      d->err_flags);
-  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(256), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
+  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
                      d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt);
   int groups = (d->n_cells + 63) / 64;
   if (groups > 4096) groups = 4096;

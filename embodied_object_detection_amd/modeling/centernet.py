@@ -59,17 +59,18 @@ class CenterNet:
             self._plans[key] = (a, b, head, dec, ops.groupnorm_workspace(off, self.device))
         return self._plans[key]
 
-    def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int):
+    def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int, gn_stats=None):
         # one launch over the whole pyramid (weights are shared across levels, centernet_head.py:144-160)
-        conv(src, 1, 0, 0, out=dst, levels=(off, shapes))
+        conv(src, 1, 0, 0, out=dst, levels=(off, shapes), gn_stats=gn_stats)
 
     def forward(self, feats: torch.Tensor, shapes, off):
         """feats [P_total,256] -> (boxes [cap,4], scores [cap], count [1]) device buffers, sorted by score."""
         a, b, head, dec, gn_ws = self._plan(shapes, off)
         src = feats
         for (conv, gamma, beta) in self.tower:
-            self._per_level(conv, src, a, shapes, off, 256)
-            ops.groupnorm_relu(a, gamma, beta, off, 256, gn_ws, out=b)   # stream order: `a` is free again
+            # the conv's slab reduce also writes GroupNorm's partial sums (one launch less per tower layer)
+            self._per_level(conv, src, a, shapes, off, 256, gn_stats=gn_ws)
+            ops.groupnorm_relu(a, gamma, beta, off, 256, gn_ws, out=b, partial_ready=conv.gn_fused)   # stream order: `a` is free again
             src = b
         self._per_level(self.out_conv, src, head, shapes, off, 5)
         return dec(head)

@@ -59,7 +59,7 @@ def _det_stream(device: torch.device, priority: int) -> torch.cuda.Stream:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, int(priority))
     if key not in _DET_STREAMS:
-        _DET_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(priority))
+        _DET_STREAMS[key] = torch.cuda.Stream(device=device, priority=0 if int(priority) >= 0 else -1)
     return _DET_STREAMS[key]
 
 
@@ -134,6 +134,7 @@ class CustomRCNNRecurrent:
         # may the detection pass of frame t still run when frame t+1 starts?  (False: the frame's chain joins it at the end of the frame)
         self.trail_detection_pass = True
         self.det_stream_priority = 0         # 0 = normal, -1 = high (like the chains)
+        self.trunk_stream_priority = -1      # -1 = high (default), 0 = a normal-priority stream of its own
         # Memory selection right after cascade stage 0 on its own stream (it needs only the stage-0 features) instead of after the
         # cascade.  Measured (tools/frame_schedule.py, same box): True lets the proposal-mask pass and the memory write finish
         # early, the next frame then starts while the detection pass still runs and its latency-bound chain is slowed 3x by the
@@ -375,7 +376,7 @@ class CustomRCNNRecurrent:
         if self._trunk_stream is None:
             # high priority like the side stream: its ~75 launches are small and must not queue behind the mask GEMMs' thousands
             # of workgroups
-            self._trunk_stream = _sched_streams(self.device)[1]
+            self._trunk_stream = _sched_streams(self.device)[1] if self.trunk_stream_priority < 0 else _det_stream(self.device, 1000)
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
         ts.wait_event(after)

@@ -57,6 +57,11 @@ class DeticCascadeROIHeads:
                              name=f"box_predictor.{k}.bbox_pred.2"),
                 zs=sd[f"{p}.cls_score.zs_weight"].contiguous().to(device),
             )
+            # cls_score.linear (1024 -> 512, no ReLU) and bbox_pred.0 (1024 -> 1024, ReLU) read the same fc2 output: one GEMM with
+            # the weights stacked, two outputs (EodConvDesc.split_n); each output column walks K as in the separate call
+            st["cls_bb0"] = ops.Conv(torch.cat([sd[f"{p}.cls_score.linear.weight"], sd[f"{p}.bbox_pred.0.weight"]], dim=0)[:, :, None, None],
+                                     torch.cat([sd[f"{p}.cls_score.linear.bias"], sd[f"{p}.bbox_pred.0.bias"]], dim=0), device=device,
+                                     name=f"box_predictor.{k}.cls_score.linear+bbox_pred.0")
             assert st["zs"].shape[1] == self.C1, (st["zs"].shape, self.C1)
             self.stages.append(st)
         m = "roi_heads.mask_head"
@@ -88,6 +93,7 @@ class DeticCascadeROIHeads:
         # deconv + ReLU + predictor + sigmoid in ONE launch (the [rois,28,28,256] activation never goes to memory); False keeps
         # the two-launch form (used by the tests as the cross-check)
         self.fuse_mask_tail = True
+        self.merge_cls_bb0 = True     # False: the two linear layers as two launches (tests: bitwise the same results)
         # three detection-list sets: the detection mask pass of frame t may still read set t % 3 while the cascades of the next
         # frames write the others (meta_arch.py, pipeline_detection_pass / RESULT_SETS)
         # LDS reserve of the DETECTION mask pass's launches (the pass that trails under the frame's / the next frame's latency-bound
@@ -112,7 +118,10 @@ class DeticCascadeROIHeads:
             st["fc1"](self.pool7, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h1)
             st["fc2"](self.h1, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h2)
             feat = self.feat0 if k == 0 else self.feat
-            st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
+            if self.merge_cls_bb0:
+                st["cls_bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=feat, split=(512, self.hb))
+            else:
+                st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
             last = k == self.num_stages - 1
             # the last stage's launch also fuses the cascade's scores: sqrt(mean_k(prob) * proposal score) (detic_roi_heads.py:164-173)
             ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp,
@@ -122,7 +131,8 @@ class DeticCascadeROIHeads:
                             final_inv_stages=1.0 / self.num_stages if last else 0.0)
             if k == 0 and stage0_event is not None:
                 stage0_event.record(torch.cuda.current_stream(self.device))
-            st["bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.hb)
+            if not self.merge_cls_bb0:
+                st["bb0"](self.h2, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.hb)
             st["bb2"](self.hb, R, 1, 1, m_count=count, m_unit=1, out=self.deltas)
             # next-stage proposals are clipped to the image (detic_roi_heads.py:314); the final boxes are clipped by
             # fast_rcnn_inference itself

@@ -138,8 +138,13 @@ class Conv:
                  m_unit: int = 0, out: Optional[torch.Tensor] = None, force_tile: int = 0, force_splitk: int = 0,
                  levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
                  fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True,
-                 plan_rows: int = 0) -> torch.Tensor:
+                 plan_rows: int = 0, gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 32,
+                 split: Optional[Tuple[int, torch.Tensor]] = None) -> torch.Tensor:
         """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
+        `split=(n0, out2)`: the layer is two stacked linear layers; columns [0, n0) go to `out` [rows, n0] without the ReLU, columns
+        [n0, Cout) to `out2` [rows, Cout - n0] with it (EodConvDesc.split_n).
+        `gn_stats` (pyramid mode; the workspace of the `groupnorm_relu` call that follows): when the layer's plan reduces split-K
+        slabs, that reduce also writes GroupNorm's partial sums into it and `self.gn_fused` is set (pass it as `partial_ready`).
         `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
         in one launch, `out` = [units, 2H, 2W] probabilities (out_mode 2 of include/eod_hip.h)."""
         _need_cuda(x, res, out)
@@ -168,6 +173,13 @@ class Conv:
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
         d.plan_rows = plan_rows
         d.lds_reserve = self.lds_reserve
+        d.gn_partial, d.gn_groups = None, 0
+        self.gn_fused = False
+        if split is not None:
+            _need_cuda(split[1])
+            d.split_n, d.y2 = int(split[0]), split[1].data_ptr()
+        else:
+            d.split_n, d.y2 = 0, None
         if levels is not None:
             off, shapes = levels
             d.levels = len(shapes)
@@ -184,6 +196,10 @@ class Conv:
             check(self._lib.eod_conv_split_weights_bf16x3(self.w.data_ptr(), self.Cout, self.Kpad, self.w_split.data_ptr(), _stream()),
                   f"eod_conv_split_weights_bf16x3[{self.name}]")
         d.w_split = self.w_split.data_ptr() if (use_split and self.w_split is not None and presplit) else None
+        if gn_stats is not None and levels is not None and self._lib.eod_conv2d_gn_fused(C.byref(d)):
+            d.gn_partial = gn_stats.data_ptr() + self._lib.eod_groupnorm_partial_offset(len(levels[1]), gn_groups)
+            d.gn_groups = gn_groups
+            self.gn_fused = True
         d.workspace, d.workspace_bytes = None, 0
         need = self._lib.eod_conv2d_workspace_bytes(C.byref(d))
         if need:
@@ -230,12 +246,14 @@ def groupnorm_workspace(level_off: Sequence[int], device, groups: int = 32) -> t
 
 
 def groupnorm_relu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, level_off: Sequence[int], Cc: int,
-                   stats: torch.Tensor, groups: int = 32, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   stats: torch.Tensor, groups: int = 32, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
+                   partial_ready: bool = False) -> torch.Tensor:
+    """`partial_ready`: the conv that produced `x` already wrote the partial sums into `stats` (Conv(..., gn_stats=stats))."""
     if out is None:
         out = torch.empty_like(x)
     lo = (C.c_int32 * len(level_off))(*level_off)
     check(_lib.load().eod_groupnorm_relu(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), lo, len(level_off) - 1,
-                                         Cc, groups, eps, stats.data_ptr(), _stream()), "eod_groupnorm_relu")
+                                         Cc, groups, eps, stats.data_ptr(), int(partial_ready), _stream()), "eod_groupnorm_relu")
     return out
 
 

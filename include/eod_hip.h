@@ -89,8 +89,21 @@ typedef struct EodConvDesc {
    * registers and LDS on every CU for the small latency-bound kernels other streams launch meanwhile: a grid of thousands of
    * ~150 us workgroups that fills every slot makes a concurrent one-workgroup kernel wait for a slot for ~100 us. */
   int32_t lds_reserve;
+  /* optional: the layer is followed by GroupNorm (CenterNet tower, centernet_head.py:76-79).  When the layer's plan splits K into
+   * slabs (eod_conv2d_gn_fused(d) == 1), the slab reduce also writes the partial sums eod_groupnorm_relu's statistics launch would
+   * write (same chunks, same order: bitwise), into the partial-sum area of that call's `stats` workspace
+   * (eod_groupnorm_partial_offset); eod_groupnorm_relu is then called with partial_ready = 1.  Pyramid mode only. */
+  double* gn_partial;
+  int32_t gn_groups;
+  /* optional: two linear layers that read the same input as ONE contraction (the box predictor's cls_score.linear and bbox_pred.0,
+   * detic_fast_rcnn.py:437-466): w = [w_a; w_b] stacked along Cout, bias likewise; output columns [0, split_n) go to y
+   * [rows, split_n] WITHOUT the ReLU, columns [split_n, Cout) to y2 [rows, Cout - split_n] with it (if relu).  out_mode 0,
+   * res_mode 0, no pyramid mode.  Every output column walks K exactly as in a separate call: bitwise the two layers' results. */
+  float* y2;
+  int32_t split_n;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
+int eod_conv2d_gn_fused(const EodConvDesc* d); /* 1 when this layer can carry gn_partial (its plan has a slab reduce), else 0 */
 size_t eod_conv2d_workspace_bytes(const EodConvDesc* d);
 /* Arithmetic of eod_conv2d when force_tile == 0 (process-wide, read at every call; initial value from the environment variable
  * EOD_CONV_MATH = fp32 | bf16x3):
@@ -120,7 +133,10 @@ int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int O
  * (mean/rstd per (level, group) followed by per-chunk double partial sums). */
 size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, int levels, int groups);
 int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
-                       int levels, int C, int groups, float eps, float* stats, eod_stream_t stream);
+                       int levels, int C, int groups, float eps, float* stats, int partial_ready, eod_stream_t stream);
+/* byte offset of the per-chunk partial sums inside `stats` (EodConvDesc.gn_partial points there); partial_ready = 1: the producing
+ * eod_conv2d wrote them, the statistics launch is skipped */
+size_t eod_groupnorm_partial_offset(int levels, int groups);
 /* mask predictor 1x1 conv -> 1 channel + sigmoid (d2 mask head predictor + mask_rcnn_inference,
  * custom_rcnn.py:574): x [R*784,C] -> prob [R*784] */
 int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,

@@ -246,6 +246,30 @@ def test_conv_wavek_few_rows_deep_k(dev, case):
         assert float((out[20:] - 7.0).abs().max()) == 0.0
 
 
+def test_two_linear_layers_as_one_gemm_with_split_outputs(dev):
+    """cls_score.linear (no ReLU) + bbox_pred.0 (ReLU) on the same input: one GEMM with stacked weights, two outputs
+    (EodConvDesc.split_n) -- bitwise the two separate layers, with a device-side row count."""
+    from embodied_object_detection_amd import ops
+    R, cap, K = 50, 64, 1024
+    x = rnd(cap, K, seed=81)
+    wa, ba = rnd(512, K, seed=82, scale=0.03), rnd(512, seed=83)
+    wb, bb = rnd(1024, K, seed=84, scale=0.03), rnd(1024, seed=85)
+    xd = x.view(cap, 1, 1, K).to(dev)
+    cnt = torch.tensor([R], dtype=torch.int32, device=dev)
+    ca = ops.Conv(wa[:, :, None, None], ba, device=dev)
+    cb = ops.Conv(wb[:, :, None, None], bb, device=dev)
+    cm = ops.Conv(torch.cat([wa, wb])[:, :, None, None], torch.cat([ba, bb]), device=dev)
+    ya = torch.zeros((cap, 1, 1, 512), device=dev); yb = torch.zeros((cap, 1, 1, 1024), device=dev)
+    ca(xd, cap, 1, 1, m_count=cnt, m_unit=1, out=ya)
+    cb(xd, cap, 1, 1, relu=True, m_count=cnt, m_unit=1, out=yb)
+    za = torch.zeros_like(ya); zb = torch.zeros_like(yb)
+    cm(xd, cap, 1, 1, relu=True, m_count=cnt, m_unit=1, out=za, split=(512, zb))
+    assert torch.equal(za, ya) and torch.equal(zb, yb)
+    close(za.view(cap, 512)[:R], (x @ wa.t() + ba)[:R], rtol=3e-4, atol=3e-4)
+    close(zb.view(cap, 1024)[:R], F.relu(x @ wb.t() + bb)[:R], rtol=3e-4, atol=3e-4)
+    assert float(za.view(cap, 512)[R:].abs().max()) == 0.0 and float(zb.view(cap, 1024)[R:].abs().max()) == 0.0
+
+
 def test_conv_wavek_pyramid_mode(dev):
     """The shared-weight head over a small pyramid (one row list, per-level zero padding) also takes the wave-split-K path."""
     from embodied_object_detection_amd import ops
@@ -355,6 +379,37 @@ def test_groupnorm_relu_multilevel(dev):
     for i, x in enumerate(xs):
         ref = F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-5))
         close(y[off[i]:off[i + 1]], nhwc(ref).reshape(-1, Cc), rtol=1e-4, atol=1e-4)
+
+
+def test_groupnorm_statistics_ride_on_the_conv_slab_reduce(dev):
+    """A pyramid-mode conv whose plan reduces split-K slabs (the CenterNet tower at 640x640: 536 tiles) also writes GroupNorm's
+    partial sums: conv output and GroupNorm output are bitwise those of the separate statistics launch."""
+    from embodied_object_detection_amd import ops
+    hw = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    Cc = 256
+    off = [0]
+    for h, w in hw:
+        off.append(off[-1] + h * w)
+    x = rnd(off[-1], Cc, seed=71).to(dev)
+    w = rnd(Cc, Cc, 3, 3, seed=72, scale=0.02)
+    b = rnd(Cc, seed=73)
+    gamma, beta = (torch.rand(Cc) + 0.5).to(dev), rnd(Cc, seed=74, scale=0.2).to(dev)
+    conv = ops.Conv(w, b, pad=1, device=dev)
+    stats_a, stats_b = ops.groupnorm_workspace(off, dev), ops.groupnorm_workspace(off, dev)
+    ya = torch.empty((off[-1], Cc), device=dev)
+    conv(x, 1, 0, 0, out=ya, levels=(off, hw))
+    assert not conv.gn_fused
+    ga = ops.groupnorm_relu(ya, gamma, beta, off, Cc, stats_a)
+    yb = torch.empty((off[-1], Cc), device=dev)
+    conv(x, 1, 0, 0, out=yb, levels=(off, hw), gn_stats=stats_b)
+    assert conv.gn_fused, "this layer's plan has a slab reduce"
+    gb = ops.groupnorm_relu(yb, gamma, beta, off, Cc, stats_b, partial_ready=True)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    # a small pyramid has no slab reduce to ride on: the statistics launch stays
+    hs = [(8, 12), (4, 6)]
+    offs = [0, 96, 120]
+    conv(x[:120].contiguous(), 1, 0, 0, out=torch.empty((120, Cc), device=dev), levels=(offs, hs), gn_stats=ops.groupnorm_workspace(offs, dev))
+    assert not conv.gn_fused
 
 
 def test_mask_predictor(dev):

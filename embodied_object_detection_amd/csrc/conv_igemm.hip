@@ -69,13 +69,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_gn_kernel(ConvArgs p) 
   const size_t slab = (size_t)p.M * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double s = 0.0, q = 0.0;
-    for (int r = r0; r < r1; ++r) {
-      const float* src = p.partial + (size_t)r * C + c;
-      float v = 0.f;
-      for (int z = 0; z < p.splitk; ++z) v += src[z * slab];
-      const double o = (double)epilogue_store(p, v, r, c);
-      s += o;
-      q += o * o;
+    for (int rb = r0; rb < r1; rb += 8) {
+      // eight rows at a time: their slab loads are independent and in flight together; sums stay in slab order, rows in row order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int z = 0; z < p.splitk; ++z) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (rb + j < r1) v[j] += p.partial[(size_t)z * slab + (size_t)(rb + j) * C + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rb + j < r1) {
+          const double o = (double)epilogue_store(p, v[j], rb + j, c);
+          s += o;
+          q += o * o;
+        }
+      }
     }
     for (int off = 1; off < cpg; off <<= 1) {
       s += __shfl_xor(s, off, 64);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 struct MwWs {
   int* inst_rows;   // [R_cap] unique proposal rows, ascending
   int* k_u;         // [1]
-  unsigned char* cover;  // [P]
+  unsigned char* cover;  // [P] 1 = at least one instance covers the pixel ("observed", custom_rcnn.py:897)
   int* cell_flag;   // [N] any pixel of the frame hit the cell                                   (zero between calls)
   int* cell_cnt;    // [N] number of sampled pixels that hit the cell                             (zero between calls)
   long long* wtab;  // [N, K_cap] fixed point 2^-32: sum over the cell's sampled pixels of 1/cover for every instance (zero between calls)
@@ -318,13 +318,15 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict_
   if (p < P) {
     const int y = p / W, x = p - y * W;
     const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
-    for (int i = 0; i < nc; ++i) {
+    // only "observed or not" is needed here (the cover COUNT matters for the sampled pixels alone, every 8th observed one: the
+    // scatter pass counts it for those): stop at the first instance that covers the pixel
+    for (int i = 0; i < nc && cnt == 0; ++i) {
       const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
       // quick reject: a sample more than one mask pixel outside the box is zero
       const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
       if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
       const RowSample rs = row_sample(y0, y1, y);
-      cnt += mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr) ? 1 : 0;
+      cnt = mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr) ? 1 : 0;
     }
     cover[p] = (unsigned char)cnt;
     int cell = proj[p];
@@ -378,16 +380,31 @@ __global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restric
   const int y = p / W, x = p - y * W;
   const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
   const int cell = clamp_cell(proj[p], n_cells);
-  const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)cv);
-  long long* dst = wtab + (size_t)cell * K_cap;
-  atomicAdd(cell_cnt + cell, 1);
+  // the instances that cover this pixel (bit i = band candidate i; MW_MAX_K <= 128 candidates), then 1 / cover to each of them
+  unsigned long long hit0 = 0, hit1 = 0;
   for (int i = 0; i < nc; ++i) {
     const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
     const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
     if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
     const RowSample rs = row_sample(y0, y1, y);
-    if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr))
-      atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
+    if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr)) {
+      if (i < 64) hit0 |= 1ull << i;
+      else hit1 |= 1ull << (i - 64);
+    }
+  }
+  const int ncov = __popcll(hit0) + __popcll(hit1);          // >= 1: the pixel is observed
+  const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)ncov);
+  long long* dst = wtab + (size_t)cell * K_cap;
+  atomicAdd(cell_cnt + cell, 1);
+  while (hit0) {
+    const int i = (int)__ffsll((long long)hit0) - 1;
+    hit0 &= hit0 - 1;
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
+  }
+  while (hit1) {
+    const int i = (int)__ffsll((long long)hit1) - 1;
+    hit1 &= hit1 - 1;
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[64 + i]), share);
   }
 }
 
@@ -564,8 +581,10 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
                      d->err_flags);
   hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
                      d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt);
+  // one workgroup per CU at most: the kernel runs beside dense launches of other streams, where every workgroup dispatch waits
+  // for a slot; a workgroup walks its 64-cell groups in a grid-stride loop
   int groups = (d->n_cells + 63) / 64;
-  if (groups > 4096) groups = 4096;
+  if (groups > 256) groups = 256;
   if (d->snapshot_f16)
     hipLaunchKernelGGL(mw_commit_kernel<true>, dim3(groups), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
                        d->K_cap, d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16), (int*)nullptr);

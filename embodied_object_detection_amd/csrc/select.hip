@@ -625,16 +625,20 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const float* __restric
   // of the key), so the sorted list does not depend on it -- and only as many keys as there are candidates get sorted: the memory
   // update's selection (threshold 0.3) sorts ~100 keys, not 8192 slots
   const int lane = threadIdx.x & 63;
+  float sc[EMAX];                       // all of a thread's scores first: eight independent loads, one latency
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    const int i = e * 1024 + threadIdx.x;
+    const int r = i / C, c = i - r * C;
+    sc[e] = (i < slots && r < R) ? scores[r * C1 + c] : -1.0f;
+  }
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
     const int i = e * 1024 + threadIdx.x;
     u64 k = 0;
     if (i < slots) {
-      const int r = i / C, c = i - r * C;
-      if (row_ok[r]) {
-        const float s = scores[r * C1 + c];
-        if (s > thr) k = make_key(s, (unsigned)i);
-      }
+      const int r = i / C;
+      if (row_ok[r] && sc[e] > thr) k = make_key(sc[e], (unsigned)i);
     }
     const u64 bal = __ballot(k != 0);
     int base = 0;

@@ -142,6 +142,7 @@ class CustomRCNNRecurrent:
         # on the detection stream (hipExtStreamCreateWithCUMask) would be the remedy; this runtime accepts the call and ignores
         # the mask (an fp32 matmul on a half-masked stream takes the same time).
         self.early_memory_selection = False
+        self.memory_selection_first = True     # on the side stream: cascade -> memory selection -> detection selection
         # how many coming frames of an episode the look-ahead computes at once (their images are all there when `forward` is
         # called): 2 = the memory-independent trunk + FPN top-down of frames t+1 and t+2 as ONE N = 2 pass every second frame
         # (planned like one image: bitwise the N = 1 results).  Measured at 640x640: the pass costs 1.23 ms per image instead of 1.61
@@ -492,20 +493,36 @@ class CustomRCNNRecurrent:
                 k = self._post_slot
                 if self._ev_det[k] is not None:
                     self._side_stream.wait_event(self._ev_det[k])     # the detection list set k is still read by frame t-2's pass
+                # The frame's critical chain (proposal masks -> memory write -> next frame's memory read) waits for the MEMORY
+                # selection, which needs the cascade's stage-0 features only; the detection selection feeds the detection pass,
+                # which has slack.  Same stream, memory selection first (`memory_selection_first`).
+                sel_first = lazy and not self.early_memory_selection and self.memory_selection_first
+                box_sel = {}
+
+                def _select_memory():
+                    box_sel["mem"] = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
+                    self._ev_sel.record(self._side_stream)
+                    self._mark("mem_select", self._side_stream)
+
+                if update_mem:
+                    self._mem_scores_frame = self._frame_no          # written by stage 0 of the cascade below
                 det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k,
                                                  stage0_event=self._ev_s0 if lazy else None,
-                                                 mem_rescore=(self.zs_weight, self.mem_scores) if update_mem else None)
-                if update_mem:
-                    self._mem_scores_frame = self._frame_no
+                                                 mem_rescore=(self.zs_weight, self.mem_scores) if update_mem else None,
+                                                 after_cascade=_select_memory if sel_first else None)
                 det_boxes, det_scores, det_classes, det_rows, det_count = det
                 self._ev_box.record(self._side_stream)
                 self._mark("cascade+det_select", self._side_stream)
+                if sel_first:
+                    mem_sel = box_sel["mem"]
             mem_stream = self._side_stream
-            if lazy and not self.early_memory_selection:
+            if lazy and not self.early_memory_selection and not self.memory_selection_first:
                 with torch.cuda.stream(self._side_stream):
                     mem_sel = self.select_memory_instances(prop_boxes, prop_scores, prop_count, (H, W))
                     self._ev_sel.record(self._side_stream)
                     self._mark("mem_select", self._side_stream)
+            elif lazy and not self.early_memory_selection:
+                pass
             elif lazy:
                 # The memory selection needs only stage 0 of the cascade (its CLIP-space features, custom_rcnn.py:825-875): it
                 # runs on its own stream beside stages 1-2 and the detection selection; the mask head then runs only on the

@@ -105,10 +105,12 @@ class DeticCascadeROIHeads:
 
     # ---- cascade box heads ------------------------------------------------------------------------
     def forward_box(self, views: List[torch.Tensor], shapes, prop_boxes: torch.Tensor, prop_scores: torch.Tensor, count: torch.Tensor,
-                    image_hw: Tuple[int, int], sel: int = 0, stage0_event=None, mem_rescore=None):
+                    image_hw: Tuple[int, int], sel: int = 0, stage0_event=None, mem_rescore=None, after_cascade=None):
         """`stage0_event` (optional torch.cuda.Event): recorded once stage 0 has produced `feat0` / `featn0` -- all that the memory
         selection (custom_rcnn.py:825-875) needs from the cascade.  `mem_rescore = (zs_weight of the meta-architecture, out [R, C1])`:
-        stage 0's classifier launch also writes the memory update's CLIP re-score of the proposals (custom_rcnn.py:838-861)."""
+        stage 0's classifier launch also writes the memory update's CLIP re-score of the proposals (custom_rcnn.py:838-861).
+        `after_cascade` (optional callable): enqueued between the cascade and the detection selection (the frame's critical chain
+        waits for the memory selection, not for the detections)."""
         h3, w3 = shapes[0]
         H, W = image_hw
         R = self.R
@@ -138,6 +140,8 @@ class DeticCascadeROIHeads:
             # fast_rcnn_inference itself
             ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
             boxes = self.boxes[k + 1]
+        if after_cascade is not None:
+            after_cascade()
         self.last_selector = self.selectors[sel]
         return self.selectors[sel](boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
 

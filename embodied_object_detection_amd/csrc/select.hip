@@ -555,19 +555,25 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
 // ------------------------------------------------------------------------------------------------------
 // fast_rcnn_inference in one launch: threshold + sort + per-class NMS + top-k (+ unique rows)
 // ------------------------------------------------------------------------------------------------------
-struct DetSort {
-  const float* boxes;
-  float img_w, img_h;
-  int C;
-  float* sorted_boxes;
-  float* sorted_scores;
-  int* sorted_labels;
-  int* sorted_rows;
-};
+// All detections of one proposal row carry the row's class-agnostic box, so per-class NMS never needs an IoU between two
+// candidates: it needs the IoU between two ROWS.  The kernel builds the R x R bit matrix M (bit r' of row r: IoU(box r, box r') >
+// thr) once -- one 64-bit word per thread -- and greedy NMS becomes bit tests: a candidate (row r, class c) is suppressed iff bit
+// r of supp[c] is set, where supp[c] is the OR of M[r'] over the kept (r', c).  Candidates are sorted in batches: the first batch
+// holds the >= 1024 best scores (histogram of the score bits, as in cn_level_topk_kernel), which is nearly always enough to keep
+// `topk`; only if it is not, the rest is sorted and the walk continues (same state, same order: exactly the greedy NMS over the
+// fully sorted list).  The walk itself is done by ONE wave (no workgroup barrier per chunk of 64 candidates).
+#define DET_MAX_R 512
+#define DET_WORDS (DET_MAX_R / 64)
+#define DET_MAX_C 24
 
-// sort the n compacted keys (n <= 1024 E) and write the sorted candidate list
+__device__ __forceinline__ int score_bin(unsigned bits) {
+  int bin = (int)(bits >> 14) - (int)(0x3C000000u >> 14);
+  return bin < 0 ? 0 : (bin > 4095 ? 4095 : bin);
+}
+
+// sort the n keys of `buf` (n <= 1024 E) descending and leave them there in sorted order
 template <int E>
-__device__ __forceinline__ void det_sort_emit(u64* buf, int n, const DetSort& d) {
+__device__ __forceinline__ void sort_in_place(u64* buf, int n) {
   u64 v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -576,33 +582,31 @@ __device__ __forceinline__ void det_sort_emit(u64* buf, int n, const DetSort& d)
   }
   __syncthreads();                     // every thread holds its keys: the buffer becomes the sort's exchange buffer
   block_sort_desc_reg<E>(v, buf);
+  __syncthreads();
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int q = threadIdx.x * E + e;
-    if (q >= n) continue;
-    const u64 k = v[e];
-    const int i = (int)key_index(k);
-    const int r = i / d.C, c = i - r * d.C;
-    d.sorted_boxes[q * 4 + 0] = fminf(fmaxf(d.boxes[r * 4 + 0], 0.f), d.img_w);
-    d.sorted_boxes[q * 4 + 1] = fminf(fmaxf(d.boxes[r * 4 + 1], 0.f), d.img_h);
-    d.sorted_boxes[q * 4 + 2] = fminf(fmaxf(d.boxes[r * 4 + 2], 0.f), d.img_w);
-    d.sorted_boxes[q * 4 + 3] = fminf(fmaxf(d.boxes[r * 4 + 3], 0.f), d.img_h);
-    d.sorted_scores[q] = key_score(k);
-    d.sorted_labels[q] = c;
-    d.sorted_rows[q] = r;
+    if (q < n) buf[q] = v[e];
   }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void det_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                            const int* __restrict__ count, int R_cap, int C1, float img_w,
-                                                           float img_h, float thr, float* sorted_boxes, float* sorted_scores,
-                                                           int* sorted_labels, int* sorted_rows, float nms_thresh, int topk,
-                                                           ScanOut o) {
+                                                           float img_h, float thr, float nms_thresh, int topk, ScanOut o) {
   EOD_CHAIN_PRIO();
   constexpr int EMAX = 8;
-  __shared__ u64 xch[1024 * EMAX];
-  __shared__ int sh_cnt;
-  __shared__ unsigned char row_ok[1024];
+  __shared__ u64 buf[1024 * EMAX];                 // compaction target / sort exchange / sorted keys of the batch
+  __shared__ u64 Mx[DET_MAX_R * DET_WORDS];        // IoU bit matrix of the rows
+  __shared__ float cbx[DET_MAX_R * 4];             // clipped boxes
+  __shared__ u64 supp[DET_MAX_C * DET_WORDS];      // per class: rows suppressed by the kept detections of that class
+  __shared__ int hist[4096];
+  __shared__ u64 kept_key[NMS_KEPT_MAX];
+  __shared__ int flag[NMS_KEPT_MAX];
+  __shared__ int wsum[16];
+  __shared__ unsigned char row_ok[DET_MAX_R];
+  __shared__ int sh_cnt, sh_cut, sh_n2, sh_total, sh_done;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int R = R_cap;
   if (count) {
     const int c = *count;
@@ -610,52 +614,266 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const float* __restric
   }
   const int C = C1 - 1;
   const int slots = R_cap * C;
-  if (threadIdx.x == 0) sh_cnt = 0;
+  const int W = (R + 63) >> 6;
+  for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+  for (int i = tid; i < DET_MAX_C * DET_WORDS; i += 1024) supp[i] = 0;
+  if (tid == 0) {
+    sh_cnt = 0;
+    sh_cut = 0;
+    sh_n2 = 0;
+    sh_total = 0;
+    sh_done = 0;
+  }
   // a row takes part only if its box and ALL its scores are finite (d2 fast_rcnn_inference drops the others)
-  for (int r = threadIdx.x; r < R_cap; r += blockDim.x) {
+  for (int r = tid; r < R_cap; r += 1024) {
     bool fin = r < R;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     if (fin) {
-      for (int q = 0; q < 4; ++q) fin = fin & (bool)isfinite(boxes[r * 4 + q]);
+      b0 = boxes[r * 4 + 0]; b1 = boxes[r * 4 + 1]; b2 = boxes[r * 4 + 2]; b3 = boxes[r * 4 + 3];
+      fin = isfinite(b0) && isfinite(b1) && isfinite(b2) && isfinite(b3);
       for (int q = 0; q < C1; ++q) fin = fin & (bool)isfinite(scores[r * C1 + q]);
     }
     row_ok[r] = fin ? 1 : 0;
+    cbx[r * 4 + 0] = fminf(fmaxf(b0, 0.f), img_w);
+    cbx[r * 4 + 1] = fminf(fmaxf(b1, 0.f), img_h);
+    cbx[r * 4 + 2] = fminf(fmaxf(b2, 0.f), img_w);
+    cbx[r * 4 + 3] = fminf(fmaxf(b3, 0.f), img_h);
   }
-  __syncthreads();
-  // candidates (score > thr) are compacted into the buffer -- in no particular order: the keys are unique (the slot index is part
-  // of the key), so the sorted list does not depend on it -- and only as many keys as there are candidates get sorted: the memory
-  // update's selection (threshold 0.3) sorts ~100 keys, not 8192 slots
-  const int lane = threadIdx.x & 63;
-  float sc[EMAX];                       // all of a thread's scores first: eight independent loads, one latency
+  // the thread's scores: eight independent loads, one latency (slot i = e * 1024 + tid = (row, class))
+  float sc[EMAX];
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
-    const int i = e * 1024 + threadIdx.x;
+    const int i = e * 1024 + tid;
     const int r = i / C, c = i - r * C;
     sc[e] = (i < slots && r < R) ? scores[r * C1 + c] : -1.0f;
   }
+  __syncthreads();
+  // IoU bit matrix: one word (64 partner rows) per thread and step
+  for (int idx = tid; idx < R * W; idx += 1024) {
+    const int r = idx / W, w = idx - r * W;
+    const float x1 = cbx[r * 4 + 0], y1 = cbx[r * 4 + 1], x2 = cbx[r * 4 + 2], y2 = cbx[r * 4 + 3];
+    const float area = (x2 - x1) * (y2 - y1);
+    u64 bits = 0;
+    for (int b = 0; b < 64; ++b) {
+      const int r2 = w * 64 + b;
+      if (r2 < R && r2 != r &&
+          iou_over(x1, y1, x2, y2, area, cbx[r2 * 4 + 0], cbx[r2 * 4 + 1], cbx[r2 * 4 + 2], cbx[r2 * 4 + 3], nms_thresh))
+        bits |= 1ull << b;
+    }
+    Mx[r * DET_WORDS + w] = bits;
+  }
+  // candidates: score > thr on a finite row; histogram of their score bits
+  u64 key[EMAX];
+  int local = 0;
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
-    const int i = e * 1024 + threadIdx.x;
+    const int i = e * 1024 + tid;
     u64 k = 0;
-    if (i < slots) {
-      const int r = i / C;
-      if (row_ok[r] && sc[e] > thr) k = make_key(sc[e], (unsigned)i);
+    if (i < slots && row_ok[i / C] && sc[e] > thr) {
+      k = make_key(sc[e], (unsigned)i);
+      atomicAdd(&hist[score_bin(__float_as_uint(sc[e]))], 1);
+      ++local;
     }
-    const u64 bal = __ballot(k != 0);
-    int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(&sh_cnt, __popcll(bal));
-    base = __shfl(base, 0, 64);
-    if (k) xch[base + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+    key[e] = k;
   }
+  if (local) atomicAdd(&sh_cnt, local);
   __syncthreads();
   const int n = sh_cnt;
-  const DetSort ds{boxes, img_w, img_h, C, sorted_boxes, sorted_scores, sorted_labels, sorted_rows};
-  if (n <= 1024) det_sort_emit<1>(xch, n, ds);
-  else if (n <= 2048) det_sort_emit<2>(xch, n, ds);
-  else if (n <= 4096) det_sort_emit<4>(xch, n, ds);
-  else det_sort_emit<8>(xch, n, ds);
-  __syncthreads();          // the sorted list (global) and the end of the sort's use of xch
-  static_assert(sizeof(NmsSmem) <= sizeof(xch), "the NMS state reuses the sort's exchange buffer");
-  block_greedy_nms(sorted_boxes, sorted_scores, sorted_labels, sorted_rows, n, nms_thresh, topk, 0, o, reinterpret_cast<NmsSmem*>(xch));
+  // the lowest bin whose suffix holds min(n, 1024) candidates
+  {
+    const int want = n < 1024 ? n : 1024;
+    const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_down(inc, off, 64);
+      if (lane + off < 64) inc += t;
+    }
+    if (lane == 0) wsum[wave] = inc;
+    __syncthreads();
+    int after = 0;
+    for (int w = wave + 1; w < 16; ++w) after += wsum[w];
+    const int above = after + inc - mine;
+    const int s3 = above + h3, s2 = s3 + h2, s1 = s2 + h1, s0 = s1 + h0;
+    if (want > 0) {
+      if (above < want && s3 >= want) sh_cut = 4 * tid + 3;
+      else if (s3 < want && s2 >= want) sh_cut = 4 * tid + 2;
+      else if (s2 < want && s1 >= want) sh_cut = 4 * tid + 1;
+      else if (s1 < want && s0 >= want) sh_cut = 4 * tid;
+    }
+  }
+  __syncthreads();
+  const int cut = sh_cut;
+  for (int batch = 0; batch < 2; ++batch) {
+    // batch 0: the candidates of the bins >= cut; batch 1 (only if batch 0 did not fill the list): all the others
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+      bool in = false;
+      if (key[e]) {
+        const bool hi = score_bin((unsigned)(key[e] >> 32)) >= cut;
+        in = batch == 0 ? hi : !hi;
+      }
+      const u64 bal = __ballot(in);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&sh_n2, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (in) buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = key[e];
+    }
+    __syncthreads();
+    const int n2 = sh_n2;
+    if (n2 <= 1024) sort_in_place<1>(buf, n2);
+    else if (n2 <= 2048) sort_in_place<2>(buf, n2);
+    else if (n2 <= 4096) sort_in_place<4>(buf, n2);
+    else sort_in_place<8>(buf, n2);
+    // greedy NMS over the batch by wave 0, 64 candidates at a time
+    if (wave == 0) {
+      int total = sh_total;
+      bool stop = false;
+      const int nchunk = (n2 + 63) >> 6;
+      for (int c = 0; c < nchunk && !stop; ++c) {
+        const int q = c * 64 + lane;
+        const bool valid = q < n2;
+        const u64 k = valid ? buf[q] : 0ull;
+        const int slot = (int)key_index(k);
+        const int r = valid ? slot / C : 0;
+        const int cl = valid ? slot - r * C : -1;
+        // suppressed by a detection kept earlier?
+        bool gone = !valid;
+        if (valid) gone = (supp[cl * DET_WORDS + (r >> 6)] >> (r & 63)) & 1ull;
+        // inside the chunk: bit j of `diag`: chunk entry j > lane has this lane's class and a row that overlaps this lane's row
+        u64 diag = 0;
+        for (int j = 0; j < 64; ++j) {
+          const int rj = __shfl(r, j, 64);
+          const int cj = __shfl(cl, j, 64);
+          if (j > lane && cj == cl && cl >= 0) {
+            if ((Mx[r * DET_WORDS + (rj >> 6)] >> (rj & 63)) & 1ull) diag |= 1ull << j;
+          }
+        }
+        u64 cur = __ballot(gone);
+        u64 kept = 0;
+        for (int i = 0; i < 64; ++i) {
+          const unsigned lo = __shfl((unsigned)(diag & 0xFFFFFFFFull), i, 64);
+          const unsigned hi = __shfl((unsigned)(diag >> 32), i, 64);
+          if (!((cur >> i) & 1ull)) {
+            kept |= (1ull << i);
+            cur |= ((u64)hi << 32) | lo;
+          }
+        }
+        // honour topk: keep the first (topk - total) of the chunk's kept entries
+        int nk = __popcll(kept);
+        if (total + nk >= topk) {
+          int room = topk - total;
+          u64 m = kept, take = 0;
+          while (room > 0 && m) {
+            take |= m & (~m + 1ull);
+            m &= m - 1;
+            --room;
+          }
+          kept = take;
+          nk = __popcll(kept);
+          stop = true;
+        }
+        if ((kept >> lane) & 1ull) {
+          const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
+          if (pos < NMS_KEPT_MAX) kept_key[pos] = k;
+          for (int w = 0; w < W; ++w) {
+            const u64 mw = Mx[r * DET_WORDS + w];
+            if (mw) atomicOr(&supp[cl * DET_WORDS + w], mw);
+          }
+        }
+        total += nk;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      if (lane == 0) {
+        sh_total = total;
+        // done when the list is full or no candidate is left for a second batch
+        sh_done = (stop || total >= topk || batch == 1 || n2 >= n) ? 1 : 0;
+        sh_n2 = 0;
+      }
+    }
+    __syncthreads();
+    if (sh_done) break;
+  }
+  __syncthreads();
+  int total = sh_total;
+  if (total > o.cap) total = o.cap;
+  if (total > NMS_KEPT_MAX) total = NMS_KEPT_MAX;
+  if (tid == 0 && o.out_count) *o.out_count = total;
+  int my_row = -1;
+  if (tid < total) {
+    const u64 k = kept_key[tid];
+    const int slot = (int)key_index(k);
+    const int r = slot / C, cl = slot - r * C;
+    my_row = r;
+    if (o.out_boxes) {
+      o.out_boxes[tid * 4 + 0] = cbx[r * 4 + 0];
+      o.out_boxes[tid * 4 + 1] = cbx[r * 4 + 1];
+      o.out_boxes[tid * 4 + 2] = cbx[r * 4 + 2];
+      o.out_boxes[tid * 4 + 3] = cbx[r * 4 + 3];
+    }
+    if (o.out_scores) o.out_scores[tid] = key_score(k);
+    if (o.out_labels) o.out_labels[tid] = cl;
+    if (o.out_rows) o.out_rows[tid] = r;
+  }
+  if (o.rep_of) {
+    // entries of one source row carry the same box: the first of them represents the group (the mask head is class agnostic)
+    if (tid < NMS_KEPT_MAX) flag[tid] = 0x7FFFFFFF;
+    __syncthreads();
+    if (tid < total && my_row >= 0 && my_row < NMS_KEPT_MAX) atomicMin(&flag[my_row], tid);
+    __syncthreads();
+    int is_rep = 0;
+    if (tid < total) {
+      const int rep = (my_row >= 0 && my_row < NMS_KEPT_MAX) ? flag[my_row] : tid;
+      o.rep_of[tid] = rep;
+      is_rep = rep == tid;
+    }
+    u64 rb = 0;
+    if (tid < NMS_KEPT_MAX) {
+      rb = __ballot(is_rep != 0);
+      if (lane == 0) wsum[wave] = __popcll(rb);
+    }
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_KEPT_MAX / 64; ++w) {
+      const int cw = wsum[w];
+      if (w < wave) before += cw;
+      all += cw;
+    }
+    if (tid < NMS_KEPT_MAX && is_rep) o.rep_list[before + __popcll(rb & ((1ull << lane) - 1ull))] = tid;
+    if (tid == 0) *o.rep_count = all;
+    __syncthreads();
+  }
+  if (o.uniq_rows) {
+    // torch.unique of the kept rows: flags over the row ids (< NMS_KEPT_MAX), ballot compaction, ascending
+    if (tid < NMS_KEPT_MAX) flag[tid] = 0;
+    __syncthreads();
+    if (tid < total && my_row >= 0 && my_row < NMS_KEPT_MAX) flag[my_row] = 1;
+    __syncthreads();
+    int f = 0;
+    u64 fb = 0;
+    if (tid < NMS_KEPT_MAX) {
+      f = flag[tid];
+      fb = __ballot(f != 0);
+      if (lane == 0) wsum[wave] = __popcll(fb);
+    }
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_KEPT_MAX / 64; ++w) {
+      const int cw = wsum[w];
+      if (w < wave) before += cw;
+      all += cw;
+    }
+    if (tid < NMS_KEPT_MAX && f) {
+      const int pos = before + __popcll(fb & ((1ull << lane) - 1ull));
+      if (pos < o.uniq_cap) o.uniq_rows[pos] = tid;
+    }
+    if (tid == 0 && o.uniq_count) *o.uniq_count = all < o.uniq_cap ? all : o.uniq_cap;
+  }
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -748,7 +966,8 @@ extern "C" int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream)
   if (!d || !d->boxes || !d->scores || !d->out_boxes || !d->out_scores || !d->out_classes || !d->out_rows || !d->out_count ||
       !d->workspace)
     return EOD_ERR_NULL;
-  if (d->R_cap <= 0 || d->R_cap > 1024 || d->C1 < 2 || d->topk <= 0 || d->topk > NMS_KEPT_MAX) return EOD_ERR_BAD_DIMS;
+  if (d->R_cap <= 0 || d->R_cap > DET_MAX_R || d->C1 < 2 || d->C1 - 1 > DET_MAX_C || d->topk <= 0 || d->topk > NMS_KEPT_MAX)
+    return EOD_ERR_BAD_DIMS;
   const int slots = d->R_cap * (d->C1 - 1);
   if (slots > 8192) return EOD_ERR_CAPACITY;
   const SelWs w = carve(d->workspace, slots, slots, 0);
@@ -759,6 +978,6 @@ extern "C" int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream)
   ScanOut o{d->out_boxes, d->out_scores, d->out_classes, d->out_rows, d->out_count, d->topk, d->out_unique_rows, d->out_unique_count,
             d->unique_cap, d->out_rep_of, d->out_rep_list, d->out_rep_count};
   hipLaunchKernelGGL(det_select_kernel, dim3(1), dim3(1024), 0, s, d->boxes, d->scores, d->count, d->R_cap, d->C1, d->img_w, d->img_h,
-                     d->score_thresh, w.sorted_boxes, w.sorted_scores, w.sorted_labels, w.sorted_rows, d->nms_thresh, d->topk, o);
+                     d->score_thresh, d->nms_thresh, d->topk, o);
   return eod_launch_status();
 }

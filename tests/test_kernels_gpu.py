@@ -495,12 +495,15 @@ def test_centernet_proposals_keep_ties(dev):
     close(b[:rb.shape[0]], rb, rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("thresh,topk,R", [(0.02, 300, 256), (0.3, 100, 256), (0.6, 50, 40), (0.999, 10, 16)])
-def test_fast_rcnn_inference_matches_oracle(dev, thresh, topk, R):
+@pytest.mark.parametrize("thresh,topk,R,spread", [(0.02, 300, 256, 1.0), (0.3, 100, 256, 1.0), (0.6, 50, 40, 1.0), (0.999, 10, 16, 1.0),
+                                                  (0.02, 300, 256, 0.02), (0.02, 300, 320, 0.15), (0.0, 100, 300, 0.3)])
+def test_fast_rcnn_inference_matches_oracle(dev, thresh, topk, R, spread):
+    """`spread` < 1 packs the boxes on top of each other: per-class NMS then suppresses nearly everything, the best 1024 candidates
+    do not fill the list and the kernel has to go on into its second sorted batch."""
     from embodied_object_detection_amd import ops
     g = torch.Generator().manual_seed(11)
-    ctr = torch.rand((R, 2), generator=g) * torch.tensor([200.0, 150.0])
-    size = torch.rand((R, 2), generator=g) * 80 + 4
+    ctr = torch.tensor([100.0, 75.0]) + (torch.rand((R, 2), generator=g) - 0.5) * torch.tensor([200.0, 150.0]) * spread
+    size = torch.rand((R, 2), generator=g) * 80 * min(1.0, spread * 4) + (4 if spread == 1.0 else 60)
     boxes = torch.cat([ctr - size / 2, ctr + size / 2], dim=1)
     scores = torch.rand((R, 21), generator=g)
     scores[3, 5] = float("nan")                                     # non-finite rows are dropped

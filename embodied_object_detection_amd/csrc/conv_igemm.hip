@@ -189,10 +189,14 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     splitk = d->force_splitk;
   } else if (pl.glds == 0 && !d->tap4 && nchunks >= 8 &&
              ((d->force_tile == 6 || d->force_tile == 7) ||
-              (tiles < 256 && nchunks <= 192 && pl.bk == 32 && d->force_tile == 0 && wavek_env()))) {
-    // Few rows, K up to 6144 (ResNet layer3/4 at batch 1, FPN laterals / outputs 4-5, P6/P7, the box heads' 1024-wide FC layers):
-    // K is split over the waves of a workgroup that owns a 32x32 tile (conv_wavek_kernel) -- no slabs, no reduce launch.  Eight
-    // waves once a wave's share would exceed 16 chunks.
+              (tiles < 256 && nchunks <= 192 && pl.bk == 32 && d->force_tile == 0 && wavek_env() &&
+               ((Mp <= 512 && nchunks / (nchunks >= 64 ? 8 : 4) >= 8) || nchunks >= 128)))) {
+    // Few rows and a deep K (ResNet layer4 at batch 1, FPN lateral / output 5, P6/P7, the box heads' 1024-wide FC layers): K is
+    // split over the waves of a workgroup that owns a 32x32 tile (conv_wavek_kernel) -- no slabs, no reduce launch.  Eight waves
+    // once a wave's share would exceed 16 chunks.  Measured per layer against the slab form (rocprofv3, 640x640 trunk,
+    // profiles/r03_*): it wins or ties where a wave gets >= 8 chunks and the row count is small (layer4 conv2 25 against 38 us,
+    // the FC layers equal with one launch less); with many rows (layer2/3: 32x32 tiles re-read the weights per tile) or a
+    // shallow K per wave (layer4 conv3) the slabs are faster (31 against 42 us, 21 against 34 us) and keep the layer.
     pl.wavek = d->force_tile == 6 ? 4 : (d->force_tile == 7 ? 8 : (nchunks >= 64 ? 8 : 4));     // force_tile 6 / 7: benchmarks, tests
     pl.bk = 32;
     pl.nchunks = d->Kpad / 32;

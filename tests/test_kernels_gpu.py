@@ -202,17 +202,20 @@ def test_conv_epilogues(dev):
     close(nchw(y), F.conv2d(F.relu(x), w, b, padding=1))
 
 
-@pytest.mark.parametrize("case", [
-    (1, 20, 20, 1024, 256, 1, 1, 0),     # layer3 conv1 / FPN lateral: 32 chunks -> 4 waves
-    (1, 20, 20, 256, 256, 3, 2, 1),      # stride-2 3x3 (layer4 conv2 / P6): 72 chunks -> 8 waves
-    (1, 10, 10, 512, 2048, 1, 1, 0),     # layer4 conv3
-    (1, 5, 5, 256, 256, 3, 2, 1),        # P7: 9 output rows
-    (3, 10, 14, 512, 96, 3, 1, 1),       # a batch, Cout not a multiple of 32, 144 chunks
-    (37, 1, 1, 1024, 4, 1, 1, 0),        # bbox_pred.2: four output channels
+@pytest.mark.parametrize("case,wavek", [
+    ((1, 20, 20, 1024, 256, 1, 1, 0), True),     # FPN lateral at 640x640: 400 rows, 32 chunks -> 4 waves x 8 chunks
+    ((1, 20, 20, 256, 256, 3, 2, 1), True),      # stride-2 3x3 (P6): 72 chunks -> 8 waves
+    ((1, 20, 20, 512, 512, 3, 1, 1), True),      # layer4 conv2: 144 chunks
+    ((1, 10, 10, 512, 2048, 1, 1, 0), False),    # layer4 conv3: 16 chunks = 4 per wave: stays on the slab form
+    ((1, 40, 40, 1024, 256, 1, 1, 0), False),    # layer3 conv1: 1600 rows: stays on the slab form
+    ((1, 5, 5, 256, 256, 3, 2, 1), True),        # P7: 9 output rows
+    ((3, 10, 14, 512, 96, 3, 1, 1), True),       # a batch, Cout not a multiple of 32, 144 chunks
+    ((37, 1, 1, 1024, 4, 1, 1, 0), True),        # bbox_pred.2: four output channels
 ])
-def test_conv_wavek_few_rows_deep_k(dev, case):
-    """Layers with fewer than 256 tiles of 64x64 and 8 <= K/32 <= 192 split K over the WAVES of a workgroup (conv_wavek_kernel):
-    no slabs, no reduce launch.  Against F.conv2d, with every epilogue; a batch gives bitwise the rows of the single-image calls."""
+def test_conv_wavek_few_rows_deep_k(dev, case, wavek):
+    """Few-row layers with a deep K split it over the WAVES of a workgroup (conv_wavek_kernel): no slabs, no reduce launch; the
+    planner keeps the slab form where it measured faster.  Against F.conv2d, with every epilogue; a batch gives bitwise the rows of
+    the single-image calls; forced onto the other form the results agree to fp32 noise."""
     from embodied_object_detection_amd import ops
     N, H, W, Cin, Cout, k, stride, pad = case
     x = rnd(N, Cin, H, W, seed=51)
@@ -220,9 +223,10 @@ def test_conv_wavek_few_rows_deep_k(dev, case):
     b = rnd(Cout, seed=53)
     conv = ops.Conv(w, b, stride=stride, pad=pad, device=dev)
     xd = nhwc(x).to(dev)
-    assert ops._lib.load().eod_conv2d_workspace_bytes is not None
     y = conv(xd, N, H, W)
-    assert conv.desc.workspace_bytes == 0, "the wave-split-K plan needs no slab workspace"
+    assert (conv.desc.workspace_bytes == 0) == wavek, "wave-split-K plans need no slab workspace; the slab form does"
+    y_forced = conv(xd, N, H, W, force_tile=7 if Cin * k * k >= 2048 else 6).clone()       # the 32x32-tile kernel, forced
+    close(y_forced, conv(xd, N, H, W), rtol=1e-5, atol=1e-5)
     ref = F.conv2d(x, w, b, stride=stride, padding=pad)
     close(nchw(y), ref)
     OH, OW = ref.shape[2:]
@@ -232,7 +236,7 @@ def test_conv_wavek_few_rows_deep_k(dev, case):
     # the slab path on the same problem agrees to fp32 noise (another summation order)
     y_slab = conv(xd, N, H, W, force_tile=3, force_splitk=3)
     close(y_slab, conv(xd, N, H, W), rtol=1e-5, atol=1e-5)
-    if N > 1:
+    if N > 1 and wavek:
         yb = conv(xd, N, H, W, plan_rows=OH * OW).clone()
         for n in range(N):
             y1 = conv(xd[n:n + 1].contiguous(), 1, H, W)

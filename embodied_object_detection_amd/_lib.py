@@ -34,7 +34,7 @@ class EodConvDesc(C.Structure):
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
         ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
         ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32), ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
-        ("y2", C.c_void_p), ("split_n", C.c_int32),
+        ("y2", C.c_void_p), ("split_n", C.c_int32), ("prefetch2", C.c_int32),
     ]
 
 

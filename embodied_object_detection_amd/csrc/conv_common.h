@@ -123,7 +123,7 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (4 waves); bf16x3 also 4 = 256x128 (8 waves, dynamic LDS); fp32 also 5 = 64x256
 // (one whole deconv quadrant per workgroup: the fused mask-head tail, out_mode 2)
-void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve = 0);
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve = 0, int prefetch2 = 0);
 void launch_conv_bf16x3(const ConvArgs& a, int tile, dim3 grid, hipStream_t s);
 void launch_conv_wavek(const ConvArgs& a, int nw, dim3 grid, hipStream_t s);
 void launch_split_weights(const float* w, void* out, int Cout, int Kpad, hipStream_t s);

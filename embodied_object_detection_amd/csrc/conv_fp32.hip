@@ -27,7 +27,10 @@
 namespace eodconv {
 namespace {
 
-template <int BM, int BN, int BK, bool TAP4, bool MULTI>
+// PF2: two operand sets in registers -- chunks c+1 and c+2 are in flight while chunk c is multiplied.  For launches that leave only
+// 2-5 workgroups on a CU (the mask head on ~40 or ~90 ROIs) the global-load latency is no longer hidden by other workgroups'
+// MFMAs; one more chunk of prefetch hides it.
+template <int BM, int BN, int BK, bool TAP4, bool MULTI, bool PF2 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int LS = BK + 4;  // LDS row stride in floats (+4: conflict-free 16-lane groups of ds_read_b128)
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
-  f32x4 ar[AR], br[BR];
+  f32x4 ar0[AR], br0[BR];
+  f32x4 ar1[PF2 ? AR : 1], br1[PF2 ? BR : 1];
   // (tap, channel offset) of the NEXT chunk to fetch: chunks are fetched in order, so the position is advanced instead of
   // re-derived with two divisions per chunk (Cin is a multiple of BK on this path)
   int nx_tap = 0, nx_c0 = 0, nx_ky = 0, nx_kx = 0;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     nx_ky = nx_tap / p.KW;
     nx_kx = nx_tap - nx_ky * p.KW;
   }
-  auto load_chunk = [&](int chunk) {
+  auto load_chunk = [&](int chunk, auto& ar, auto& br) {
     const int k0 = chunk * BK;
     if (!TAP4) {
       const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
@@ -204,14 +208,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const float* a_base = As + (wm * TM * 32 + frag_row) * LS + frag_k;
   const float* b_base = Bs + (wn * TN * 32 + frag_row) * LS + frag_k;
 
-  load_chunk(c_begin);
-  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+  auto stage_and_multiply = [&](auto& ar, auto& br, int next_chunk) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + (lr + RPP * i) * LS + 4 * lq) = ar[i];
 #pragma unroll
     for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + RPP * j) * LS + 4 * lq) = br[j];
     __syncthreads();
-    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+    if (next_chunk < c_end) load_chunk(next_chunk, ar, br);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];
@@ -233,6 +236,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
+  };
+  load_chunk(c_begin, ar0, br0);
+  if constexpr (PF2) {
+    if (c_begin + 1 < c_end) load_chunk(c_begin + 1, ar1, br1);
+    for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+      stage_and_multiply(ar0, br0, chunk + 2);
+      if (chunk + 1 < c_end) stage_and_multiply(ar1, br1, chunk + 3);
+    }
+  } else {
+    for (int chunk = c_begin; chunk < c_end; ++chunk) stage_and_multiply(ar0, br0, chunk + 1);
   }
 
   if (TM * TN == 1) {
@@ -502,8 +515,12 @@ static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hi
 }
 
 // `lds_reserve`: dynamic LDS the launch allocates and the kernel never touches (EodConvDesc.lds_reserve): caps the workgroups per CU
-void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve) {
+void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve, int prefetch2) {
   const int dyn = lds_reserve > 0 ? lds_reserve : 0;
+  if (prefetch2 && !tap4 && a.nlv == 0 && bk == 32 && tile == 3) {      // 64x64 only: the 64x256 tail would need 256 VGPRs
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 32, false, false, true>), grid, dim3(256), dyn, s, a);
+    return;
+  }
   switch (tile) {
     case 5: hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 32, false, false>), grid, dim3(256), dyn, s, a); break;
     case 1: launch_fp32_tile<128, 128>(a, tap4, bk, grid, s, dyn); break;

@@ -377,7 +377,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk);
   if (pl.wavek) launch_conv_wavek(a, pl.wavek, grid, s);
   else if (pl.glds == 2) launch_conv_bf16x3(a, pl.tile, grid, s);
-  else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s, d->lds_reserve);
+  else launch_conv_fp32(a, pl.tile, pl.bk, d->tap4 != 0, grid, s, d->lds_reserve, d->prefetch2);
   if (pl.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;
     const bool vec = a.Cout % 4 == 0;

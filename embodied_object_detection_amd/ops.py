@@ -129,6 +129,7 @@ class Conv:
         self.event_log = None   # bench.py: list that receives (start_event, end_event, event_tag) per launch
         self.event_tag = None   # what the caller wants to know the launch by (no device work: a clone of m_count would be a launch)
         self.lds_reserve = 0    # EodConvDesc.lds_reserve: caps this layer's workgroups per CU (see include/eod_hip.h)
+        self.prefetch2 = 0      # EodConvDesc.prefetch2: two chunks of operands in flight (small launches)
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -173,6 +174,7 @@ class Conv:
         d.force_tile, d.force_splitk, d.out_scale = force_tile, force_splitk, out_scale
         d.plan_rows = plan_rows
         d.lds_reserve = self.lds_reserve
+        d.prefetch2 = self.prefetch2
         d.gn_partial, d.gn_groups = None, 0
         self.gn_fused = False
         if split is not None:

@@ -101,6 +101,9 @@ typedef struct EodConvDesc {
    * res_mode 0, no pyramid mode.  Every output column walks K exactly as in a separate call: bitwise the two layers' results. */
   float* y2;
   int32_t split_n;
+  /* 1: the 64x64 fp32 kernel keeps TWO chunks of operands in flight (one more set of prefetch registers).  For launches that put
+   * only 2-5 workgroups on a CU (the mask head on ~40 / ~90 ROIs) the global-load latency is otherwise exposed.  Same results. */
+  int32_t prefetch2;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 int eod_conv2d_gn_fused(const EodConvDesc* d); /* 1 when this layer can carry gn_partial (its plan has a slab reduce), else 0 */

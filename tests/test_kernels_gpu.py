@@ -295,6 +295,27 @@ def test_conv_wavek_pyramid_mode(dev):
         close(out[off[i]:off[i + 1]].view(1, h, ww, Cout).permute(0, 3, 1, 2), ref)
 
 
+def test_conv_two_chunk_prefetch_is_bitwise_the_same(dev):
+    """EodConvDesc.prefetch2 changes when operands are fetched, not what is computed: the mask-head shape with a device-side ROI
+    count, odd and even chunk counts per split."""
+    from embodied_object_detection_amd import ops
+    x = rnd(40, 256, 14, 14, seed=91)
+    w = rnd(256, 256, 3, 3, seed=92, scale=0.02)
+    conv = ops.Conv(w, rnd(256, seed=93), pad=1, device=dev)
+    xd = nhwc(x).to(dev)
+    cnt = torch.tensor([33], dtype=torch.int32, device=dev)
+    for splitk in (1, 3, 8):            # 72 chunks: 72 / 24 / 9 per split
+        outs = []
+        for pf in (0, 1):
+            conv.prefetch2 = pf
+            y = torch.zeros((40, 14, 14, 256), device=dev)
+            conv(xd, 40, 14, 14, relu=True, m_count=cnt, m_unit=196, out=y, force_tile=13, force_splitk=splitk)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), splitk
+    conv.prefetch2 = 1
+    close(nchw(conv(xd, 40, 14, 14, relu=True)), F.relu(F.conv2d(x, w, conv.bias.cpu(), padding=1)))
+
+
 def test_conv_stem_tap4_with_bn_fold(dev):
     from embodied_object_detection_amd import ops
     H, W = 64, 96

@@ -8,7 +8,7 @@ from embodied_object_detection_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 
-def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=(0,), deconv=False, iters=20):
+def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=(0,), deconv=False, iters=20, prefetch2=0):
     x = torch.randn((N, H, W, Cin), generator=g).to(dev)
     if deconv:
         w = torch.randn((Cin, Cout, 2, 2), generator=g) * 0.05
@@ -19,6 +19,7 @@ def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=
         conv = ops.Conv(w, torch.zeros(Cout), stride=stride, pad=pad, device=dev)
         OH, OW = conv.out_hw(H, W)
         flops = 2.0 * N * OH * OW * Cout * Cin * k * k
+        conv.prefetch2 = prefetch2
     for t in tiles:
         for sk in splitks:
             try:
@@ -40,6 +41,7 @@ if which == "propmask":
     # the proposal-mask pass (~43 ROIs) and the de-duplicated detection pass (~100 ROIs): 64x64 tiles against the wave-split-K kernel
     for rois in (43, 100, 300):
         bench(f"mask_fcn {rois} rois", rois, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 6, 7), iters=30)
+        bench(f"mask_fcn {rois} rois prefetch2", rois, 14, 14, 256, 256, 3, 1, 1, tiles=(13,), iters=30, prefetch2=1)
     sys.exit(0)
 if which == "masktiles":
     bench("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1, tiles=(13, 12, 11, 13, 12), iters=30)

@@ -56,38 +56,20 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
       *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8 + 4) = f32x4{x[4], x[5], x[6], x[7]};
     }
     const float ps = (final_inv_stages > 0.f && prop_scores) ? prop_scores[row] : 0.f;
-    // all classes' per-lane partial sums first, then ONE set of butterfly steps over all of them: the 6 shuffle steps of a class
-    // are a dependent chain (~60 cycles each), 21 classes one after the other were 126 of them; the sums and their order per class
-    // are unchanged
-    float s[ZS_MAX_C];
-#pragma unroll
-    for (int c = 0; c < ZS_MAX_C; ++c) {
-      s[c] = 0.f;
-      if (c < C1) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
-        float t = 0.f;
-        t += x[0] * w0.x; t += x[1] * w0.y; t += x[2] * w0.z; t += x[3] * w0.w;
-        t += x[4] * w1.x; t += x[5] * w1.y; t += x[6] * w1.z; t += x[7] * w1.w;
-        s[c] = t;
+    for (int c = 0; c < C1; ++c) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
+      float s = 0.f;
+      s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
+      s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
+      s = wave_reduce_sum(s);
+      if (lane == 0) {
+        const float p = eod_sigmoid_precise(s);
+        float* o = prob_acc + (size_t)row * C1 + c;
+        float v = accumulate ? (*o + p) : p;
+        if (final_inv_stages > 0.f) v = sqrtf(v * final_inv_stages * ps);       // cascade score fusion (detic_roi_heads.py:164-173)
+        *o = v;
       }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int c = 0; c < ZS_MAX_C; ++c)
-        if (c < C1) s[c] += __shfl_xor(s[c], off, 64);
-    // lane c finishes class c: sigmoid, accumulate, optional cascade score fusion (detic_roi_heads.py:164-173)
-    float mine = 0.f;
-#pragma unroll
-    for (int c = 0; c < ZS_MAX_C; ++c)
-      if (lane == c) mine = s[c];
-    if (lane < C1) {
-      const float p = eod_sigmoid_precise(mine);
-      float* o = prob_acc + (size_t)row * C1 + lane;
-      float v = accumulate ? (*o + p) : p;
-      if (final_inv_stages > 0.f) v = sqrtf(v * final_inv_stages * ps);
-      *o = v;
     }
   }
   if (!zs_mem) return;
@@ -101,29 +83,15 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
   __syncthreads();
   if (!active) return;
   const float p = prop_scores[row];
-  float s[ZS_MAX_C];
-#pragma unroll
-  for (int c = 0; c < ZS_MAX_C; ++c) {
-    s[c] = 0.f;
-    if (c < C1) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
-      float t = 0.f;
-      t += x[0] * w0.x; t += x[1] * w0.y; t += x[2] * w0.z; t += x[3] * w0.w;
-      t += x[4] * w1.x; t += x[5] * w1.y; t += x[6] * w1.z; t += x[7] * w1.w;
-      s[c] = t;
-    }
+  for (int c = 0; c < C1; ++c) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
+    float s = 0.f;
+    s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
+    s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
+    s = wave_reduce_sum(s);
+    if (lane == 0) mem_scores[(size_t)row * C1 + c] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(s) * p) : 0.0f;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int c = 0; c < ZS_MAX_C; ++c)
-      if (c < C1) s[c] += __shfl_xor(s[c], off, 64);
-  float mine = 0.f;
-#pragma unroll
-  for (int c = 0; c < ZS_MAX_C; ++c)
-    if (lane == c) mine = s[c];
-  if (lane < C1) mem_scores[(size_t)row * C1 + lane] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(mine) * p) : 0.0f;
 }
 
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, float* __restrict__ out,

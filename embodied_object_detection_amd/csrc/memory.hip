@@ -375,46 +375,36 @@ __global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restric
   const int first = sh_off;
   if (((first + 7) & ~7) >= first + total) return;           // block-uniform
   const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
-  // the block's sampled pixels (every 8th observed pixel, row-major, custom_rcnn.py:913-914) go into a list; then ONE WAVE per
-  // sampled pixel with the lanes over the band's candidate instances: a lane tests one (pixel, instance) pair, the ballot of the
-  // hits is the cover count, every hitting lane adds the pixel's 1 / cover share to its instance's weight
-  __shared__ int samp_s[SCAN_ELEMS / 8 + 2], nsamp_s;
-  if (threadIdx.x == 0) nsamp_s = 0;
-  __syncthreads();
   const int rank = first + local;
-  if (cv != 0 && (rank & 7) == 0) samp_s[atomicAdd(&nsamp_s, 1)] = p;       // order inside the list is irrelevant (integer atomics)
-  __syncthreads();
-  const int ns = nsamp_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int q = wave; q < ns; q += 16) {
-    const int pp = samp_s[q];
-    const int y = pp / W, x = pp - y * W;
-    const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
-    const int cell = clamp_cell(proj[pp], n_cells);
-    long long* dst = wtab + (size_t)cell * K_cap;
-    int ncov = 0;
-    unsigned long long hits[2] = {0ull, 0ull};
-    for (int i0 = 0; i0 < nc; i0 += 64) {
-      const int i = i0 + lane;
-      bool hit = false;
-      if (i < nc) {
-        const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
-        const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
-        if (!(fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my)) {
-          const RowSample rs = row_sample(y0, y1, y);
-          hit = mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr);
-        }
-      }
-      const unsigned long long bal = __ballot(hit);
-      hits[i0 >> 6] = bal;
-      ncov += __popcll(bal);
+  if (cv == 0 || (rank & 7) != 0) return;                    // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
+  const int y = p / W, x = p - y * W;
+  const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
+  const int cell = clamp_cell(proj[p], n_cells);
+  // the instances that cover this pixel (bit i = band candidate i; MW_MAX_K <= 128 candidates), then 1 / cover to each of them
+  unsigned long long hit0 = 0, hit1 = 0;
+  for (int i = 0; i < nc; ++i) {
+    const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
+    const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
+    if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
+    const RowSample rs = row_sample(y0, y1, y);
+    if (mask_hit_row(masks + (size_t)rows_s[cand_s[i]] * 784, rs, x0, x1, x, thr)) {
+      if (i < 64) hit0 |= 1ull << i;
+      else hit1 |= 1ull << (i - 64);
     }
-    if (lane == 0) atomicAdd(cell_cnt + cell, 1);
-    const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)(ncov > 0 ? ncov : 1));
-    for (int i0 = 0; i0 < nc; i0 += 64) {
-      const int i = i0 + lane;
-      if (i < nc && ((hits[i0 >> 6] >> lane) & 1ull)) atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
-    }
+  }
+  const int ncov = __popcll(hit0) + __popcll(hit1);          // >= 1: the pixel is observed
+  const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)ncov);
+  long long* dst = wtab + (size_t)cell * K_cap;
+  atomicAdd(cell_cnt + cell, 1);
+  while (hit0) {
+    const int i = (int)__ffsll((long long)hit0) - 1;
+    hit0 &= hit0 - 1;
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
+  }
+  while (hit1) {
+    const int i = (int)__ffsll((long long)hit1) - 1;
+    hit1 &= hit1 - 1;
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[64 + i]), share);
   }
 }
 

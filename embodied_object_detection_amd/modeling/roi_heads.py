@@ -67,9 +67,11 @@ class DeticCascadeROIHeads:
         m = "roi_heads.mask_head"
         self.mask_convs = [ops.Conv(sd[f"{m}.mask_fcn{i}.weight"], sd[f"{m}.mask_fcn{i}.bias"], pad=1, device=device, name=f"mask_fcn{i}")
                            for i in range(1, 5)]
+        # EodConvDesc.prefetch2 (two chunks of operands in flight) was built for these launches (~40 / ~90 ROIs leave 2-5 workgroups
+        # on a CU) and measured slower at every size (tools/conv_bench.py propmask: 43 ROIs 128 against 121 us, 100 ROIs 254
+        # against 229, 300 ROIs 688 against 644; whole frame 273 against 281 frames/s): off; EOD_MASK_PREFETCH2=1 turns it on
         for conv in self.mask_convs:
-            # ~40 (memory instances) / ~90 (distinct detection boxes) ROIs put 2-5 workgroups on a CU: two chunks of prefetch
-            conv.prefetch2 = int(__import__("os").environ.get("EOD_MASK_PREFETCH2", "1"))
+            conv.prefetch2 = int(__import__("os").environ.get("EOD_MASK_PREFETCH2", "0"))
         self.deconv = ops.Conv(sd[f"{m}.deconv.weight"], sd[f"{m}.deconv.bias"], device=device, deconv=True, name="mask_deconv")
         self.pred_w = sd[f"{m}.predictor.weight"].reshape(-1).contiguous().to(device)
         self.pred_b = float(sd[f"{m}.predictor.bias"].item())

@@ -30,15 +30,20 @@ namespace {
 // PF2: two operand sets in registers -- chunks c+1 and c+2 are in flight while chunk c is multiplied.  For launches that leave only
 // 2-5 workgroups on a CU (the mask head on ~40 or ~90 ROIs) the global-load latency is no longer hidden by other workgroups'
 // MFMAs; one more chunk of prefetch hides it.
-template <int BM, int BN, int BK, bool TAP4, bool MULTI, bool PF2 = false>
+// PIPE 2: the operand tiles are double buffered in LDS -- chunk c+1 is written to the other buffer while chunk c is multiplied: ONE
+// workgroup barrier per chunk instead of two, at twice the LDS (36 KB for 64x64: 4 workgroups per CU).
+template <int BM, int BN, int BK, bool TAP4, bool MULTI, int PIPE = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  constexpr bool PF2 = PIPE == 1;
+  constexpr bool DB = PIPE == 2;
   constexpr int LS = BK + 4;  // LDS row stride in floats (+4: conflict-free 16-lane groups of ds_read_b128)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int QPR = BK / 4;        // float4 per tile row
   constexpr int RPP = 256 / QPR;     // tile rows staged per pass of the 256 threads
   constexpr int AR = BM / RPP, BR = BN / RPP;
   static_assert(!TAP4 || BK == 32, "the stem path stages one 7x7 tap per float4: BK must be 32");
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LS];
+  constexpr int BUF = (BM + BN) * LS;
+  __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * BUF];
   float* As = lds;
   float* Bs = lds + BM * LS;
 
@@ -238,7 +243,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     __syncthreads();
   };
   load_chunk(c_begin, ar0, br0);
-  if constexpr (PF2) {
+  if constexpr (DB) {
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + buf * BUF + (lr + RPP * i) * LS + 4 * lq) = ar0[i];
+#pragma unroll
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + buf * BUF + (lr + RPP * j) * LS + 4 * lq) = br0[j];
+    };
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const bool more = chunk + 1 < c_end;
+      if (more) load_chunk(chunk + 1, ar0, br0);
+      const float* ab = a_base + cur * BUF;
+      const float* bb = b_base + cur * BUF;
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(ab + i * 32 * LS + kk * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bb + j * 32 * LS + kk * 8);
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              if (TM * TN == 1 && (tt & 1))
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc_b, 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else if constexpr (PF2) {
     if (c_begin + 1 < c_end) load_chunk(c_begin + 1, ar1, br1);
     for (int chunk = c_begin; chunk < c_end; chunk += 2) {
       stage_and_multiply(ar0, br0, chunk + 2);
@@ -517,8 +561,13 @@ static void launch_fp32_tile(const ConvArgs& a, bool tap4, int bk, dim3 grid, hi
 // `lds_reserve`: dynamic LDS the launch allocates and the kernel never touches (EodConvDesc.lds_reserve): caps the workgroups per CU
 void launch_conv_fp32(const ConvArgs& a, int tile, int bk, bool tap4, dim3 grid, hipStream_t s, int lds_reserve, int prefetch2) {
   const int dyn = lds_reserve > 0 ? lds_reserve : 0;
-  if (prefetch2 && !tap4 && a.nlv == 0 && bk == 32 && tile == 3) {      // 64x64 only: the 64x256 tail would need 256 VGPRs
-    hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 32, false, false, true>), grid, dim3(256), dyn, s, a);
+  if (prefetch2 == 1 && !tap4 && a.nlv == 0 && bk == 32 && tile == 3) {      // 64x64 only: the 64x256 tail would need 256 VGPRs
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 32, false, false, 1>), grid, dim3(256), dyn, s, a);
+    return;
+  }
+  if (prefetch2 == 2 && !tap4 && bk == 32 && tile == 3) {                     // double-buffered LDS, 64x64
+    if (a.nlv > 0) hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 32, false, true, 2>), grid, dim3(256), dyn, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 32, false, false, 2>), grid, dim3(256), dyn, s, a);
     return;
   }
   switch (tile) {

@@ -101,8 +101,9 @@ typedef struct EodConvDesc {
    * res_mode 0, no pyramid mode.  Every output column walks K exactly as in a separate call: bitwise the two layers' results. */
   float* y2;
   int32_t split_n;
-  /* 1: the 64x64 fp32 kernel keeps TWO chunks of operands in flight (one more set of prefetch registers).  For launches that put
-   * only 2-5 workgroups on a CU (the mask head on ~40 / ~90 ROIs) the global-load latency is otherwise exposed.  Same results. */
+  /* pipeline variant of the 64x64 fp32 kernel (same results, bitwise): 0 = one LDS buffer, one chunk of register prefetch, two
+   * barriers per chunk (default); 1 = two chunks of operands in flight (one more set of prefetch registers); 2 = the operand
+   * tiles double buffered in LDS, one barrier per chunk (36 KB per workgroup). */
   int32_t prefetch2;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);

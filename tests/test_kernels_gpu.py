@@ -306,13 +306,13 @@ def test_conv_two_chunk_prefetch_is_bitwise_the_same(dev):
     cnt = torch.tensor([33], dtype=torch.int32, device=dev)
     for splitk in (1, 3, 8):            # 72 chunks: 72 / 24 / 9 per split
         outs = []
-        for pf in (0, 1):
+        for pf in (0, 1, 2):           # one LDS buffer | two chunks of register prefetch | double-buffered LDS
             conv.prefetch2 = pf
             y = torch.zeros((40, 14, 14, 256), device=dev)
             conv(xd, 40, 14, 14, relu=True, m_count=cnt, m_unit=196, out=y, force_tile=13, force_splitk=splitk)
             outs.append(y)
-        assert torch.equal(outs[0], outs[1]), splitk
-    conv.prefetch2 = 1
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), splitk
+    conv.prefetch2 = 2
     close(nchw(conv(xd, 40, 14, 14, relu=True)), F.relu(F.conv2d(x, w, conv.bias.cpu(), padding=1)))
 
 

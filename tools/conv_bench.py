@@ -37,6 +37,19 @@ def bench(name, N, H, W, Cin, Cout, k, stride, pad, tiles=(0, 1, 2, 3), splitks=
                 print(name, t, sk, "ERR", ex)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "pipe":
+    # pipeline variants of the 64x64 kernel (EodConvDesc.prefetch2: 0 default, 2 = double-buffered LDS) on shapes of the frame
+    shapes = [("stem-like l1 conv1 256->64", 1, 160, 160, 256, 64, 1, 1, 0), ("l1 conv2 3x3 64->64", 1, 160, 160, 64, 64, 3, 1, 1),
+              ("l1 conv3 64->256", 1, 160, 160, 64, 256, 1, 1, 0), ("l2 conv2 3x3 128->128", 1, 80, 80, 128, 128, 3, 1, 1),
+              ("l2 conv3 128->512", 1, 80, 80, 128, 512, 1, 1, 0), ("l3 conv1 1024->256", 1, 40, 40, 1024, 256, 1, 1, 0),
+              ("l3 conv2 3x3 256->256", 1, 40, 40, 256, 256, 3, 1, 1), ("l3 conv3 256->1024", 1, 40, 40, 256, 1024, 1, 1, 0),
+              ("fpn out3 3x3 256", 1, 80, 80, 256, 256, 3, 1, 1), ("fc1 256 rois", 256, 1, 1, 12544, 1024, 1, 1, 0),
+              ("mask_fcn 43 rois", 43, 14, 14, 256, 256, 3, 1, 1), ("mask_fcn 92 rois", 92, 14, 14, 256, 256, 3, 1, 1),
+              ("mask_fcn 300 rois", 300, 14, 14, 256, 256, 3, 1, 1)]
+    for sh in shapes:
+        for pf in (0, 2):
+            bench(f"{sh[0]} pipe={pf}", *sh[1:], tiles=(0,), iters=30, prefetch2=pf)
+    sys.exit(0)
 if which == "propmask":
     # the proposal-mask pass (~43 ROIs) and the de-duplicated detection pass (~100 ROIs): 64x64 tiles against the wave-split-K kernel
     for rois in (43, 100, 300):

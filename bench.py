@@ -95,13 +95,24 @@ def available_cores() -> int:
     return max(1, min(n, 32))
 
 
+def _profile_json(name):
+    """The newest committed summary of that name (profiles/r03_*.json, else r02_*.json)."""
+    for rnd in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as fh:
+                return json.load(fh)
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate passes: profiles/r02_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
+    WRITE_SIZE, separate passes: profiles/r03_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
+    d = _profile_json("dominant_kernel_traffic")
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")) as fh:
-            return round(float(json.load(fh)["traffic_bytes_per_launch"]), 1)
-    except (OSError, KeyError, ValueError):
+        return round(float(d["traffic_bytes_per_launch"]), 1)
+    except (TypeError, KeyError, ValueError):
         return None
 
 
@@ -194,9 +205,8 @@ def hbm_class_probe(model, frames, idx, H, W, n_cells, reps=30, gather_frames=No
     traffic = None
     try:
         if (H, W, n_cells) == (640, 640, 40000):        # the committed PMC passes were taken on this configuration
-            with open(os.path.join(ROOT, "profiles", "r02_hbm_class_traffic.json")) as fh:
-                traffic = round(float(json.load(fh)["traffic_bytes_total_x2_reads"]), 1)
-    except (OSError, KeyError, ValueError):
+            traffic = round(float(_profile_json("hbm_class_traffic")["traffic_bytes_total_x2_reads"]), 1)
+    except (TypeError, KeyError, ValueError):
         pass
 
     def rate(nbytes, t_us):

@@ -33,7 +33,7 @@ def main():
     # ---- dominant kernel: conv_igemm_kernel<64,64,32,false,false>, by grid (= launch capacity: detection pass / proposal pass)
     shapes = {}
     for (name, grid), v in fetch.items():
-        if "conv_igemm_kernel<64, 64, 32, false, false>" not in name.replace("(anonymous namespace)::", ""):
+        if "conv_igemm_kernel<64, 64, 32, false, false" not in name.replace("(anonymous namespace)::", ""):
             continue
         w = write.get((name, grid), [0.0])
         shapes[grid] = {"grid_threads": grid, "workgroups": grid // 256, "dispatches": [len(v), len(w)], "fetch_bytes_raw": round(avg(v), 1),

@@ -735,6 +735,18 @@ def main():
                             "proposal-mask pass, ROI counts in config): in the default schedule these launches run concurrently with each "
                             "other and with the look-ahead trunk, so a launch's duration includes sharing the chip; "
                             "exclusive_launches is the kernel with the chip to itself"}
+        prof = None if b3 else _profile_json("dominant_kernel_rocprof")
+        if prof:
+            # committed `rocprofv3 --kernel-trace` of this same command, per grid shape: 3676 workgroups = the detection pass's
+            # launch capacity (300 ROIs), 1568 = the proposal-mask pass's (128); the live events above must agree with their mean
+            by_wg = {s_["workgroups"]: s_ for s_ in prof.get("shapes", [])}
+            sel = [by_wg[w_] for w_ in (3676, 1568) if w_ in by_wg]
+            if sel:
+                n_ = sum(s_["launches"] for s_ in sel)
+                roofline["rocprof"] = {"file": "profiles/r03_dominant_kernel_rocprof.json",
+                                       "avg_launch_ms": round(sum(s_["avg_us"] * s_["launches"] for s_ in sel) / n_ * 1e-3, 4),
+                                       "by_workgroups": {str(s_["workgroups"]): {"launches": s_["launches"], "avg_us": s_["avg_us"],
+                                                                                 "min_us": s_["min_us"]} for s_ in sel}}
         if ev_excl:
             d2 = [s_.elapsed_time(e_) for (s_, e_, _c) in ev_excl]
             f2 = [2.0 * r_ * 196 * 256 * 2304 for r_ in rows_of(ev_excl, excl_counts)]

@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--no-variants", dest="variants", action="store_false", help="skip the extra (non-headline) variant timings")
     ap.add_argument("--concurrent-scenes", type=int, default=0, help="with --batch: scenes in flight at once (0 = BatchedSequences decides)")
+    ap.add_argument("--lockstep", choices=["launches", "streams"], default="launches",
+                    help="with --batch: 'launches' = N = B through every stage, one launch per stage (modeling/lockstep.py); 'streams' = "
+                         "B scene objects on their own streams, only the trunk batched (modeling/batched.py)")
     ap.add_argument("--batch", type=int, default=1, help="B independent sequences per GPU in lock-step (BASELINE configs[4]: "
                     "--size 960 960 --grid 512 512 --cell 0.08 --batch 4); a step = B frames")
     return ap.parse_args()
@@ -360,7 +363,15 @@ def bench_batched(args):
     B = args.batch
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
                            "MODEL.MEMORY_CLS_SCORE_THRESH", args.memory_thresh, "MODEL.DEVICE", "cuda:0"])
-    model = BatchedSequences(cfg, B, synthetic_state_dict(0), concurrent_scenes=args.concurrent_scenes)
+    if args.lockstep == "launches":
+        from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+        model = LockstepScenes(cfg, B, synthetic_state_dict(0))
+        how = (f"N = {B} through every stage of the frame: one launch per stage for all scenes (trunk, memory read, tower, proposal "
+               f"decoding, cascade, selections, both mask passes over the concatenated ROI lists, memory write of the {B} states, paste)")
+    else:
+        model = BatchedSequences(cfg, B, synthetic_state_dict(0), concurrent_scenes=args.concurrent_scenes)
+        how = (f"the memory-independent trunk + FPN top-down run once per step with N = {B}, the scenes continue on their own streams "
+               f"({len(set(id(s_) for s_ in model.streams))} in flight)")
     n = args.warmup + args.steps
     eps = []
     for b in range(B):
@@ -386,10 +397,8 @@ def bench_batched(args):
         "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[4]: {B} independent sequences in lock-step per GPU, {H}x{W}, memory grid "
-                               f"{map_w}x{map_h} @ {args.cell} m; a step = {B} frames through the boundary (Instances materialised); the "
-                               f"memory-independent trunk + FPN top-down run once per step with N = {B}, the scenes continue on their "
-                               f"own streams", "batch": B, "scenes_in_flight": len(set(id(s_) for s_ in model.streams)),
-                   "detections_per_frame_mean": round(nd, 1)}}), flush=True)
+                               f"{map_w}x{map_h} @ {args.cell} m; a step = {B} frames through the boundary (Instances materialised); "
+                               + how, "batch": B, "lockstep": args.lockstep, "detections_per_frame_mean": round(nd, 1)}}), flush=True)
 
 
 def main():

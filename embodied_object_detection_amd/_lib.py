@@ -23,16 +23,21 @@ class EodError(RuntimeError):
 _ERR = {-1: "EOD_ERR_BAD_DIMS", -2: "EOD_ERR_ALIGN", -3: "EOD_ERR_LAUNCH", -4: "EOD_ERR_NULL", -5: "EOD_ERR_CAPACITY"}
 
 
+MAX_BATCH = 8       # EOD_MAX_BATCH
+MAX_LEVELS = 40     # EOD_MAX_LEVELS
+
+
 class EodConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("m_count", C.c_void_p), ("m_unit", C.c_int32),
+        ("m_segments", C.c_int32),
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("Kpad", C.c_int32), ("relu", C.c_int32), ("res_mode", C.c_int32), ("in_relu", C.c_int32),
         ("out_mode", C.c_int32), ("tap4", C.c_int32), ("force_tile", C.c_int32), ("force_splitk", C.c_int32),
-        ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * 6), ("level_h", C.c_int32 * 5),
-        ("level_w", C.c_int32 * 5), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
+        ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * (MAX_LEVELS + 1)), ("level_h", C.c_int32 * MAX_LEVELS),
+        ("level_w", C.c_int32 * MAX_LEVELS), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
         ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32), ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
         ("y2", C.c_void_p), ("split_n", C.c_int32), ("prefetch2", C.c_int32),
     ]
@@ -44,7 +49,7 @@ class EodProposalDesc(C.Structure):
         ("level_w", C.c_int32 * 5), ("level_stride", C.c_int32 * 5), ("level_scale", C.c_float * 5),
         ("score_thresh", C.c_float), ("pre_nms_topk", C.c_int32), ("post_nms_topk", C.c_int32), ("nms_thresh", C.c_float),
         ("cap", C.c_int32), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_count", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("batch", C.c_int32),
     ]
 
 
@@ -55,7 +60,7 @@ class EodDetDesc(C.Structure):
         ("topk", C.c_int32), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p), ("out_classes", C.c_void_p),
         ("out_rows", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("out_unique_rows", C.c_void_p), ("out_unique_count", C.c_void_p), ("unique_cap", C.c_int32),
-        ("out_rep_of", C.c_void_p), ("out_rep_list", C.c_void_p), ("out_rep_count", C.c_void_p),
+        ("out_rep_of", C.c_void_p), ("out_rep_list", C.c_void_p), ("out_rep_count", C.c_void_p), ("batch", C.c_int32),
     ]
 
 
@@ -66,6 +71,7 @@ class EodMemWriteDesc(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("D", C.c_int32), ("n_cells", C.c_int32), ("mask_thresh", C.c_float),
         ("mem", C.c_void_p), ("obs", C.c_void_p), ("k_out", C.c_void_p), ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t), ("dirty", C.c_void_p), ("err_flags", C.c_void_p), ("snapshot_f16", C.c_void_p),
+        ("batch", C.c_int32),
     ]
 
 
@@ -89,33 +95,34 @@ SIGNATURES = {
     "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "eod_roi_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),
     "eod_zs_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                  C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+                                  C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "eod_apply_deltas": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
-                                   C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+                                   C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "eod_cascade_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "eod_detections_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "eod_fast_rcnn_inference": (C.c_int, [C.POINTER(EodDetDesc), C.c_void_p]),
     "eod_detector_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_int, C.c_void_p]),
+    "eod_concat_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_paste_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_unproject_grid_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                            C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_memory_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_normalize_dirty_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_gather_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_int, C.c_void_p]),
+                                         C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_pooled_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "eod_memory_project_weights_bytes": (C.c_size_t, []),
     "eod_memory_project_prepare": (C.c_int, [C.c_void_p] * 8),
-    "eod_memory_project_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "eod_memory_project_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_project_backward_weights": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 7),
     "eod_memory_pool_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5),
     "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

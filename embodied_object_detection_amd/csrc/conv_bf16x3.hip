@@ -61,17 +61,14 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   int M = p.M;
-  if (p.m_count) {
-    const int c = *p.m_count;
-    const int lim = c * p.m_unit;
-    M = lim < M ? lim : M;
-  }
+  M = conv_row_limit(p, M);
   const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   if ((int)blockIdx.x >= ntiles) return;
   const int t = xcd_remap(blockIdx.x, ntiles);
   const int tile_m = t / p.tiles_n;
   const int tile_n = t - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!conv_tile_active(p, m0, BM)) return;
   const int z = blockIdx.y;
   const int c_begin = z * p.cps;
   int c_end = c_begin + p.cps;
@@ -297,17 +294,14 @@ __global__ __launch_bounds__(512) void conv_bf16x3_w8_kernel(ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   int M = p.M;
-  if (p.m_count) {
-    const int c = *p.m_count;
-    const int lim = c * p.m_unit;
-    M = lim < M ? lim : M;
-  }
+  M = conv_row_limit(p, M);
   const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   if ((int)blockIdx.x >= ntiles) return;
   const int t = xcd_remap(blockIdx.x, ntiles);
   const int tile_m = t / p.tiles_n;
   const int tile_n = t - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!conv_tile_active(p, m0, BM)) return;
   const int z = blockIdx.y;
   const int c_begin = z * p.cps;
   int c_end = c_begin + p.cps;

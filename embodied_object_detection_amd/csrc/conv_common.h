@@ -3,6 +3,7 @@
 // argument checks and the C ABI live in conv_igemm.hip.
 #pragma once
 #include "eod_common.h"
+#include "../../include/eod_hip.h"
 
 namespace eodconv {
 
@@ -16,6 +17,7 @@ struct ConvArgs {
   float* partial;
   const int* m_count;
   int m_unit;
+  int m_segs, seg_rows;     // m_segs > 1: m_count holds m_segs counts, one per run of seg_rows output rows (EodConvDesc.m_segments)
   const float* fuse_w;      // out_mode 2: predictor weights / bias / unit scatter
   const int* out_units;
   float fuse_b;
@@ -26,7 +28,7 @@ struct ConvArgs {
   float out_scale;
   // multi-level mode (shared-weight head over the FPN pyramid): rows [lv_off[l], lv_off[l+1]) form an lv_h[l] x lv_w[l] image
   int nlv;
-  int lv_off[6], lv_h[5], lv_w[5];
+  int lv_off[EOD_MAX_LEVELS + 1], lv_h[EOD_MAX_LEVELS], lv_w[EOD_MAX_LEVELS];
   unsigned x_bytes, w_bytes;   // sizes of the two operand buffers (range of the buffer descriptors)
   const void* w3;              // optional pre-split weights of the bf16x3 kernels (eod_conv_split_weights_bf16x3)
   unsigned w3_bytes;
@@ -36,6 +38,33 @@ struct ConvArgs {
   int split_n;                 // [0, split_n) to y [M, split_n] (never with the ReLU): two linear layers on one input as one GEMM
   FastDiv div_ow, div_oh, div_cd, div_row;
 };
+
+// Rows that hold work under the device-side count.  One count: rows [0, count * m_unit).  m_segs > 1 (independent ROI lists back to
+// back, seg_rows rows each): row m holds work iff (m mod seg_rows) < count[m / seg_rows] * m_unit; the row limit then stays p.M and
+// whole tiles without work leave early (conv_tile_active).
+__device__ __forceinline__ int conv_row_limit(const ConvArgs& p, int M) {
+  if (p.m_count && p.m_segs <= 1) {
+    const int lim = *p.m_count * p.m_unit;
+    M = lim < M ? lim : M;
+  }
+  return M;
+}
+
+__device__ __forceinline__ bool conv_row_active(const ConvArgs& p, int m) {
+  if (!p.m_count || p.m_segs <= 1) return true;      // the single count is applied through the row limit
+  const int s = m / p.seg_rows;
+  return m - s * p.seg_rows < p.m_count[s] * p.m_unit;
+}
+
+__device__ __forceinline__ bool conv_tile_active(const ConvArgs& p, int m0, int bm) {
+  if (!p.m_count || p.m_segs <= 1) return true;
+  const int last = (m0 + bm - 1 < p.M ? m0 + bm - 1 : p.M - 1);
+  const int s0 = m0 / p.seg_rows, s1 = last / p.seg_rows;
+  if (m0 - s0 * p.seg_rows < p.m_count[s0] * p.m_unit) return true;
+  for (int s = s0 + 1; s <= s1; ++s)
+    if (p.m_count[s] > 0) return true;
+  return false;
+}
 
 __device__ __forceinline__ float epilogue_store(const ConvArgs& p, float v, int m, int n) {
   int co = n;

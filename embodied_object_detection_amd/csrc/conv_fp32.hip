@@ -53,11 +53,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   int M = p.M;
-  if (p.m_count) {
-    const int c = *p.m_count;
-    const int lim = c * p.m_unit;
-    M = lim < M ? lim : M;
-  }
+  M = conv_row_limit(p, M);
   // Only the tiles that hold valid rows do work; the XCD remap is taken over THAT count so that a short dynamic
   // row count (e.g. 256 of 320 ROI slots) still spreads evenly over the 8 XCDs instead of idling the last ones.
   const int ntiles = ((M + BM - 1) / BM) * p.tiles_n;
@@ -66,6 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int tile_m = t / p.tiles_n;
   const int tile_n = t - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (!conv_tile_active(p, m0, BM)) return;
 
   const int z = blockIdx.y;
   const int c_begin = z * p.cps;
@@ -371,17 +368,14 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
   float* Bs = As + 32 * LS;
 
   int M = p.M;
-  if (p.m_count) {
-    const int c = *p.m_count;
-    const int lim = c * p.m_unit;
-    M = lim < M ? lim : M;
-  }
+  M = conv_row_limit(p, M);
   const int ntiles = ((M + 31) / 32) * p.tiles_n;
   if ((int)blockIdx.x >= ntiles) return;
   const int t = xcd_remap(blockIdx.x, ntiles);
   const int tile_m = t / p.tiles_n;
   const int tile_n = t - tile_m * p.tiles_n;
   const int m0 = tile_m * 32, n0 = tile_n * 32;
+  if (!conv_tile_active(p, m0, 32)) return;
 
   // this wave's chunks
   const int cpw = (p.nchunks + NW - 1) / NW;

@@ -19,17 +19,13 @@ using namespace eodconv;
 template <int VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
   EOD_CHAIN_PRIO();
-  int M = p.M;
-  if (p.m_count) {
-    const int c = *p.m_count;
-    const int lim = c * p.m_unit;
-    M = lim < M ? lim : M;
-  }
+  const int M = conv_row_limit(p, p.M);
   const unsigned per_row = (unsigned)p.Cout / VEC;
   const unsigned total = (unsigned)M * per_row;
   const size_t slab = (size_t)p.M * p.Cout;
   for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const unsigned m = fdiv(idx, p.div_row);
+    if (!conv_row_active(p, (int)m)) continue;          // segmented counts: the tile that would have written this row's slabs left early
     const unsigned n = (idx - m * per_row) * VEC;
     const float* src = p.partial + (size_t)m * p.Cout + n;
     if (VEC == 4) {
@@ -250,7 +246,7 @@ int check_desc(const EodConvDesc* d) {
   }
   if (d->levels > 0) {
     // pyramid mode: stride-1 'same' conv over up to 5 level images stored back to back
-    if (d->levels > 5 || d->N != 1 || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2 || d->tap4 || d->out_mode != 0 ||
+    if (d->levels > EOD_MAX_LEVELS || d->N != 1 || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2 || d->tap4 || d->out_mode != 0 ||
         d->res_mode == 2 || d->level_off[0] != 0)
       return EOD_ERR_BAD_DIMS;
     for (int l = 0; l < d->levels; ++l)
@@ -276,6 +272,11 @@ int check_desc(const EodConvDesc* d) {
   if (d->res_mode != 0 && !d->res) return EOD_ERR_NULL;
   if (d->res_mode == 2 && ((d->OH & 1) || (d->OW & 1))) return EOD_ERR_BAD_DIMS;
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
+  if (d->m_segments > 1) {
+    // B unit lists back to back: whole images per list, a count per list
+    if (!d->m_count || d->levels > 0 || d->m_segments > EOD_MAX_BATCH || d->N % d->m_segments != 0) return EOD_ERR_BAD_DIMS;
+    if (((long)(d->N / d->m_segments) * d->OH * d->OW) % d->m_unit != 0) return EOD_ERR_BAD_DIMS;
+  }
   if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;
   if (d->split_n != 0) {
     if (!d->y2) return EOD_ERR_NULL;
@@ -338,6 +339,8 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->res; a.y = d->y;
   a.partial = d->workspace;
   a.m_count = d->m_count; a.m_unit = d->m_unit;
+  a.m_segs = d->m_segments > 1 ? d->m_segments : 1;
+  a.seg_rows = a.m_segs > 1 ? (d->N / d->m_segments) * d->OH * d->OW : 0;
   a.fuse_w = d->fuse_w; a.out_units = d->out_units; a.fuse_b = d->fuse_b;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Kpad = d->Kpad;

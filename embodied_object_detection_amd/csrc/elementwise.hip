@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
 }
 
 struct LevelOff {
-  int off[9];
+  int off[EOD_MAX_LEVELS + 1];   // 5 levels x up to EOD_MAX_BATCH scenes in lock-step: every (level, scene) image has its own statistics
   int levels;
 };
 
@@ -288,7 +288,7 @@ extern "C" int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, i
 }
 
 extern "C" size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, int levels, int groups) {
-  if (!level_off_host || levels < 1 || levels > 8) return 0;
+  if (!level_off_host || levels < 1 || levels > EOD_MAX_LEVELS) return 0;
   size_t chunks = 0;
   for (int i = 0; i < levels; ++i) chunks += (size_t)(level_off_host[i + 1] - level_off_host[i] + GN_ROWS - 1) / GN_ROWS;
   return ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8 + chunks * groups * 2 * sizeof(double);
@@ -301,7 +301,7 @@ extern "C" size_t eod_groupnorm_partial_offset(int levels, int groups) {
 extern "C" int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float* beta, const int32_t* level_off_host,
                                   int levels, int C, int groups, float eps, float* stats, int partial_ready, eod_stream_t stream) {
   if (!x || !y || !gamma || !beta || !level_off_host || !stats) return EOD_ERR_NULL;
-  if (levels < 1 || levels > 8 || C % groups != 0 || C % 4 != 0 || (C / groups) % 4 != 0) return EOD_ERR_BAD_DIMS;
+  if (levels < 1 || levels > EOD_MAX_LEVELS || C % groups != 0 || C % 4 != 0 || (C / groups) % 4 != 0) return EOD_ERR_BAD_DIMS;
   LevelOff lo{};
   lo.levels = levels;
   for (int i = 0; i <= levels; ++i) lo.off[i] = level_off_host[i];

@@ -13,6 +13,13 @@ __device__ __forceinline__ int dyn_rows(const int* count, int cap) {
   return c < cap ? c : cap;
 }
 
+// B ROI lists back to back (EOD batch convention): row r of R_cap * batch holds work iff (r mod R_cap) < count[r / R_cap]
+__device__ __forceinline__ bool row_has_work(const int* count, int R_cap, int row) {
+  const int s = row / R_cap;
+  const int c = count ? count[s] : R_cap;
+  return row - s * R_cap < (c < R_cap ? c : R_cap);
+}
+
 // one wave per row, 4 rows per workgroup.  feat [R,D] (D = 512 -> 8 per lane).  The class matrix zs [D,C1] is staged once per
 // workgroup in LDS, transposed to [c][k], so that every class costs two conflict-free ds_read_b128 per lane instead of eight
 // strided global loads behind a dependent chain (80 / 37 us -> a few us on the cascade's critical path).  Same arithmetic and
@@ -22,11 +29,11 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
                                                            const int* __restrict__ count, int R_cap, int D, int C1, float temp,
                                                            const float* __restrict__ zs_mem, const float* __restrict__ prop_scores,
-                                                           float* __restrict__ mem_scores, float final_inv_stages) {
+                                                           float* __restrict__ mem_scores, float final_inv_stages, int batch) {
   EOD_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
-  const int R = dyn_rows(count, R_cap);
-  if ((int)(blockIdx.x * 4) >= R) return;    // whole workgroup beyond the count
+  // R_cap % 4 == 0 whenever the rows are a batch of lists: a workgroup's four rows belong to one list
+  if (!row_has_work(count, R_cap, (int)(blockIdx.x * 4))) return;    // whole workgroup beyond its list's count
   for (int i = threadIdx.x; i < D * C1; i += blockDim.x) {
     const int k = i / C1, c = i - k * C1;    // coalesced read of zs[k][c]
     zt[c * 512 + k] = zs[i];
@@ -34,7 +41,7 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const bool active = row < R;
+  const bool active = row < R_cap * batch && row_has_work(count, R_cap, row);
   float x[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) x[q] = 0.f;
@@ -96,11 +103,10 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
 
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, float* __restrict__ out,
                                     const int* __restrict__ count, int R_cap, float wx, float wy, float ww, float wh, int clip,
-                                    float img_w, float img_h) {
+                                    float img_w, float img_h, int batch) {
   EOD_CHAIN_PRIO();
-  const int R = dyn_rows(count, R_cap);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+  if (r >= R_cap * batch || !row_has_work(count, R_cap, r)) return;
   const float x1 = boxes[r * 4 + 0], y1 = boxes[r * 4 + 1], x2 = boxes[r * 4 + 2], y2 = boxes[r * 4 + 3];
   const float w = x2 - x1, h = y2 - y1;
   const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
@@ -156,13 +162,18 @@ __global__ __launch_bounds__(256) void memory_scores_kernel(const float* __restr
 }
 
 // detector_postprocess: scale, clip, drop empty boxes (single block)
-__global__ __launch_bounds__(512) void postprocess_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                           const int* __restrict__ classes, const int* __restrict__ count, int cap,
-                                                           float sx, float sy, float out_w, float out_h, float* __restrict__ ob,
-                                                           float* __restrict__ os, int* __restrict__ oc, int* __restrict__ osrc,
-                                                           int* __restrict__ ocount, const int* __restrict__ remap) {
+__global__ __launch_bounds__(512) void postprocess_kernel(const float* boxes, const float* scores, const int* classes, const int* count,
+                                                           int cap, float sx, float sy, float out_w, float out_h, float* ob, float* os,
+                                                           int* oc, int* osrc, int* ocount, const int* remap) {
   __shared__ int sh_keep[512];
   __shared__ int sh_pos[512];
+  {
+    const int b = blockIdx.x;         // scene of a batch: every buffer is `batch` single-scene buffers back to back
+    boxes += (size_t)b * cap * 4; scores += (size_t)b * cap; classes += (size_t)b * cap;
+    if (count) count += b;
+    ob += (size_t)b * cap * 4; os += (size_t)b * cap; oc += (size_t)b * cap; osrc += (size_t)b * cap; ocount += b;
+    if (remap) remap += (size_t)b * cap;
+  }
   const int D = dyn_rows(count, cap);
   const int t = threadIdx.x;
   float b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -199,9 +210,15 @@ __global__ __launch_bounds__(512) void postprocess_kernel(const float* __restric
 
 // grid (pixel tiles, K).  Exact op order of F.grid_sample(bilinear, zeros, align_corners=False) on the
 // normalised grid detectron2 builds in _do_paste_mask.
-__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ prob, const float* __restrict__ boxes,
-                                                           const int* __restrict__ rows, const int* __restrict__ count, int K_cap, int H,
-                                                           int W, float thr, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* prob, const float* boxes, const int* rows, const int* count,
+                                                           int K_cap, int H, int W, float thr, uint8_t* out, int prob_units) {
+  {
+    const int b = blockIdx.z;         // scene of a batch
+    prob += (size_t)b * prob_units * 784; boxes += (size_t)b * K_cap * 4;
+    if (rows) rows += (size_t)b * K_cap;
+    if (count) count += b;
+    out += (size_t)b * K_cap * H * W;
+  }
   const int K = dyn_rows(count, K_cap);
   const int k = blockIdx.y;
   if (k >= K) return;
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 
 extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_acc, int accumulate, float* feat_norm_out,
                                const int32_t* count, int R_cap, int D, int C1, float temp, const float* zs_mem, const float* prop_scores,
-                               float* mem_scores_out, float final_inv_stages, eod_stream_t stream) {
+                               float* mem_scores_out, float final_inv_stages, int batch, eod_stream_t stream) {
   if (!feat || !zs || !prob_acc) return EOD_ERR_NULL;
   if (zs_mem && (!prop_scores || !mem_scores_out)) return EOD_ERR_NULL;
   if (final_inv_stages > 0.f && !prop_scores) return EOD_ERR_NULL;
@@ -267,17 +284,20 @@ extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_a
   if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
   if (C1 > ZS_MAX_C) return EOD_ERR_CAPACITY;
   if (!eod_aligned16(feat) || (feat_norm_out && !eod_aligned16(feat_norm_out))) return EOD_ERR_ALIGN;
-  hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
-                     feat_norm_out, count, R_cap, D, C1, temp, zs_mem, prop_scores, mem_scores_out, final_inv_stages);
+  if (batch > 1 && (batch > EOD_MAX_BATCH || R_cap % 4 != 0)) return EOD_ERR_BAD_DIMS;
+  const int nb = batch > 1 ? batch : 1;
+  hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap * nb + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
+                     feat_norm_out, count, R_cap, D, C1, temp, zs_mem, prop_scores, mem_scores_out, final_inv_stages, nb);
   return eod_launch_status();
 }
 
 extern "C" int eod_apply_deltas(const float* deltas, int ld, const float* boxes, float* out, const int32_t* count, int R_cap, float wx,
-                                float wy, float ww, float wh, int clip, float img_w, float img_h, eod_stream_t stream) {
+                                float wy, float ww, float wh, int clip, float img_w, float img_h, int batch, eod_stream_t stream) {
   if (!deltas || !boxes || !out) return EOD_ERR_NULL;
-  if (ld < 4 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
-  hipLaunchKernelGGL(apply_deltas_kernel, dim3((R_cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas, ld, boxes, out, count,
-                     R_cap, wx, wy, ww, wh, clip, img_w, img_h);
+  if (ld < 4 || R_cap <= 0 || batch > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  const int nb = batch > 1 ? batch : 1;
+  hipLaunchKernelGGL(apply_deltas_kernel, dim3((R_cap * nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas, ld, boxes, out, count,
+                     R_cap, wx, wy, ww, wh, clip, img_w, img_h, nb);
   return eod_launch_status();
 }
 
@@ -302,21 +322,22 @@ extern "C" int eod_memory_scores(const float* featn, const float* zs, const floa
 extern "C" int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
                                         float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
                                         int32_t* out_classes, int32_t* out_src, int32_t* out_count, const int32_t* remap,
-                                        eod_stream_t stream) {
+                                        int batch, eod_stream_t stream) {
   if (!boxes || !scores || !classes || !out_boxes || !out_scores || !out_classes || !out_src || !out_count) return EOD_ERR_NULL;
   if (cap <= 0 || cap > 512) return EOD_ERR_CAPACITY;
-  hipLaunchKernelGGL(postprocess_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, boxes, scores, classes, count, cap, sx, sy, out_w,
+  if (batch > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(postprocess_kernel, dim3(batch > 1 ? batch : 1), dim3(512), 0, (hipStream_t)stream, boxes, scores, classes, count, cap, sx, sy, out_w,
                      out_h, out_boxes, out_scores, out_classes, out_src, out_count, remap);
   return eod_launch_status();
 }
 
 extern "C" int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap, int H, int W,
-                               float threshold, uint8_t* out, eod_stream_t stream) {
+                               float threshold, uint8_t* out, int batch, int prob_units, eod_stream_t stream) {
   if (!prob || !boxes || !out) return EOD_ERR_NULL;
-  if (K_cap <= 0 || H <= 0 || W <= 0 || (W & 15)) return EOD_ERR_BAD_DIMS;
+  if (K_cap <= 0 || H <= 0 || W <= 0 || (W & 15) || batch > EOD_MAX_BATCH || (batch > 1 && prob_units <= 0)) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(out)) return EOD_ERR_ALIGN;
   int tiles = (H * W / 16 + 256 * 2 - 1) / (256 * 2);
-  hipLaunchKernelGGL(paste_masks_kernel, dim3(tiles, K_cap), dim3(256), 0, (hipStream_t)stream, prob, boxes, rows, count, K_cap, H, W,
-                     threshold, out);
+  hipLaunchKernelGGL(paste_masks_kernel, dim3(tiles, K_cap, batch > 1 ? batch : 1), dim3(256), 0, (hipStream_t)stream, prob, boxes, rows,
+                     count, K_cap, H, W, threshold, out, batch > 1 ? prob_units : 0);
   return eod_launch_status();
 }

@@ -116,6 +116,12 @@ struct MwWs {
 
 inline size_t up(size_t v) { return (v + 255) / 256 * 256; }
 
+// scene b of a batch (blockIdx.y of the three write kernels): a workspace pointer of scene 0 moved to scene b's workspace
+template <class T>
+__device__ __forceinline__ T* scene_ws(T* p, size_t ws_stride) {
+  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)blockIdx.y * ws_stride);
+}
+
 MwWs mw_carve(void* base, int H, int W, int D, int n_cells, int R_cap, int K_cap) {
   (void)D;
   MwWs w{};
@@ -292,15 +298,20 @@ __device__ __forceinline__ bool mask_hit_row(const float* __restrict__ m, const 
 }
 
 // Launch 1.  Block = 1024 threads = 1024 consecutive pixels.
-__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                         const int* __restrict__ det_rows, const int* __restrict__ det_count, int K_cap,
-                                                         int R_cap, const int* __restrict__ proj, int H, int W, int n_cells, float thr,
-                                                         unsigned char* __restrict__ cover, int* __restrict__ cell_flag,
-                                                         int* __restrict__ blk_pix, int* __restrict__ inst_rows, int* __restrict__ k_u,
-                                                         int* __restrict__ k_out, int* __restrict__ err) {
+__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* boxes, const float* masks, const int* det_rows, const int* det_count,
+                                                         int K_cap, int R_cap, const int* proj, int H, int W, int n_cells, float thr,
+                                                         unsigned char* cover, int* cell_flag, int* blk_pix, int* inst_rows, int* k_u,
+                                                         int* k_out, int* __restrict__ err, size_t ws_stride) {
   EOD_CHAIN_PRIO();
   __shared__ int flag_s[MW_MAX_R], wcnt_s[8], rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s;
   __shared__ float box_s[MW_MAX_K * 4];
+  if (blockIdx.y) {
+    const size_t b = blockIdx.y;
+    boxes += b * R_cap * 4; masks += b * (size_t)R_cap * 784; det_rows += b * K_cap; det_count += b; proj += b * (size_t)H * W;
+    cover = scene_ws(cover, ws_stride); cell_flag = scene_ws(cell_flag, ws_stride); blk_pix = scene_ws(blk_pix, ws_stride);
+    inst_rows = scene_ws(inst_rows, ws_stride); k_u = scene_ws(k_u, ws_stride);
+    if (k_out) k_out += b;
+  }
   const int K = block_unique_rows(det_rows, det_count, K_cap, R_cap, flag_s, wcnt_s, rows_s);
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < K; i += blockDim.x) inst_rows[i] = rows_s[i];
@@ -346,12 +357,17 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* __restrict_
 //   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
 // so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
 // bitwise reproducible) instead of 512 channel atomics.
-__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
-                                                           const int* __restrict__ inst_rows, const int* __restrict__ k_u,
-                                                           const unsigned char* __restrict__ cover, const int* __restrict__ blk_pix,
-                                                           const int* __restrict__ proj, int H, int W, int n_cells, int K_cap, float thr,
-                                                           long long* __restrict__ wtab, int* __restrict__ cell_cnt) {
+__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* boxes, const float* masks, const int* inst_rows, const int* k_u,
+                                                           const unsigned char* cover, const int* blk_pix, const int* proj, int H, int W,
+                                                           int n_cells, int K_cap, float thr, long long* wtab, int* cell_cnt, int R_cap,
+                                                           size_t ws_stride) {
   EOD_CHAIN_PRIO();
+  if (blockIdx.y) {
+    const size_t b = blockIdx.y;
+    boxes += b * R_cap * 4; masks += b * (size_t)R_cap * 784; proj += b * (size_t)H * W;
+    inst_rows = scene_ws(inst_rows, ws_stride); k_u = scene_ws(k_u, ws_stride); cover = scene_ws(cover, ws_stride);
+    blk_pix = scene_ws(blk_pix, ws_stride); wtab = scene_ws(wtab, ws_stride); cell_cnt = scene_ws(cell_cnt, ws_stride);
+  }
   const int K = *k_u;
   if (K == 0) return;
   __shared__ int rows_s[MW_MAX_K], cand_s[MW_MAX_K], ncand_s, sh_off;
@@ -415,11 +431,18 @@ __global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* __restric
 // at the start of the next frame, without its launch and its scan of the flags) or its `dirty` mark.  Resets the per-frame
 // tables it consumed (flags, counts, weight-table entries).
 template <bool SNAPSHOT>
-__global__ __launch_bounds__(256) void mw_commit_kernel(int* __restrict__ cell_flag, int* __restrict__ cell_cnt, long long* __restrict__ wtab,
-                                                         const int* __restrict__ k_u, const int* __restrict__ inst_rows,
-                                                         const float* __restrict__ featn, int K_cap, int N, float* __restrict__ obs,
-                                                         float* __restrict__ mem, __half* __restrict__ snapshot, int* __restrict__ dirty) {
+__global__ __launch_bounds__(256) void mw_commit_kernel(int* cell_flag, int* cell_cnt, long long* wtab, const int* k_u, const int* inst_rows,
+                                                         const float* featn, int K_cap, int N, float* obs, float* mem, __half* snapshot,
+                                                         int* dirty, int R_cap, size_t ws_stride) {
   EOD_CHAIN_PRIO();
+  if (blockIdx.y) {
+    const size_t b = blockIdx.y;
+    cell_flag = scene_ws(cell_flag, ws_stride); cell_cnt = scene_ws(cell_cnt, ws_stride); wtab = scene_ws(wtab, ws_stride);
+    k_u = scene_ws(k_u, ws_stride); inst_rows = scene_ws(inst_rows, ws_stride);
+    featn += b * (size_t)R_cap * 512; obs += b * (size_t)N; mem += b * (size_t)N * 512;
+    if (SNAPSHOT) snapshot += b * (size_t)N * 512;
+    if (dirty) dirty += b * (size_t)N;
+  }
   const int K = *k_u;
   if (K == 0) return;
   const int lane = threadIdx.x & 63;
@@ -539,19 +562,23 @@ extern "C" int eod_memory_normalize_f16(const float* mem, const float* obs, uint
 }
 
 extern "C" size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap) {
-  return mw_carve(nullptr, H, W, D, n_cells, R_cap, K_cap).bytes;
+  return mw_carve(nullptr, H, W, D, n_cells, R_cap, K_cap).bytes;      // one scene; a batch needs `batch` times this
 }
 
 extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, int H, int W, int D, int n_cells, int K_cap, int R_cap,
                                      eod_stream_t stream) {
-  // the per-frame cell tables must start at zero; every eod_memory_write leaves them zero again
+  // the per-frame cell tables must start at zero; every eod_memory_write leaves them zero again.  A workspace of B scenes
+  // (workspace_bytes >= B x the single-scene size) is initialised scene by scene.
   if (!workspace) return EOD_ERR_NULL;
   if (K_cap <= 0 || K_cap > MW_MAX_K || R_cap <= 0 || R_cap > MW_MAX_R) return EOD_ERR_BAD_DIMS;
-  const MwWs w = mw_carve(workspace, H, W, D, n_cells, R_cap, K_cap);
-  if (workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
-  if (hipMemsetAsync(w.cell_flag, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
-  if (hipMemsetAsync(w.cell_cnt, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
-  if (hipMemsetAsync(w.wtab, 0, (size_t)n_cells * (size_t)K_cap * 8, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  const size_t one = mw_carve(nullptr, H, W, D, n_cells, R_cap, K_cap).bytes;
+  if (workspace_bytes < one) return EOD_ERR_CAPACITY;
+  for (size_t b = 0; (b + 1) * one <= workspace_bytes && b < EOD_MAX_BATCH; ++b) {
+    const MwWs w = mw_carve(static_cast<char*>(workspace) + b * one, H, W, D, n_cells, R_cap, K_cap);
+    if (hipMemsetAsync(w.cell_flag, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+    if (hipMemsetAsync(w.cell_cnt, 0, (size_t)n_cells * 4, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+    if (hipMemsetAsync(w.wtab, 0, (size_t)n_cells * (size_t)K_cap * 8, (hipStream_t)stream) != hipSuccess) return EOD_ERR_LAUNCH;
+  }
   return eod_launch_status();
 }
 
@@ -571,26 +598,30 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
       d->K_cap > MW_MAX_K)
     return EOD_ERR_BAD_DIMS;
   const MwWs w = mw_carve(d->workspace, d->H, d->W, d->D, d->n_cells, d->R_cap, d->K_cap);
-  if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
+  const int nb = d->batch > 1 ? d->batch : 1;
+  if (nb > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  if (d->workspace_bytes < w.bytes * nb) return EOD_ERR_CAPACITY;
   if (!eod_aligned16(d->mem) || !eod_aligned16(d->featn) || (d->snapshot_f16 && !eod_aligned16(d->snapshot_f16))) return EOD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int P = d->H * d->W;
   const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS;
-  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
+  const size_t wss = w.bytes;      // scene b's workspace starts b * wss bytes further (every carved piece is 256-byte aligned)
+  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb, nb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
                      d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, w.blk_pix, w.inst_rows, w.k_u, d->k_out,
-                     d->err_flags);
-  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
-                     d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt);
+                     d->err_flags, wss);
+  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb, nb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
+                     d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt, d->R_cap, wss);
   // one workgroup per CU at most: the kernel runs beside dense launches of other streams, where every workgroup dispatch waits
   // for a slot; a workgroup walks its 64-cell groups in a grid-stride loop
   int groups = (d->n_cells + 63) / 64;
   if (groups > 256) groups = 256;
+  if (nb > 1 && groups > 256 / nb) groups = 256 / nb;
   if (d->snapshot_f16)
-    hipLaunchKernelGGL(mw_commit_kernel<true>, dim3(groups), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
-                       d->K_cap, d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16), (int*)nullptr);
+    hipLaunchKernelGGL(mw_commit_kernel<true>, dim3(groups, nb), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16), (int*)nullptr, d->R_cap, wss);
   else
-    hipLaunchKernelGGL(mw_commit_kernel<false>, dim3(groups), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows,
-                       d->featn, d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty);
+    hipLaunchKernelGGL(mw_commit_kernel<false>, dim3(groups, nb), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows,
+                       d->featn, d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty, d->R_cap, wss);
   return eod_launch_status();
 }
 

@@ -134,10 +134,16 @@ __device__ __forceinline__ size_t frag_half_offset(int tile32, int r, int c8) {
 // (in-kernel stamps: ~8 cycles per instruction and wave, two waves per SIMD): the per-block (cell, count) lists are built once per
 // wave in vector code, 16 blocks in parallel, and a block then costs ~12 instructions per distinct cell instead of ~180.
 template <bool TORCH_ORDER>
-__global__ __launch_bounds__(256) void gather_pool_kernel(const __half* __restrict__ mem, const int* __restrict__ proj, int H, int W,
-                                                           int n_cells, __half* __restrict__ pooled, int* __restrict__ err) {
+__global__ __launch_bounds__(256) void gather_pool_kernel(const __half* mem, const int* proj, int H, int W, int n_cells, __half* pooled,
+                                                           int* __restrict__ err, size_t pooled_halves) {
   EOD_CHAIN_PRIO();
   static_assert(GP_CAP <= 16, "slot ids must fit a nibble");
+  {
+    const size_t b = blockIdx.y;        // scene of a batch: its own table, index image and pooled rows
+    mem += b * (size_t)n_cells * 512;
+    proj += b * (size_t)H * W;
+    pooled += b * pooled_halves;
+  }
   // LDS: per wave GP_CAP rows of 1 KiB, then the stride-16 exchange buffer
   extern __shared__ __align__(1024) unsigned char smem_raw[];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -487,17 +493,26 @@ struct ProjArgs {
   int frag_tile_off[3]; // first 32-row fragment tile of each level in the pooled buffer
   float weight;         // MODEL.MAP_FEATURE_WEIGHT
   int mode;             // 0: P = (x.W + b) * weight + P   (sum)     1: P = (x.W + b) * weight   (mem_only)
+  int batch;            // scenes in lock-step (grid.y)
+  size_t pooled_halves; // one scene's pooled buffer
 };
 
 // Workgroup = 64 rows x 128 columns, 4 waves; wave w owns columns [128 half + 32 w, +32) for both 32-row tiles: per k-step
 // 2 A + 2 B fragment loads (1 KiB each, contiguous) feed 4 MFMAs.  Small tiles on purpose: the op is 2.2 GFLOP, what matters
 // is how many bytes are in flight per CU (264 workgroups at 640x640, 2 per CU fit).
-__global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Wsplit,
+__global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* X, const _Float16* __restrict__ Wsplit,
                                                             const float* __restrict__ sinv, const float* __restrict__ bias,
-                                                            float* __restrict__ P, ProjArgs a) {
+                                                            float* P, ProjArgs a) {
   EOD_CHAIN_PRIO();
   const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int lvl = t >= a.tile_off[2] ? 2 : (t >= a.tile_off[1] ? 1 : 0);
+  if (a.batch > 1) {
+    // scene b of a batch: its own pooled rows; `feats` is level major over the scenes, level l of scene b starts at row
+    // batch * level_off[l] + b * rows_l
+    const size_t b = blockIdx.y;
+    X += b * a.pooled_halves;
+    P += ((size_t)(a.batch - 1) * a.level_off[lvl] + b * (size_t)(a.level_off[lvl + 1] - a.level_off[lvl])) * 256;
+  }
   const int row0 = a.level_off[lvl] + (t - a.tile_off[lvl]) * 64;
   const int row_end = a.level_off[lvl + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -594,9 +609,10 @@ extern "C" int eod_memory_normalize_dirty_f16(const float* mem, const float* obs
 }
 
 extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells, uint16_t* pooled_f16,
-                                      int32_t* err_flags, int torch_order, eod_stream_t stream) {
+                                      int32_t* err_flags, int torch_order, int batch, eod_stream_t stream) {
   if (!mem_f16 || !proj || !pooled_f16) return EOD_ERR_NULL;
-  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22)) return EOD_ERR_BAD_DIMS;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || D != 512 || n_cells <= 0 || n_cells > (1 << 22) || batch > EOD_MAX_BATCH)
+    return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(mem_f16) || !eod_aligned16(pooled_f16) || !eod_aligned16(proj)) return EOD_ERR_ALIGN;
   const size_t lds = (size_t)4 * GP_CAP * 1024 + 4 * 512 * sizeof(float);
   // the attribute belongs to the (device, function) pair: one flag per device ordinal, set under a mutex (a second device in the
@@ -615,13 +631,14 @@ extern "C" int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* pr
       return EOD_ERR_LAUNCH;
     attr_set = true;
   }
-  const dim3 grid((H >> 5) * (W >> 5));
+  const dim3 grid((H >> 5) * (W >> 5), batch > 1 ? batch : 1);
+  const size_t ph = eod_memory_pooled_halves(H, W);
   if (torch_order)
     hipLaunchKernelGGL(gather_pool_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
-                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags, ph);
   else
     hipLaunchKernelGGL(gather_pool_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const __half*>(mem_f16), proj, H,
-                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags);
+                       W, n_cells, reinterpret_cast<__half*>(pooled_f16), err_flags, ph);
   return eod_launch_status();
 }
 
@@ -646,9 +663,9 @@ extern "C" int eod_memory_project_prepare(const float* w1, const float* b1, cons
 }
 
 extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* prepared, float* feats, int H, int W, float weight, int mode,
-                                       eod_stream_t stream) {
+                                       int batch, eod_stream_t stream) {
   if (!pooled_f16 || !prepared || !feats) return EOD_ERR_NULL;
-  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || (mode != 0 && mode != 1)) return EOD_ERR_BAD_DIMS;
+  if (H <= 0 || W <= 0 || (H & 31) || (W & 31) || (mode != 0 && mode != 1) || batch > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(pooled_f16) || !eod_aligned16(prepared)) return EOD_ERR_ALIGN;
   ProjArgs a{};
   const int rows[3] = {(H >> 3) * (W >> 3), (H >> 4) * (W >> 4), (H >> 5) * (W >> 5)};
@@ -663,10 +680,12 @@ extern "C" int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* p
   }
   a.weight = weight;
   a.mode = mode;
+  a.batch = batch > 1 ? batch : 1;
+  a.pooled_halves = eod_memory_pooled_halves(H, W);
   const _Float16* ws = static_cast<const _Float16*>(prepared);
   const float* sinv = reinterpret_cast<const float*>(ws + (size_t)3 * 2 * 256 * 512);
   const float* bias = sinv + 3 * 256;
-  hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3] * 2), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(project_fuse_kernel, dim3(a.tile_off[3] * 2, a.batch), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(pooled_f16), ws, sinv, bias, feats, a);
   return eod_launch_status();
 }

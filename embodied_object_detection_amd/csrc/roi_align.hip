@@ -22,13 +22,15 @@ struct RoiArgs {
   int R_cap;
   int S;
   float* out;
+  int batch, boxes_per_image;   // batch > 1: feat[l] holds `batch` images; box j belongs to image j / boxes_per_image
   FastDiv div_bins, div_s;   // wave id -> (roi, bin) -> (ph, pw) without integer division sequences
 };
 
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
   EOD_CHAIN_PRIO();
   int R = p.R_cap;
-  if (p.count) {
+  const bool segmented = p.batch > 1 && !p.box_rows;      // one ROI list per image, a count per list
+  if (p.count && !segmented) {
     const int c = *p.count;
     R = c < R ? c : R;
   }
@@ -41,14 +43,19 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
     const int b = wid - r * bins;
     const int ph = (int)fdiv((unsigned)b, p.div_s), pw = b - ph * p.S;
     const int br = p.box_rows ? p.box_rows[r] : r;
+    int img = 0;
+    if (p.batch > 1) {
+      img = br / p.boxes_per_image;
+      if (segmented && p.count && br - img * p.boxes_per_image >= p.count[img]) continue;
+    }
     const float bx1 = p.boxes[br * 4 + 0], by1 = p.boxes[br * 4 + 1], bx2 = p.boxes[br * 4 + 2], by2 = p.boxes[br * 4 + 3];
     // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [3,5]
     const float area = (bx2 - bx1) * (by2 - by1);
     float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
     lv = fminf(fmaxf(lv, 3.0f), 5.0f);
     const int l = (int)lv - 3;
-    const float* feat = p.feat[l];
     const int H = p.h[l], W = p.w[l];
+    const float* feat = p.feat[l] + (size_t)img * H * W * p.C;
     const float sc = p.scale[l];
     const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f, x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
     const float roi_w = x2 - x1, roi_h = y2 - y1;
@@ -120,17 +127,19 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
 }  // namespace
 
 extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C, const float* boxes,
-                             const int32_t* box_rows, const int32_t* count, int R_cap, int out_size, float* out,
-                             eod_stream_t stream) {
+                             const int32_t* box_rows, const int32_t* count, int R_cap, int out_size, float* out, int batch,
+                             int boxes_per_image, eod_stream_t stream) {
   if (!p3 || !p4 || !p5 || !boxes || !out) return EOD_ERR_NULL;
   if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
   if ((long)R_cap * out_size * out_size >= (1L << 30)) return EOD_ERR_BAD_DIMS;
+  if (batch > 1 && (batch > EOD_MAX_BATCH || boxes_per_image <= 0 || (!box_rows && R_cap != batch * boxes_per_image))) return EOD_ERR_BAD_DIMS;
   if (!eod_aligned16(p3) || !eod_aligned16(p4) || !eod_aligned16(p5) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
   RoiArgs a{};
   a.feat[0] = p3; a.feat[1] = p4; a.feat[2] = p5;
   a.h[0] = h3; a.w[0] = w3; a.h[1] = h3 / 2; a.w[1] = w3 / 2; a.h[2] = h3 / 4; a.w[2] = w3 / 4;
   a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
   a.C = C; a.boxes = boxes; a.box_rows = box_rows; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
+  a.batch = batch > 1 ? batch : 1; a.boxes_per_image = boxes_per_image;
   a.div_bins = eod_make_fastdiv((unsigned)(out_size * out_size));
   a.div_s = eod_make_fastdiv((unsigned)out_size);
   const long waves = (long)R_cap * out_size * out_size;

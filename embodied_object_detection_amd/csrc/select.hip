@@ -114,6 +114,21 @@ struct ScanOut {
   int* rep_count;
 };
 
+// scene b of a batch: every output is `batch` single-scene buffers back to back
+__device__ __forceinline__ ScanOut scene_outputs(ScanOut o, int b) {
+  if (o.out_boxes) o.out_boxes += (size_t)b * o.cap * 4;
+  if (o.out_scores) o.out_scores += (size_t)b * o.cap;
+  if (o.out_labels) o.out_labels += (size_t)b * o.cap;
+  if (o.out_rows) o.out_rows += (size_t)b * o.cap;
+  if (o.out_count) o.out_count += b;
+  if (o.uniq_rows) o.uniq_rows += (size_t)b * o.uniq_cap;
+  if (o.uniq_count) o.uniq_count += b;
+  if (o.rep_of) o.rep_of += (size_t)b * o.cap;
+  if (o.rep_list) o.rep_list += (size_t)b * o.cap;
+  if (o.rep_count) o.rep_count += b;
+  return o;
+}
+
 #define NMS_KEPT_MAX 512
 
 struct NmsSmem {
@@ -373,7 +388,15 @@ struct CnArgs {
   u64* cand_keys;  // packed per level: level l owns slots [pk_off[l], pk_off[l+1]), min(level size, topk) each
   int* cand_cnt;   // [levels]
   int pk_off[6];
+  // batch > 1: `head` is level major over the scenes (level l of scene b = rows batch * level_off[l] + b * n_l ...), candidate keys
+  // carry the scene's own position level_off[l] + i; cand_keys / cand_cnt hold `batch` sets back to back
+  int batch;
 };
+
+__device__ __forceinline__ size_t cn_head_row(const CnArgs& p, int scene, int level, int i) {
+  const int n = p.level_off[level + 1] - p.level_off[level];
+  return (size_t)p.batch * p.level_off[level] + (size_t)scene * n + i;
+}
 
 #define EOD_SORT_MAX 16384
 
@@ -413,9 +436,12 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
   __shared__ int hist[4096];
   __shared__ int wsum[16];
   __shared__ int sh_cnt, sh_cut, sh_n2;
-  const int level = blockIdx.x;
+  const int level = blockIdx.x, scene = blockIdx.y;
   const int r0 = p.level_off[level];
   const int n = p.level_off[level + 1] - r0;
+  const size_t head0 = cn_head_row(p, scene, level, 0);
+  p.cand_keys += (size_t)scene * p.pk_off[p.levels];
+  p.cand_cnt += scene * 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
   if (tid == 0) {
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
     const int i = e * 1024 + tid;
     u64 k = 0;
     if (i < n) {
-      const float heat = eod_sigmoid_precise(p.head[(size_t)(r0 + i) * p.head_stride]);
+      const float heat = eod_sigmoid_precise(p.head[(head0 + i) * p.head_stride]);
       if (heat > p.score_thresh) {
         k = make_key(heat, (unsigned)i);
         int bin = (int)(__float_as_uint(heat) >> 14) - (int)(0x3C000000u >> 14);
@@ -508,6 +534,12 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
   __shared__ u64 xch[1024 * E];
   static_assert(sizeof(NmsSmem) <= sizeof(u64) * 1024 * E, "the NMS state reuses the sort's exchange buffer");
   const int total_slots = p.pk_off[p.levels];
+  const int scene = blockIdx.x;
+  p.cand_keys += (size_t)scene * total_slots;
+  p.cand_cnt += scene * 8;
+  sorted_boxes += (size_t)scene * total_slots * 4;
+  sorted_scores += (size_t)scene * total_slots;
+  o = scene_outputs(o, scene);
   u64 v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -531,7 +563,7 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
     const int gy_i = i / w, gx_i = i - gy_i * w;
     const float gx = (float)(gx_i * stride + stride / 2);
     const float gy = (float)(gy_i * stride + stride / 2);
-    const float* h = p.head + (size_t)g * p.head_stride;
+    const float* h = p.head + cn_head_row(p, scene, level, i) * p.head_stride;
     const float sc = p.level_scale[level];
     const float st = (float)stride;
     const float r0 = fmaxf(h[1] * sc, 0.f) * st;
@@ -591,11 +623,17 @@ __device__ __forceinline__ void sort_in_place(u64* buf, int n) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void det_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                           const int* __restrict__ count, int R_cap, int C1, float img_w,
-                                                           float img_h, float thr, float nms_thresh, int topk, ScanOut o) {
+__global__ __launch_bounds__(1024) void det_select_kernel(const float* boxes, const float* scores, const int* count, int R_cap, int C1,
+                                                           float img_w, float img_h, float thr, float nms_thresh, int topk, ScanOut o) {
   EOD_CHAIN_PRIO();
   constexpr int EMAX = 8;
+  {
+    const int scene = blockIdx.x;      // one workgroup per scene of a batch
+    boxes += (size_t)scene * R_cap * 4;
+    scores += (size_t)scene * R_cap * C1;
+    if (count) count += scene;
+    o = scene_outputs(o, scene);
+  }
   __shared__ u64 buf[1024 * EMAX];                 // compaction target / sort exchange / sorted keys of the batch
   __shared__ u64 Mx[DET_MAX_R * DET_WORDS];        // IoU bit matrix of the rows
   __shared__ float cbx[DET_MAX_R * 4];             // clipped boxes
@@ -876,6 +914,21 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const float* __restric
   }
 }
 
+// The scene-local index lists of a batch (kept proposal rows, detection-group representatives) as ONE list of global indices
+// b * id_stride + list[b][k], scene by scene: the mask head then runs once over the concatenation with a single count.
+__global__ __launch_bounds__(256) void concat_lists_kernel(const int* __restrict__ lists, const int* __restrict__ counts, int cap_in,
+                                                            int id_stride, int batch, int* __restrict__ out, int* __restrict__ out_count) {
+  EOD_CHAIN_PRIO();
+  int off = 0;
+  for (int b = 0; b < batch; ++b) {
+    int c = counts[b];
+    c = c < 0 ? 0 : (c > cap_in ? cap_in : c);
+    for (int k = threadIdx.x; k < c; k += blockDim.x) out[off + k] = b * id_stride + lists[(size_t)b * cap_in + k];
+    off += c;
+  }
+  if (threadIdx.x == 0) *out_count = off;
+}
+
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct SelWs {
@@ -903,17 +956,17 @@ SelWs carve(void* base, int cap_sort, int keep_cap, int cand_slots) {
   w.sorted_labels = reinterpret_cast<int*>(take((size_t)cap_sort * sizeof(int)));
   w.sorted_rows = reinterpret_cast<int*>(take((size_t)cap_sort * sizeof(int)));
   w.cand_keys = reinterpret_cast<u64*>(take((size_t)(cand_slots > 0 ? cand_slots : 1) * sizeof(u64)));
-  w.cand_cnt = reinterpret_cast<int*>(take(8 * sizeof(int)));
+  w.cand_cnt = reinterpret_cast<int*>(take(8 * EOD_MAX_BATCH * sizeof(int)));
   w.bytes = off;
   return w;
 }
 
 }  // namespace
 
-extern "C" size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk) {
+extern "C" size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk, int batch) {
   (void)total_positions;
-  const int slots = levels * pre_nms_topk;
-  return carve(nullptr, slots, slots, slots).bytes;
+  const int slots = levels * pre_nms_topk, nb = batch > 1 ? batch : 1;
+  return carve(nullptr, slots * nb, slots, slots * nb).bytes;
 }
 
 extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream) {
@@ -926,10 +979,13 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
     if (n <= 0 || n > EOD_SORT_MAX || d->level_w[l] <= 0 || n % d->level_w[l] != 0) return EOD_ERR_CAPACITY;
   }
   if (d->cap < d->post_nms_topk || d->cap > NMS_KEPT_MAX) return EOD_ERR_CAPACITY;
-  const SelWs w = carve(d->workspace, slots, slots, slots);
+  const int nb = d->batch > 1 ? d->batch : 1;
+  if (nb > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  const SelWs w = carve(d->workspace, slots * nb, slots, slots * nb);
   if (d->workspace_bytes < w.bytes) return EOD_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
   CnArgs a{};
+  a.batch = nb;
   a.head = d->head_out; a.head_stride = d->head_stride; a.levels = d->levels;
   for (int l = 0; l <= d->levels; ++l) a.level_off[l] = d->level_off[l];
   for (int l = 0; l < d->levels; ++l) {
@@ -944,15 +1000,15 @@ extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t st
   int max_level = 0;
   for (int l = 0; l < d->levels; ++l) max_level = std::max(max_level, d->level_off[l + 1] - d->level_off[l]);
   if (max_level <= 8192)
-    hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels, nb), dim3(1024), 0, s, a);
   else
-    hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels, nb), dim3(1024), 0, s, a);
   ScanOut o{d->out_boxes, d->out_scores, nullptr, nullptr, d->out_count, d->cap, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
   if (a.pk_off[d->levels] <= 4096)
-    hipLaunchKernelGGL(cn_merge_nms_kernel<4>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
+    hipLaunchKernelGGL(cn_merge_nms_kernel<4>, dim3(nb), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
                        d->post_nms_topk, o);
   else
-    hipLaunchKernelGGL(cn_merge_nms_kernel<8>, dim3(1), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
+    hipLaunchKernelGGL(cn_merge_nms_kernel<8>, dim3(nb), dim3(1024), 0, s, a, w.sorted_boxes, w.sorted_scores, d->nms_thresh,
                        d->post_nms_topk, o);
   return eod_launch_status();
 }
@@ -977,7 +1033,16 @@ extern "C" int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream)
   if (d->out_rep_of && (!d->out_rep_list || !d->out_rep_count || d->R_cap > NMS_KEPT_MAX)) return EOD_ERR_BAD_DIMS;
   ScanOut o{d->out_boxes, d->out_scores, d->out_classes, d->out_rows, d->out_count, d->topk, d->out_unique_rows, d->out_unique_count,
             d->unique_cap, d->out_rep_of, d->out_rep_list, d->out_rep_count};
-  hipLaunchKernelGGL(det_select_kernel, dim3(1), dim3(1024), 0, s, d->boxes, d->scores, d->count, d->R_cap, d->C1, d->img_w, d->img_h,
+  if (d->batch > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(det_select_kernel, dim3(d->batch > 1 ? d->batch : 1), dim3(1024), 0, s, d->boxes, d->scores, d->count, d->R_cap, d->C1, d->img_w, d->img_h,
                      d->score_thresh, d->nms_thresh, d->topk, o);
+  return eod_launch_status();
+}
+
+extern "C" int eod_concat_lists(const int32_t* lists, const int32_t* counts, int cap_in, int id_stride, int batch, int32_t* out,
+                                int32_t* out_count, eod_stream_t stream) {
+  if (!lists || !counts || !out || !out_count) return EOD_ERR_NULL;
+  if (cap_in <= 0 || id_stride <= 0 || batch < 1 || batch > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(concat_lists_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lists, counts, cap_in, id_stride, batch, out, out_count);
   return eod_launch_status();
 }

@@ -140,10 +140,11 @@ class Conv:
                  levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
                  fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True,
                  plan_rows: int = 0, gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 32,
-                 split: Optional[Tuple[int, torch.Tensor]] = None) -> torch.Tensor:
+                 split: Optional[Tuple[int, torch.Tensor]] = None, m_segments: int = 0) -> torch.Tensor:
         """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
         `split=(n0, out2)`: the layer is two stacked linear layers; columns [0, n0) go to `out` [rows, n0] without the ReLU, columns
         [n0, Cout) to `out2` [rows, Cout - n0] with it (EodConvDesc.split_n).
+        `m_segments` = B: the N images are B unit lists back to back, `m_count` holds B counts (EodConvDesc.m_segments).
         `gn_stats` (pyramid mode; the workspace of the `groupnorm_relu` call that follows): when the layer's plan reduces split-K
         slabs, that reduce also writes GroupNorm's partial sums into it and `self.gn_fused` is set (pass it as `partial_ready`).
         `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
@@ -163,7 +164,7 @@ class Conv:
                 out = torch.empty((N, OH, OW, self.Cout), dtype=torch.float32, device=x.device)
         d = self.desc
         d.x, d.w, d.bias, d.res, d.y = x.data_ptr(), self.w.data_ptr(), _ptr(self.bias), _ptr(res), out.data_ptr()
-        d.m_count, d.m_unit = _ptr(m_count), m_unit
+        d.m_count, d.m_unit, d.m_segments = _ptr(m_count), m_unit, int(m_segments)
         d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, self.Cin, OH, OW, self.Cout
         d.KH, d.KW, d.stride, d.pad, d.Kpad = self.KH, self.KW, self.stride, self.pad, self.Kpad
         d.relu, d.res_mode, d.in_relu, d.out_mode, d.tap4 = int(relu), res_mode, int(in_relu), self.out_mode, self.tap4
@@ -221,12 +222,16 @@ class Conv:
 # ----------------------------------------------------------------------------------------------------
 # elementwise / pooling
 # ----------------------------------------------------------------------------------------------------
-def preprocess_image(img_u8_chw: torch.Tensor, mean: Sequence[float], std: Sequence[float], div: int = 32) -> Tuple[torch.Tensor, int, int]:
+def preprocess_image(img_u8_chw: torch.Tensor, mean: Sequence[float], std: Sequence[float], div: int = 32,
+                     out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
+    """`out` (optional): a [1,Hp,Wp,4] slice of a batch buffer to write into."""
     _need_cuda(img_u8_chw)
     assert img_u8_chw.dtype == torch.uint8 and img_u8_chw.dim() == 3 and img_u8_chw.is_contiguous()
     _, H, W = img_u8_chw.shape
     Hp, Wp = (H + div - 1) // div * div, (W + div - 1) // div * div
-    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img_u8_chw.device)
+    if out is None:
+        out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img_u8_chw.device)
+    assert out.numel() == Hp * Wp * 4 and out.is_contiguous()
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
     check(_lib.load().eod_preprocess_image(img_u8_chw.data_ptr(), out.data_ptr(), H, W, Hp, Wp, m, s, _stream()),
@@ -269,12 +274,22 @@ def mask_predictor_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: float, rows: 
 
 
 def roi_align(p3, p4, p5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count: Optional[torch.Tensor], R_cap: int, S: int,
-              out: Optional[torch.Tensor] = None, box_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, box_rows: Optional[torch.Tensor] = None, batch: int = 1,
+              boxes_per_image: int = 0) -> torch.Tensor:
+    """`batch` > 1: p3..p5 are [batch,h,w,C]; box j is pooled from image j // boxes_per_image (include/eod_hip.h)."""
     if out is None:
         out = torch.empty((R_cap, S, S, Cc), dtype=torch.float32, device=p3.device)
     check(_lib.load().eod_roi_align(p3.data_ptr(), p4.data_ptr(), p5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(box_rows),
-                                    _ptr(count), R_cap, S, out.data_ptr(), _stream()), "eod_roi_align")
+                                    _ptr(count), R_cap, S, out.data_ptr(), batch, boxes_per_image, _stream()), "eod_roi_align")
     return out
+
+
+def concat_lists(lists: torch.Tensor, counts: torch.Tensor, cap_in: int, id_stride: int, batch: int, out: torch.Tensor,
+                 out_count: torch.Tensor):
+    """The scene-local index lists of a batch as one list of global indices b * id_stride + lists[b][k] (eod_concat_lists)."""
+    check(_lib.load().eod_concat_lists(lists.data_ptr(), counts.data_ptr(), cap_in, id_stride, batch, out.data_ptr(), out_count.data_ptr(),
+                                       _stream()), "eod_concat_lists")
+    return out, out_count
 
 
 def unique_rows(rows: torch.Tensor, count: torch.Tensor, K_cap: int, R_cap: int, out_rows: torch.Tensor, out_count: torch.Tensor):
@@ -289,7 +304,8 @@ class ProposalDecoder:
     """CenterNet.inference on device (centernet.py:603-745)."""
 
     def __init__(self, level_hw: Sequence[Tuple[int, int]], strides: Sequence[int], scales: Sequence[float], score_thresh: float,
-                 pre_nms_topk: int, post_nms_topk: int, nms_thresh: float, cap: int, device, head_stride: int = 5):
+                 pre_nms_topk: int, post_nms_topk: int, nms_thresh: float, cap: int, device, head_stride: int = 5, batch: int = 1):
+        """`batch` > 1: B scenes in lock-step; `head_out` is level major over the scenes, the outputs are [B*cap,4] / [B*cap] / [B]."""
         self.lib = _lib.load()
         d = EodProposalDesc()
         off = [0]
@@ -304,11 +320,12 @@ class ProposalDecoder:
             d.level_scale[i] = scales[i]
         d.head_stride = head_stride
         d.score_thresh, d.pre_nms_topk, d.post_nms_topk, d.nms_thresh, d.cap = score_thresh, pre_nms_topk, post_nms_topk, nms_thresh, cap
-        nbytes = self.lib.eod_proposals_workspace_bytes(off[-1], d.levels, pre_nms_topk)
+        nbytes = self.lib.eod_proposals_workspace_bytes(off[-1], d.levels, pre_nms_topk, batch)
+        d.batch = batch
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        self.boxes = torch.zeros((cap, 4), dtype=torch.float32, device=device)
-        self.scores = torch.zeros((cap,), dtype=torch.float32, device=device)
-        self.count = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.boxes = torch.zeros((batch * cap, 4), dtype=torch.float32, device=device)
+        self.scores = torch.zeros((batch * cap,), dtype=torch.float32, device=device)
+        self.count = torch.zeros((batch,), dtype=torch.int32, device=device)
         d.out_boxes, d.out_scores, d.out_count = self.boxes.data_ptr(), self.scores.data_ptr(), self.count.data_ptr()
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
         self.desc = d
@@ -327,31 +344,33 @@ class DetectionSelector:
     proposal row -- detections of one row carry the same class-agnostic box: `rep_of[k]` = the first detection of k's group,
     `rep_list` / `rep_count` = the group representatives."""
 
-    def __init__(self, R_cap: int, C1: int, topk: int, device, unique: bool = False, groups: bool = False):
+    def __init__(self, R_cap: int, C1: int, topk: int, device, unique: bool = False, groups: bool = False, batch: int = 1):
+        """`batch` > 1: B scenes, one workgroup each; every buffer is B single-scene buffers back to back, indices stay scene-local."""
         self.lib = _lib.load()
-        self.R_cap, self.C1, self.topk = R_cap, C1, topk
+        self.R_cap, self.C1, self.topk, self.batch = R_cap, C1, topk, batch
         nbytes = self.lib.eod_detections_workspace_bytes(R_cap, C1)
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        self.boxes = torch.zeros((topk, 4), dtype=torch.float32, device=device)
-        self.scores = torch.zeros((topk,), dtype=torch.float32, device=device)
-        self.classes = torch.zeros((topk,), dtype=torch.int32, device=device)
-        self.rows = torch.zeros((topk,), dtype=torch.int32, device=device)
-        self.count = torch.zeros((1,), dtype=torch.int32, device=device)
+        B = batch
+        self.boxes = torch.zeros((B * topk, 4), dtype=torch.float32, device=device)
+        self.scores = torch.zeros((B * topk,), dtype=torch.float32, device=device)
+        self.classes = torch.zeros((B * topk,), dtype=torch.int32, device=device)
+        self.rows = torch.zeros((B * topk,), dtype=torch.int32, device=device)
+        self.count = torch.zeros((B,), dtype=torch.int32, device=device)
         d = EodDetDesc()
-        d.R_cap, d.C1, d.topk = R_cap, C1, topk
+        d.R_cap, d.C1, d.topk, d.batch = R_cap, C1, topk, batch
         d.out_boxes, d.out_scores, d.out_classes = self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr()
         d.out_rows, d.out_count = self.rows.data_ptr(), self.count.data_ptr()
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
         self.uniq_rows = self.uniq_count = None
         if unique:
-            self.uniq_rows = torch.zeros((R_cap,), dtype=torch.int32, device=device)
-            self.uniq_count = torch.zeros((1,), dtype=torch.int32, device=device)
+            self.uniq_rows = torch.zeros((B * R_cap,), dtype=torch.int32, device=device)
+            self.uniq_count = torch.zeros((B,), dtype=torch.int32, device=device)
             d.out_unique_rows, d.out_unique_count, d.unique_cap = self.uniq_rows.data_ptr(), self.uniq_count.data_ptr(), R_cap
         self.rep_of = self.rep_list = self.rep_count = None
         if groups:
-            self.rep_of = torch.zeros((topk,), dtype=torch.int32, device=device)
-            self.rep_list = torch.zeros((topk,), dtype=torch.int32, device=device)
-            self.rep_count = torch.zeros((1,), dtype=torch.int32, device=device)
+            self.rep_of = torch.zeros((B * topk,), dtype=torch.int32, device=device)
+            self.rep_list = torch.zeros((B * topk,), dtype=torch.int32, device=device)
+            self.rep_count = torch.zeros((B,), dtype=torch.int32, device=device)
             d.out_rep_of, d.out_rep_list, d.out_rep_count = self.rep_of.data_ptr(), self.rep_list.data_ptr(), self.rep_count.data_ptr()
         self.desc = d
 
@@ -365,22 +384,22 @@ class DetectionSelector:
 
 
 def zs_classify(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: int, C1: int, temp: float = 50.0, zs_mem=None,
-                prop_scores=None, mem_scores_out=None, final_inv_stages: float = 0.0):
+                prop_scores=None, mem_scores_out=None, final_inv_stages: float = 0.0, batch: int = 1):
     """`zs_mem` + `prop_scores` + `mem_scores_out`: also the memory update's CLIP re-score (what `memory_scores` computes) in the same
     launch; `final_inv_stages` > 0 (last cascade stage): also the cascade score fusion (what `cascade_scores` does)."""
     st = _lib.load().eod_zs_classify(feat.data_ptr(), zs.data_ptr(), prob_acc.data_ptr(), int(accumulate), _ptr(featn_out), _ptr(count),
                                      R_cap, 512, C1, temp, _ptr(zs_mem), _ptr(prop_scores), _ptr(mem_scores_out),
-                                     float(final_inv_stages), _stream())
+                                     float(final_inv_stages), batch, _stream())
     if st == -5:
         raise _lib.EodError(f"eod_zs_classify: {C1 - 1} classes + background do not fit the kernel's LDS-staged class matrix (at most 23 "
                             "classes): a RESET_CLS_TESTS / TEST_NUM_CLASSES vocabulary of this size is not supported on the HIP path")
     check(st, "eod_zs_classify")
 
 
-def apply_deltas(deltas, ld: int, boxes, out, count, R_cap: int, weights, clip: bool, img_w: float, img_h: float):
+def apply_deltas(deltas, ld: int, boxes, out, count, R_cap: int, weights, clip: bool, img_w: float, img_h: float, batch: int = 1):
     wx, wy, ww, wh = weights
     check(_lib.load().eod_apply_deltas(deltas.data_ptr(), ld, boxes.data_ptr(), out.data_ptr(), _ptr(count), R_cap, wx, wy, ww, wh,
-                                       int(clip), img_w, img_h, _stream()), "eod_apply_deltas")
+                                       int(clip), img_w, img_h, batch, _stream()), "eod_apply_deltas")
 
 
 def cascade_scores(prob_acc, prop_scores, count, R_cap: int, C1: int, inv_stages: float):
@@ -394,16 +413,17 @@ def memory_scores(featn, zs, prop_scores, scores_out, count, R_cap: int, C1: int
 
 
 def detector_postprocess(boxes, scores, classes, count, cap: int, sx: float, sy: float, out_w: float, out_h: float, ob, os_, oc, osrc,
-                         ocount, remap=None):
+                         ocount, remap=None, batch: int = 1):
     """`remap` (int32 [cap], optional): osrc[q] = remap[index of the kept detection] -- the detection whose mask stands for it."""
     check(_lib.load().eod_detector_postprocess(boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), _ptr(count), cap, sx, sy,
                                                out_w, out_h, ob.data_ptr(), os_.data_ptr(), oc.data_ptr(), osrc.data_ptr(),
-                                               ocount.data_ptr(), _ptr(remap), _stream()), "eod_detector_postprocess")
+                                               ocount.data_ptr(), _ptr(remap), batch, _stream()), "eod_detector_postprocess")
 
 
-def paste_masks(prob, boxes, rows, count, K_cap: int, H: int, W: int, thr: float, out: torch.Tensor):
+def paste_masks(prob, boxes, rows, count, K_cap: int, H: int, W: int, thr: float, out: torch.Tensor, batch: int = 1,
+                prob_units: int = 0):
     check(_lib.load().eod_paste_masks(prob.data_ptr(), boxes.data_ptr(), _ptr(rows), _ptr(count), K_cap, H, W, thr, out.data_ptr(),
-                                      _stream()), "eod_paste_masks")
+                                      batch, prob_units, _stream()), "eod_paste_masks")
     return out
 
 
@@ -448,13 +468,14 @@ def pooled_rows(H: int, W: int) -> int:
 
 
 def memory_gather_pool(mem_f16: torch.Tensor, proj: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None,
-                       err: Optional[torch.Tensor] = None, torch_order: bool = False) -> torch.Tensor:
-    """a8 gather + cascaded pooling -> fp16 pooled rows of the three levels in MFMA operand-fragment order (see the header)."""
-    N, D = mem_f16.shape
+                       err: Optional[torch.Tensor] = None, torch_order: bool = False, batch: int = 1) -> torch.Tensor:
+    """a8 gather + cascaded pooling -> fp16 pooled rows of the three levels in MFMA operand-fragment order (see the header).
+    `batch` > 1: mem_f16 [B,N,D], proj [B,H,W], out [B * pooled_rows, D]."""
+    N, D = mem_f16.shape[-2:]
     if out is None:
-        out = torch.empty((pooled_rows(H, W), D), dtype=torch.float16, device=mem_f16.device)
+        out = torch.empty((batch * pooled_rows(H, W), D), dtype=torch.float16, device=mem_f16.device)
     check(_lib.load().eod_memory_gather_pool(mem_f16.data_ptr(), proj.data_ptr(), H, W, D, N, out.data_ptr(), _ptr(err), int(torch_order),
-                                             _stream()),
+                                             batch, _stream()),
           "eod_memory_gather_pool")
     return out
 
@@ -471,10 +492,11 @@ class MemoryProjector:
                                                   bs[2].data_ptr(), self.prepared.data_ptr(), _stream()), "eod_memory_project_prepare")
         torch.cuda.current_stream().synchronize()       # ws / bs die with this frame; the prepare kernels must have read them
 
-    def __call__(self, pooled_f16: torch.Tensor, feats: torch.Tensor, H: int, W: int, weight: float, mode: str):
+    def __call__(self, pooled_f16: torch.Tensor, feats: torch.Tensor, H: int, W: int, weight: float, mode: str, batch: int = 1):
+        """`batch` > 1: `feats` is level major over the scenes (include/eod_hip.h)."""
         _need_cuda(pooled_f16, feats)
         check(self.lib.eod_memory_project_fuse(pooled_f16.data_ptr(), self.prepared.data_ptr(), feats.data_ptr(), H, W, float(weight),
-                                               {"sum": 0, "mem_only": 1}[mode], _stream()), "eod_memory_project_fuse")
+                                               {"sum": 0, "mem_only": 1}[mode], batch, _stream()), "eod_memory_project_fuse")
         return feats
 
 
@@ -514,13 +536,15 @@ class MemoryProjectorBackward:
 class MemoryWriter:
     """a16-a19 write path (custom_rcnn.py:681-760) on device."""
 
-    def __init__(self, H: int, W: int, n_cells: int, K_cap: int, R_cap: int, device, mask_thresh: float = 0.5):
+    def __init__(self, H: int, W: int, n_cells: int, K_cap: int, R_cap: int, device, mask_thresh: float = 0.5, batch: int = 1):
+        """`batch` > 1: B scenes with B independent states; every buffer handed to the call is B single-scene buffers back to back."""
         self.lib = _lib.load()
-        nbytes = self.lib.eod_memory_write_workspace_bytes(H, W, 512, n_cells, K_cap, R_cap)
+        nbytes = self.lib.eod_memory_write_workspace_bytes(H, W, 512, n_cells, K_cap, R_cap) * batch
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         check(self.lib.eod_memory_write_init(self.ws.data_ptr(), nbytes, H, W, 512, n_cells, K_cap, R_cap, _stream()), "eod_memory_write_init")
-        self.k_out = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.k_out = torch.zeros((batch,), dtype=torch.int32, device=device)
         d = EodMemWriteDesc()
+        d.batch = batch
         d.K_cap, d.R_cap, d.H, d.W, d.D, d.n_cells, d.mask_thresh = K_cap, R_cap, H, W, 512, n_cells, mask_thresh
         d.workspace, d.workspace_bytes, d.k_out = self.ws.data_ptr(), nbytes, self.k_out.data_ptr()
         self.desc = d

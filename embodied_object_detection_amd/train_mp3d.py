@@ -32,8 +32,10 @@ def default_argument_parser():
     p.add_argument("--machine-rank", type=int, default=0)
     p.add_argument("--dist-url", default="tcp://127.0.0.1:29512")
     p.add_argument("--scenes-in-lockstep", type=int, default=1,
-                   help="B > 1: every rank runs its scenes B at a time in lock-step (modeling.batched.BatchedSequences: the "
-                        "memory-independent trunk once per step with N = B); scenes are independent, the AP is the same")
+                   help="B > 1: every rank runs its scenes B at a time in lock-step; scenes are independent, the AP is the same")
+    p.add_argument("--lockstep-schedule", choices=["launches", "streams"], default="launches",
+                   help="launches: N = B through every stage, one launch per stage (modeling.lockstep.LockstepScenes); streams: B scene "
+                        "objects on their own streams, only the trunk batched (modeling.batched.BatchedSequences)")
     p.add_argument("--synthetic-scenes", type=int, default=2, help="number of synthetic scenes (no real data offline)")
     p.add_argument("--synthetic-frames", type=int, default=40)
     p.add_argument("--synthetic-size", type=int, nargs=2, default=[640, 640])
@@ -85,7 +87,10 @@ def main(args, rank: int = 0, world: int = 1, local_rank: int = 0):
         opts = opts[1:]
     opts += ["MODEL.DEVICE", f"cuda:{local_rank}"]
     cfg = setup_cfg(args.config_file or None, opts)
-    if args.scenes_in_lockstep > 1:
+    if args.scenes_in_lockstep > 1 and args.lockstep_schedule == "launches":
+        from .modeling.lockstep import LockstepScenes
+        model = LockstepScenes(cfg, args.scenes_in_lockstep)
+    elif args.scenes_in_lockstep > 1:
         from .modeling.batched import BatchedSequences
         model = BatchedSequences(cfg, args.scenes_in_lockstep)
     else:

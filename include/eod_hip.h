@@ -31,6 +31,14 @@ typedef void* eod_stream_t; /* hipStream_t */
 #define EOD_ERR_NULL (-4)
 #define EOD_ERR_CAPACITY (-5)
 
+/* Batches (B independent scenes in lock-step, BASELINE configs[4]; Detic/SMNet/loader.py:289-293: only independent sequences may be
+ * batched).  Every entry point with a `batch` argument (or descriptor field) treats EVERY buffer of the call -- inputs, outputs,
+ * counts, workspaces, recurrent state -- as `batch` single-scene buffers laid back to back, scene b at offset b x (single-scene
+ * size), and runs the B problems in ONE launch per stage; batch <= 1 is the single-scene call.  Weights are shared.  Results of
+ * scene b are bitwise those of the single-scene call on scene b's buffers. */
+#define EOD_MAX_BATCH 8
+#define EOD_MAX_LEVELS 40   /* 5 pyramid levels x EOD_MAX_BATCH scenes */
+
 int eod_abi_version(void);
 
 /* ---- dense contraction: implicit-GEMM convolution / linear layer on fp32 MFMA ------------------------
@@ -52,6 +60,9 @@ typedef struct EodConvDesc {
   size_t workspace_bytes;
   const int32_t* m_count; /* optional device int: number of valid units (each m_unit output rows) */
   int32_t m_unit;
+  /* 0 / 1, or B: the rows are B independent unit lists back to back (B scenes in lock-step, each N / B images); m_count then
+   * holds B counts and list b has work in its first m_count[b] units only.  Rows without work are neither computed nor written. */
+  int32_t m_segments;
   int32_t N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad;
   int32_t relu;      /* ReLU on the output */
   int32_t res_mode;  /* 0 none, 1 same-shape add, 2 add nearest-x2-upsampled res [N,OH/2,OW/2,Cout] */
@@ -64,11 +75,12 @@ typedef struct EodConvDesc {
   int32_t force_splitk; /* 0 auto */
   float out_scale;
   /* pyramid mode (levels > 0): x / y are [level_off[levels], C] row lists, level l is a level_h[l] x level_w[l] image;
-   * stride-1 'same' convolution with weights shared across levels (CenterNetHead, centernet_head.py:141-161). N must be 1. */
+   * stride-1 'same' convolution with weights shared across levels (CenterNetHead, centernet_head.py:141-161). N must be 1.
+   * A batch of B scenes in lock-step passes its 5 B level images as 5 B levels (EOD_MAX_LEVELS) and plan_rows = one scene's rows. */
   int32_t levels;
-  int32_t level_off[6];
-  int32_t level_h[5];
-  int32_t level_w[5];
+  int32_t level_off[EOD_MAX_LEVELS + 1];
+  int32_t level_h[EOD_MAX_LEVELS];
+  int32_t level_w[EOD_MAX_LEVELS];
   /* out_mode 2 -- tail of the mask head in one launch (d2 MaskRCNNConvUpsampleHead deconv + ReLU -> predictor 1x1 conv to one
    * channel, then mask_rcnn_inference's sigmoid; via detic_roi_heads.py:257,268 and custom_rcnn.py:574):
    *   y[u][2oy+dy][2ox+dx] = sigmoid( sum_co relu(deconv(x)[img][2oy+dy][2ox+dx][co]) * fuse_w[co] + fuse_b )
@@ -147,10 +159,14 @@ int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float
                                const int32_t* unit_count, int unit_rows, const int32_t* out_units /* optional scatter of units */,
                                eod_stream_t stream);
 
-/* ---- ROIAlignV2 over p3..p5 (d2 ROIPooler, detic_roi_heads.py:332,265) -------------------------------- */
+/* ---- ROIAlignV2 over p3..p5 (d2 ROIPooler, detic_roi_heads.py:332,265) --------------------------------
+ * batch > 1: p3..p5 hold `batch` images ([batch,h,w,C]), boxes holds batch x boxes_per_image boxes and box j is pooled from image
+ * j / boxes_per_image.  Without box_rows: R_cap = batch x boxes_per_image ROIs, one list per image, count[batch].  With box_rows:
+ * ONE compact list of box indices over all images (eod_concat_lists), count[1]. */
 int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C,
                   const float* boxes /*[R,4]*/, const int32_t* box_rows /* optional gather: ROI r pools boxes[box_rows[r]] */,
-                  const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/, eod_stream_t stream);
+                  const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/, int batch, int boxes_per_image,
+                  eod_stream_t stream);
 
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
@@ -171,8 +187,12 @@ typedef struct EodProposalDesc {
   int32_t* out_count;      /* [1] */
   void* workspace;         /* >= eod_proposals_workspace_bytes() */
   size_t workspace_bytes;
+  /* 0 / 1, or B scenes in lock-step: head_out is level major over the scenes ([level][scene][h_l * w_l] rows: the layout the
+   * batched pyramid-mode eod_conv2d writes), out_boxes [B*cap,4], out_scores [B*cap], out_count [B]; one workgroup per (level,
+   * scene) and per scene */
+  int32_t batch;
 } EodProposalDesc;
-size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk);
+size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk, int batch);
 int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream);
 
 /* ---- cascade box head glue ---------------------------------------------------------------------------- */
@@ -186,11 +206,11 @@ int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream);
  *     (detic_roi_heads.py:164-173) -- what eod_cascade_scores does in place. */
 int eod_zs_classify(const float* feat /*[R,512]*/, const float* zs /*[512,C1]*/, float* prob_acc /*[R,C1]*/, int accumulate,
                     float* feat_norm_out /*[R,512] or NULL*/, const int32_t* count, int R_cap, int D, int C1, float temp,
-                    const float* zs_mem, const float* prop_scores, float* mem_scores_out, float final_inv_stages,
+                    const float* zs_mem, const float* prop_scores, float* mem_scores_out, float final_inv_stages, int batch,
                     eod_stream_t stream);
 /* Box2BoxTransform.apply_deltas + optional clip (detic_roi_heads.py:121-122,314) */
 int eod_apply_deltas(const float* deltas /*[R,ld]*/, int ld, const float* boxes, float* out, const int32_t* count, int R_cap,
-                     float wx, float wy, float ww, float wh, int clip, float img_w, float img_h, eod_stream_t stream);
+                     float wx, float wy, float ww, float wh, int clip, float img_w, float img_h, int batch, eod_stream_t stream);
 /* scores = sqrt(mean_k(prob) * proposal_score) (detic_roi_heads.py:164-173) in place on prob_acc */
 int eod_cascade_scores(float* prob_acc, const float* prop_scores, const int32_t* count, int R_cap, int C1, float inv_stages,
                        eod_stream_t stream);
@@ -223,20 +243,29 @@ typedef struct EodDetDesc {
   int32_t* out_rep_of;     /* [topk] */
   int32_t* out_rep_list;   /* [topk] */
   int32_t* out_rep_count;  /* [1] */
+  int32_t batch;           /* 0 / 1, or B scenes (batch convention: every buffer above B x, one workgroup per scene; indices stay scene-local) */
 } EodDetDesc;
 size_t eod_detections_workspace_bytes(int R_cap, int C1);
 int eod_fast_rcnn_inference(const EodDetDesc* d, eod_stream_t stream);
 
+/* The scene-local index lists of a batch (EodDetDesc.out_unique_rows / out_rep_list: lists [batch, cap_in], counts [batch]) as ONE
+ * list of global indices b * id_stride + lists[b][k], scene by scene, with its total length: the mask head then runs once over all
+ * scenes' ROIs (eod_roi_align box_rows, EodConvDesc.m_count / out_units). */
+int eod_concat_lists(const int32_t* lists, const int32_t* counts, int cap_in, int id_stride, int batch, int32_t* out /*[batch*cap_in]*/,
+                     int32_t* out_count /*[1]*/, eod_stream_t stream);
+
 /* d2 detector_postprocess without the mask paste (custom_rcnn.py:579): scale, clip, drop empty boxes.
  * out_src[q] = index of the kept detection in the input list, or remap[that index] when remap is given (EodDetDesc.out_rep_of:
- * the detection whose mask stands for it). cap <= 512. */
+ * the detection whose mask stands for it). cap <= 512.  batch: see the batch convention (one workgroup per scene). */
 int eod_detector_postprocess(const float* boxes, const float* scores, const int32_t* classes, const int32_t* count, int cap,
                              float sx, float sy, float out_w, float out_h, float* out_boxes, float* out_scores,
-                             int32_t* out_classes, int32_t* out_src, int32_t* out_count, const int32_t* remap, eod_stream_t stream);
+                             int32_t* out_classes, int32_t* out_src, int32_t* out_count, const int32_t* remap, int batch,
+                             eod_stream_t stream);
 /* paste_masks_in_image (d2, inside detector_postprocess; custom_rcnn.py:579,880): out[k] = grid_sample(prob[rows[k]],
- * box k) >= threshold, u8 [K,H,W].  rows NULL = identity. */
+ * box k) >= threshold, u8 [K,H,W].  rows NULL = identity.  batch > 1: rows are scene-local indices into the scene's prob_units masks. */
 int eod_paste_masks(const float* prob, const float* boxes, const int32_t* rows, const int32_t* count, int K_cap,
-                    int H, int W, float threshold, uint8_t* out, eod_stream_t stream);
+                    int H, int W, float threshold, uint8_t* out, int batch, int prob_units /* batch > 1: masks per scene in prob */,
+                    eod_stream_t stream);
 
 /* ---- spatial feature memory --------------------------------------------------------------------------- */
 /* a1+a2: ProjectorUtils.pixel_to_world_mapping (SMNet/projector/core.py:177-225) + grid-cell index
@@ -262,16 +291,18 @@ int eod_memory_normalize_dirty_f16(const float* mem, const float* obs, int32_t* 
  * that sum is exact (exponents inside the block span <= 9 bits per channel); fewer instructions on an issue-bound kernel. */
 size_t eod_memory_pooled_halves(int H, int W);
 int eod_memory_gather_pool(const uint16_t* mem_f16, const int32_t* proj, int H, int W, int D, int n_cells,
-                           uint16_t* pooled_f16, int32_t* err_flags, int torch_order, eod_stream_t stream);
+                           uint16_t* pooled_f16, int32_t* err_flags, int torch_order, int batch, eod_stream_t stream);
 /* a8 projection + fusion (timm.py:174-189): for the three levels P_l = (pooled_l . W_l^T + b_l) * weight (+ P_l if mode 0
  * "sum"; mode 1 "mem_only" overwrites), in place on the [h8*w8 + h16*w16 + h32*w32, 256] fp32 row list `feats`.
  * `prepared` (eod_memory_project_weights_bytes() bytes, 16-byte aligned) is built once from the three Conv2d(512,256,1)
- * layers `map_merge_projection{1,2,3}` (weights [256,512] fp32, bias [256]). */
+ * layers `map_merge_projection{1,2,3}` (weights [256,512] fp32, bias [256]).  batch > 1: B tables / index images / pooled
+ * buffers back to back (err_flags shared); `feats` is LEVEL MAJOR over the scenes -- level l of scene b starts at row
+ * B * level_off[l] + b * rows_l -- the [B,h,w,256] level images the batched FPN convs write and read. */
 size_t eod_memory_project_weights_bytes(void);
 int eod_memory_project_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                const float* b3, void* prepared, eod_stream_t stream);
 int eod_memory_project_fuse(const uint16_t* pooled_f16, const void* prepared, float* feats, int H, int W, float weight,
-                            int mode, eod_stream_t stream);
+                            int mode, int batch, eod_stream_t stream);
 /* a16 scoring of proposals in CLIP space (custom_rcnn.py:848-855): scores = sqrt(sigmoid(featn@zs)*ps) */
 int eod_memory_scores(const float* featn /*[R,512]*/, const float* zs, const float* prop_scores, float* scores /*[R,C1]*/,
                       const int32_t* count, int R_cap, int D, int C1, eod_stream_t stream);
@@ -311,6 +342,8 @@ typedef struct EodMemWriteDesc {
   uint16_t* snapshot_f16;   /* [N,512] fp16 or NULL: the normalised table eod_memory_gather_pool reads.  When given, the rows of
                              * every cell whose observation count changed are refreshed by the write itself (the snapshot stays
                              * current: no eod_memory_normalize_dirty_f16 launch before the next read) and `dirty` is not touched */
+  int32_t batch;            /* 0 / 1, or B scenes with B independent states (batch convention: every buffer above B x, err_flags
+                             * shared; workspace >= B x eod_memory_write_workspace_bytes()); three launches for all scenes */
 } EodMemWriteDesc;
 size_t eod_memory_write_workspace_bytes(int H, int W, int D, int n_cells, int K_cap, int R_cap);
 int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream);

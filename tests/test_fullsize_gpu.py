@@ -91,19 +91,29 @@ def test_960_config5_frame_matches_oracle(synthetic_sd):
     model([[frames[1]]])      # second frame reads the written memory at full size without faults
 
 
-def _batch_equals_singles(synthetic_sd, H, W, grid, cell, B, T):
+def _lockstep_model(kind, B, synthetic_sd):
+    """"launches": N = B through every stage, one launch per stage (modeling/lockstep.py); "streams": B scene objects on B streams,
+    only the trunk batched (modeling/batched.py)."""
+    if kind == "launches":
+        from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+        return LockstepScenes(_cfg(), B, synthetic_sd)
+    from embodied_object_detection_amd.modeling.batched import BatchedSequences
+    return BatchedSequences(_cfg(), B, synthetic_sd)
+
+
+def _batch_equals_singles(synthetic_sd, H, W, grid, cell, B, T, kind="streams", lengths=None):
     from embodied_object_detection_amd import build_model
     from embodied_object_detection_amd.data.synthetic import SyntheticSequence
-    from embodied_object_detection_amd.modeling.batched import BatchedSequences
     seqs = [SyntheticSequence(40 + b, H=H, W=W, n_frames=T, map_w=grid, map_h=grid, cell=cell) for b in range(B)]
-    eps = [[s.frame(i) for i in range(T)] for s in seqs]
-    batched = BatchedSequences(_cfg(), B, synthetic_sd)
+    eps = [[s.frame(i) for i in range(T if lengths is None else lengths[b])] for b, s in enumerate(seqs)]
+    batched = _lockstep_model(kind, B, synthetic_sd)
     outs = batched(eps)
-    assert len(outs) == B and all(len(o) == T for o in outs)
+    T = None
+    assert len(outs) == B and all(len(o) == len(e) for o, e in zip(outs, eps))
     for b in range(B):
         single = build_model(_cfg(), synthetic_sd)
         ref = single([eps[b]])
-        for t in range(T):
+        for t in range(len(eps[b])):
             a, r = outs[b][t]["instances"], ref[t]["instances"]
             assert torch.equal(a.pred_boxes.tensor, r.pred_boxes.tensor) and torch.equal(a.scores, r.scores), (b, t)
             assert torch.equal(a.pred_classes, r.pred_classes) and torch.equal(a.pred_masks, r.pred_masks), (b, t)
@@ -137,18 +147,27 @@ def test_scenes_in_flight_do_not_change_results(synthetic_sd):
         torch.cuda.empty_cache()
 
 
-def test_batch_of_3_equals_3_single_runs_small(synthetic_sd):
-    """Lock-step batch (the trunk batched with N = 3, planned like one image) == three independent runs, bit for bit."""
-    _batch_equals_singles(synthetic_sd, 128, 160, 24, 0.5, 3, 3)
+@pytest.mark.parametrize("kind", ["launches", "streams"])
+def test_batch_of_3_equals_3_single_runs_small(synthetic_sd, kind):
+    """Lock-step batch (planned like one image) == three independent runs, bit for bit."""
+    _batch_equals_singles(synthetic_sd, 128, 160, 24, 0.5, 3, 3, kind)
 
 
-def test_config5_batch_of_4_equals_4_single_runs(synthetic_sd):
+def test_ragged_lockstep_batch_equals_single_runs(synthetic_sd):
+    """Episodes of different lengths (one scene sits most of the call out as an idle slot): every scene still gets exactly its own
+    run's results and state."""
+    _batch_equals_singles(synthetic_sd, 128, 160, 24, 0.5, 3, 5, "launches", lengths=[5, 2, 4])
+
+
+@pytest.mark.parametrize("kind", ["launches", "streams"])
+def test_config5_batch_of_4_equals_4_single_runs(synthetic_sd, kind):
     """BASELINE.json configs[4]: 4 sequences batched per GPU at 960x960 with a 512x512 memory grid; detections, masks and memory
     state of every sequence are bitwise those of its own single-sequence run."""
-    _batch_equals_singles(synthetic_sd, 960, 960, 512, 0.08, 4, 2)
+    _batch_equals_singles(synthetic_sd, 960, 960, 512, 0.08, 4, 2, kind)
 
 
-def test_eval_loop_in_lockstep_gives_the_same_records(synthetic_sd):
+@pytest.mark.parametrize("kind", ["launches", "streams"])
+def test_eval_loop_in_lockstep_gives_the_same_records(synthetic_sd, kind):
     """`inference_on_scenes` with a `BatchedSequences` of 2: three scenes of different lengths (25, 40 and 12 frames: ragged episodes,
     one scene without a partner) produce exactly the records of the one-scene-after-the-other loop (`train_mp3d.py:186`)."""
     from embodied_object_detection_amd import build_model
@@ -160,7 +179,7 @@ def test_eval_loop_in_lockstep_gives_the_same_records(synthetic_sd):
     offs = {70 + s: o for s, o in enumerate(episode_offsets(lens))}
     seq = inference_on_scenes(build_model(_cfg(), synthetic_sd), mk(), 0, max_rows=1 << 16, every=5, scene_episode_offset=offs)
     seen = []
-    par = inference_on_scenes(BatchedSequences(_cfg(), 2, synthetic_sd), mk(), 0, max_rows=1 << 16, every=5, scene_episode_offset=offs,
+    par = inference_on_scenes(_lockstep_model(kind, 2, synthetic_sd), mk(), 0, max_rows=1 << 16, every=5, scene_episode_offset=offs,
                               on_episode=lambda idx, inp, out: seen.append((idx, len(inp), len(out))))
     assert seq["frames"] == par["frames"] == sum(lens)
     assert sorted(seen) == [(0, 20, 20), (1, 5, 5), (2, 20, 20), (3, 20, 20), (4, 12, 12)]

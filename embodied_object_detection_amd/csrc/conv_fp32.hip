@@ -23,6 +23,9 @@
 #ifndef EOD_MFMA_PRIO
 #define EOD_MFMA_PRIO 1
 #endif
+#ifndef EOD_LDS_PIPE
+#define EOD_LDS_PIPE 1
+#endif
 
 namespace eodconv {
 namespace {
@@ -217,25 +220,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(Bs + (lr + RPP * j) * LS + 4 * lq) = br[j];
     __syncthreads();
     if (next_chunk < c_end) load_chunk(next_chunk, ar, br);
+    if constexpr (EOD_LDS_PIPE && TM * TN == 1) {
+      // 64x64 tile: the fragment reads of k-step kk + 1 are issued before the four MFMAs of k-step kk (two fragment sets in
+      // registers), so that the LDS latency runs under the MFMAs of the same wave instead of after them
+      f32x4 af[2], bf[2];
+      af[0] = *reinterpret_cast<const f32x4*>(a_base);
+      bf[0] = *reinterpret_cast<const f32x4*>(b_base);
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 af[TM], bf[TN];
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 8) {
+          af[nxt] = *reinterpret_cast<const f32x4*>(a_base + (kk + 1) * 8);
+          bf[nxt] = *reinterpret_cast<const f32x4*>(b_base + (kk + 1) * 8);
+        }
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
+        for (int tt = 0; tt < 4; ++tt)
+          if (tt & 1)
+            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][tt], bf[cur][tt], acc_b, 0, 0, 0);
+          else
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][tt], bf[cur][tt], acc[0][0], 0, 0, 0);
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LS + kk * 8);
-      if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LS + kk * 8);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LS + kk * 8);
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            if (TM * TN == 1 && (tt & 1))
-              acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc_b, 0, 0, 0);
-            else
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
-      if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              if (TM * TN == 1 && (tt & 1))
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc_b, 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+        if (EOD_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+      }
     }
     __syncthreads();
   };

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void normalize_f16_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------------
 // a16-a19 write path: three launches
-//   mw_cover_kernel    unique instance rows (custom_rcnn.py:875), per-pixel cover count, observed pixels per 4096-pixel block,
+//   mw_cover_kernel    unique instance rows (custom_rcnn.py:875), per-pixel cover count, observed pixels per SCAN_ELEMS-pixel block,
 //                      cells the frame hits
 //   mw_scatter_kernel  every 8th observed pixel in row-major order (custom_rcnn.py:913-914) adds its 1/cover share to the
 //                      (cell, instance) weight table
@@ -110,7 +110,7 @@ struct MwWs {
   int* cell_flag;   // [N] any pixel of the frame hit the cell                                   (zero between calls)
   int* cell_cnt;    // [N] number of sampled pixels that hit the cell                             (zero between calls)
   long long* wtab;  // [N, K_cap] fixed point 2^-32: sum over the cell's sampled pixels of 1/cover for every instance (zero between calls)
-  int* blk_pix;     // [ceil(P/4096)]
+  int* blk_pix;     // [ceil(P/SCAN_ELEMS)]
   size_t bytes;
 };
 
@@ -197,7 +197,7 @@ __device__ __forceinline__ int clamp_cell(int cell, int n_cells) { return cell <
 
 
 // The instances whose box (grown by one mask pixel: a sample further out is exactly zero) reaches the image rows of this block's
-// 4096 pixels, in instance order: cand_s[i] = index k into the unique list, box_s[i] = its box.  Returns their number.
+// SCAN_ELEMS pixels, in instance order: cand_s[i] = index k into the unique list, box_s[i] = its box.  Returns their number.
 __device__ __forceinline__ int block_band_candidates(const float* __restrict__ boxes, const int* rows_s, int K, int W, int P,
                                                      int* cand_s, float* box_s, int* ncand_s) {
   const int p0 = blockIdx.x * SCAN_ELEMS;
@@ -232,9 +232,10 @@ __device__ __forceinline__ int block_band_candidates(const float* __restrict__ b
   return *ncand_s;
 }
 
-// exclusive scan over the 1024 threads of a workgroup (16 waves)
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
-  __shared__ int wsum[16];
+// exclusive scan over the SCAN_ELEMS threads of a workgroup
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  constexpr int NW = SCAN_ELEMS / 64;
+  __shared__ int wsum[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -246,7 +247,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   __syncthreads();
   int before = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const int c = wsum[w];
     if (w < wave) before += c;
     all += c;
@@ -297,8 +298,11 @@ __device__ __forceinline__ bool mask_hit_row(const float* __restrict__ m, const 
   return v >= thr;
 }
 
-// Launch 1.  Block = 1024 threads = 1024 consecutive pixels.
-__global__ __launch_bounds__(1024) void mw_cover_kernel(const float* boxes, const float* masks, const int* det_rows, const int* det_count,
+// Launch 1.  Block = SCAN_ELEMS threads = SCAN_ELEMS consecutive pixels.  (256-thread workgroups -- which fit into a CU wherever one
+// 4-wave implicit-GEMM workgroup of the concurrent detection pass fits -- were measured in the frame: the write took 0.31 ms beside
+// the detection pass instead of 0.26 ms, 280 against 283 frames/s: four times the workgroups repeat the per-block row list and
+// band set-up, and the stretch of the write beside the GEMMs is not a matter of wave slots.)
+__global__ __launch_bounds__(SCAN_ELEMS) void mw_cover_kernel(const float* boxes, const float* masks, const int* det_rows, const int* det_count,
                                                          int K_cap, int R_cap, const int* proj, int H, int W, int n_cells, float thr,
                                                          unsigned char* cover, int* cell_flag, int* blk_pix, int* inst_rows, int* k_u,
                                                          int* k_out, int* __restrict__ err, size_t ws_stride) {
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* boxes, cons
     cell_flag[cell] = 1;
   }
   int total;
-  block_exclusive_scan_1024(cnt > 0 ? 1 : 0, &total);
+  block_exclusive_scan(cnt > 0 ? 1 : 0, &total);
   if (threadIdx.x == 0) blk_pix[blockIdx.x] = total;
   if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
 }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(1024) void mw_cover_kernel(const float* boxes, cons
 //   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
 // so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
 // bitwise reproducible) instead of 512 channel atomics.
-__global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* boxes, const float* masks, const int* inst_rows, const int* k_u,
+__global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* boxes, const float* masks, const int* inst_rows, const int* k_u,
                                                            const unsigned char* cover, const int* blk_pix, const int* proj, int H, int W,
                                                            int n_cells, int K_cap, float thr, long long* wtab, int* cell_cnt, int R_cap,
                                                            size_t ws_stride) {
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(1024) void mw_scatter_kernel(const float* boxes, co
   const int p = blockIdx.x * SCAN_ELEMS + threadIdx.x;
   const int cv = p < P ? (int)cover[p] : 0;
   int total;
-  const int local = block_exclusive_scan_1024(cv != 0 ? 1 : 0, &total);
+  const int local = block_exclusive_scan(cv != 0 ? 1 : 0, &total);
   if (total == 0) return;                                    // no observed pixel in this block (block-uniform)
   // observed pixels in the blocks before this one (one wave; its barrier follows)
   if (threadIdx.x < 64) {
@@ -606,10 +610,10 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   const int P = d->H * d->W;
   const int pb = (P + SCAN_ELEMS - 1) / SCAN_ELEMS;
   const size_t wss = w.bytes;      // scene b's workspace starts b * wss bytes further (every carved piece is 256-byte aligned)
-  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb, nb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
+  hipLaunchKernelGGL(mw_cover_kernel, dim3(pb, nb), dim3(SCAN_ELEMS), 0, s, d->prop_boxes, d->prop_masks, d->det_rows, d->det_count, d->K_cap, d->R_cap,
                      d->proj, d->H, d->W, d->n_cells, d->mask_thresh, w.cover, w.cell_flag, w.blk_pix, w.inst_rows, w.k_u, d->k_out,
                      d->err_flags, wss);
-  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb, nb), dim3(1024), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
+  hipLaunchKernelGGL(mw_scatter_kernel, dim3(pb, nb), dim3(SCAN_ELEMS), 0, s, d->prop_boxes, d->prop_masks, w.inst_rows, w.k_u, w.cover, w.blk_pix,
                      d->proj, d->H, d->W, d->n_cells, d->K_cap, d->mask_thresh, w.wtab, w.cell_cnt, d->R_cap, wss);
   // one workgroup per CU at most: the kernel runs beside dense launches of other streams, where every workgroup dispatch waits
   // for a slot; a workgroup walks its 64-cell groups in a grid-stride loop

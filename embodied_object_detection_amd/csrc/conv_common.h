@@ -137,7 +137,7 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m_base + i * 32 + row;
-        if (m < M && n < p.Cout) {
+        if (m < M && n < p.Cout && conv_row_active(p, m)) {
           const float v = acc[i][j][r];
           if (p.splitk > 1) {
             p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;

@@ -274,7 +274,8 @@ int check_desc(const EodConvDesc* d) {
   if (d->m_count && d->m_unit <= 0) return EOD_ERR_BAD_DIMS;
   if (d->m_segments > 1) {
     // B unit lists back to back: whole images per list, a count per list
-    if (!d->m_count || d->levels > 0 || d->m_segments > EOD_MAX_BATCH || d->N % d->m_segments != 0) return EOD_ERR_BAD_DIMS;
+    if (!d->m_count || d->levels > 0 || d->out_mode == 2 || d->m_segments > EOD_MAX_BATCH || d->N % d->m_segments != 0)
+      return EOD_ERR_BAD_DIMS;
     if (((long)(d->N / d->m_segments) * d->OH * d->OW) % d->m_unit != 0) return EOD_ERR_BAD_DIMS;
   }
   if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;

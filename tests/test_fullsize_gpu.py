@@ -153,6 +153,30 @@ def test_batch_of_3_equals_3_single_runs_small(synthetic_sd, kind):
     _batch_equals_singles(synthetic_sd, 128, 160, 24, 0.5, 3, 3, kind)
 
 
+def test_lockstep_longterm_two_calls_equal_single_runs(synthetic_sd):
+    """MODEL.TEST_TYPE longterm (the fp16 snapshot is frozen after the first frame of a call: the write only marks rows) and a second
+    call that continues the scenes: N = B through every stage still equals the single-scene runs bit for bit."""
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+    cfg = lambda: _cfg(**{"MODEL.TEST_TYPE": "longterm"})
+    B, T = 2, 4
+    seqs = [SyntheticSequence(60 + b, H=128, W=160, n_frames=T, map_w=24, map_h=24, cell=0.5) for b in range(B)]
+    eps = [[s.frame(i) for i in range(T)] for s in seqs]
+    ls = LockstepScenes(cfg(), B, synthetic_sd)
+    outs = [a + b for a, b in zip(ls([e[:2] for e in eps]), ls([e[2:] for e in eps]))]
+    for b in range(B):
+        single = build_model(cfg(), synthetic_sd)
+        ref = single([eps[b][:2]]) + single([eps[b][2:]])
+        for t in range(T):
+            a, r = outs[b][t]["instances"], ref[t]["instances"]
+            assert torch.equal(a.pred_boxes.tensor, r.pred_boxes.tensor) and torch.equal(a.scores, r.scores), (b, t)
+            assert torch.equal(a.pred_masks, r.pred_masks), (b, t)
+        assert torch.equal(ls.scenes[b].implicit_memory, single.implicit_memory) and torch.equal(ls.scenes[b].observations, single.observations)
+        del single
+        torch.cuda.empty_cache()
+
+
 def test_ragged_lockstep_batch_equals_single_runs(synthetic_sd):
     """Episodes of different lengths (one scene sits most of the call out as an idle slot): every scene still gets exactly its own
     run's results and state."""

@@ -653,37 +653,41 @@ def main():
         # two independent sequences per GPU in lock-step (scenes are independent: `train_mp3d.py --scenes-in-lockstep 2`): the
         # latency-bound chains of one scene run beside the dense passes of the other
         if not distributed:
-            from embodied_object_detection_amd.modeling.batched import BatchedSequences
+            from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
             try:
-                pair = BatchedSequences(cfg, 2, sd)
-                seq2 = SyntheticSequence(1000 + rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell)
-                fr2 = []
-                for i in range(n_frames - 1):
-                    f = seq2.frame(i)
-                    f["image"] = f["image"].to(dev)
-                    f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
-                    fr2.append(f)
-                half = args.steps // 2
-                both = lambda lo, hi: [e[lo:hi] for e in (frames[:n_frames - 1], fr2)]
-                for e0 in range(0, args.warmup, EPISODE_LEN):
-                    pair(both(e0, min(args.warmup, e0 + EPISODE_LEN)))
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                n2 = 0
-                for e0 in range(args.warmup, args.warmup + half, EPISODE_LEN):
-                    o2 = pair(both(e0, min(args.warmup + half, e0 + EPISODE_LEN)))
-                    n2 += sum(len(o) for o in o2)
-                torch.cuda.synchronize()
-                el2 = time.perf_counter() - t0
-                log(f"two sequences in lock-step: {el2:.3f} s for {n2} frames ({n2 / el2:.1f} frames/s)")
-                variants["two_sequences_in_lockstep"] = {
-                    "value": round(n2 / el2, 3), "unit": "frames/s", "ms_per_step": round(el2 / max(n2, 1) * 1e3, 3),
-                    "note": f"BatchedSequences(cfg, 2): two independent scenes per GPU, {half} steps of 2 frames, through the boundary "
-                            "(Instances materialised), episodes of 20; the memory-independent trunk runs once per step with N = 2 as "
-                            "a look-ahead, every scene keeps its own memory; per-scene results bitwise those of a single-scene run "
-                            "(tests/test_fullsize_gpu.py)"}
-                del pair, fr2
-                torch.cuda.empty_cache()
+                for nb, key in ((2, "two_sequences_in_lockstep"), (4, "four_sequences_in_lockstep")):
+                    group = LockstepScenes(cfg, nb, sd)
+                    eps = [frames[:n_frames - 1]]
+                    for extra in range(1, nb):
+                        seq2 = SyntheticSequence(1000 * extra + rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell)
+                        fr2 = []
+                        for i in range(n_frames - 1):
+                            f = seq2.frame(i)
+                            f["image"] = f["image"].to(dev)
+                            f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
+                            fr2.append(f)
+                        eps.append(fr2)
+                    part = args.steps // 2
+                    cut = lambda lo, hi: [e[lo:hi] for e in eps]
+                    for e0 in range(0, args.warmup, EPISODE_LEN):
+                        group(cut(e0, min(args.warmup, e0 + EPISODE_LEN)))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n2 = 0
+                    for e0 in range(args.warmup, args.warmup + part, EPISODE_LEN):
+                        o2 = group(cut(e0, min(args.warmup + part, e0 + EPISODE_LEN)))
+                        n2 += sum(len(o) for o in o2)
+                    torch.cuda.synchronize()
+                    el2 = time.perf_counter() - t0
+                    log(f"{nb} sequences in lock-step: {el2:.3f} s for {n2} frames ({n2 / el2:.1f} frames/s)")
+                    variants[key] = {
+                        "value": round(n2 / el2, 3), "unit": "frames/s", "ms_per_step": round(el2 / max(n2, 1) * 1e3, 3),
+                        "note": f"LockstepScenes(cfg, {nb}): {nb} independent scenes per GPU, {part} steps of {nb} frames, through the boundary "
+                                f"(Instances materialised), episodes of 20; N = {nb} through every stage of the frame (one launch per stage "
+                                "for all scenes), every scene keeps its own memory; per-scene results bitwise those of a single-scene run "
+                                "(tests/test_fullsize_gpu.py)"}
+                    del group, eps
+                    torch.cuda.empty_cache()
             except Exception as e:      # never lose the headline to a variant
                 log(f"lock-step variant failed: {e!r}")
 

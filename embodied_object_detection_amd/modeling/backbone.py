@@ -45,12 +45,13 @@ class ResNet50Trunk:
                     ds = ops.Conv(wd, bd, stride=stride, device=device, name=f"{p}.downsample")
                 self.blocks.append((li, c1, c2, c3, ds))
 
-    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1):
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, plan_like_single: bool = True):
         """x4: [N,H,W,4] normalised image(s) -> {'layer3','layer4','layer5'}: (tensor, h, w).  N > 1: every layer is ONE launch
-        over the batch, planned like a single image (`plan_rows`), so each image's result is bitwise that of an N = 1 call."""
+        over the batch, planned like a single image (`plan_rows`), so each image's result is bitwise that of an N = 1 call
+        (`plan_like_single = False`: planned for the rows the launch really has)."""
         def pr(conv, hh, ww):
             oh, ow = conv.out_hw(hh, ww)
-            return oh * ow if N > 1 else 0
+            return oh * ow if (N > 1 and plan_like_single) else 0
 
         x = self.stem(x4, N, H, W, relu=True, plan_rows=pr(self.stem, H, W))
         h, w = self.stem.out_hw(H, W)

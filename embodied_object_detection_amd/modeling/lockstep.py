@@ -73,6 +73,12 @@ class LockstepScenes:
         self.scenes = [_SceneView(self, b) for b in range(self.B)]
         self.trunk_lookahead = True          # step t + 1's memory-independent trunk on its own stream beside step t's chain
         self.trail_detection_pass = True     # step t's detection mask pass + paste under step t + 1's latency-bound front
+        # True: every layer is planned like ONE scene (same split-K slabs / wave split, same summation order): each scene's results are
+        # bitwise those of its own single-scene run.  False: layers are planned for the rows the batched launch really has (fewer
+        # slabs and reduce launches, 64x64 tiles instead of the wave-split kernel on the B x R rows of the FC layers): the same
+        # arithmetic in another summation order -- results agree with the single-scene run like two fp32 implementations do
+        # (tests/test_fullsize_gpu.py::test_lockstep_planned_for_the_batch_agrees_within_tolerance)
+        self.plan_like_single = True
         self.implicit_memory: Optional[torch.Tensor] = None     # [B,N,512]
         self.observations: Optional[torch.Tensor] = None        # [B,N]
         self._mem_f16 = self._dirty = None
@@ -91,7 +97,10 @@ class LockstepScenes:
         self._slot = 0
         self._step_no = 0
         self.stats_log = None
+        self.trace = None                    # diagnostics: list of (step, name, timing event), see tools/frame_schedule.py
         self.host_profile = {"frames": 0, "enqueue_s": 0.0, "materialize_s": 0.0, "wait_s": 0.0}
+        if bool(cfg.MODEL.TEST_SAVE_SEMMAP):
+            raise NotImplementedError("MODEL.TEST_SAVE_SEMMAP is served by the single-scene model (custom_rcnn.py:518-530)")
         R, C1, dev, B = m.proposal_generator.cap, m.C1, self.device, self.B
         rh = m.roi_heads
         f32 = dict(dtype=torch.float32, device=dev)
@@ -131,6 +140,16 @@ class LockstepScenes:
 
     def __call__(self, episodes):
         return self.forward(episodes)
+
+    def _pr(self, rows: int) -> int:
+        return rows if self.plan_like_single else 0
+
+    def _mark(self, name: str, stream=None):
+        if self.trace is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        self.trace.append((self._step_no, name, ev))
 
     # ---- buffers that depend on the frame size -----------------------------------------------------------------------------
     def _frame_buffers(self, H: int, W: int, n_cells: int):
@@ -222,15 +241,15 @@ class LockstepScenes:
         x = d["x"]
         for b, f in enumerate(frames):
             ops.preprocess_image(m._device_image(f), m.pixel_mean, m.pixel_std, out=x[b:b + 1])
-        c = bb.bottom_up.forward(x, H, W, N=B)
+        c = bb.bottom_up.forward(x, H, W, N=B, plan_like_single=self.plan_like_single)
         (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
         views = d["pyr"][which][1]
-        lat5 = bb.lateral[5](c5, B, h5, w5, plan_rows=h5 * w5)
-        bb.output[5](lat5, B, h5, w5, out=views[2], plan_rows=h5 * w5)
-        lat4 = bb.lateral[4](c4, B, h4, w4, res=lat5, res_mode=2, plan_rows=h4 * w4)
-        bb.output[4](lat4, B, h4, w4, out=views[1], plan_rows=h4 * w4)
-        lat3 = bb.lateral[3](c3, B, h3, w3, res=lat4, res_mode=2, plan_rows=h3 * w3)
-        bb.output[3](lat3, B, h3, w3, out=views[0], plan_rows=h3 * w3)
+        lat5 = bb.lateral[5](c5, B, h5, w5, plan_rows=self._pr(h5 * w5))
+        bb.output[5](lat5, B, h5, w5, out=views[2], plan_rows=self._pr(h5 * w5))
+        lat4 = bb.lateral[4](c4, B, h4, w4, res=lat5, res_mode=2, plan_rows=self._pr(h4 * w4))
+        bb.output[4](lat4, B, h4, w4, out=views[1], plan_rows=self._pr(h4 * w4))
+        lat3 = bb.lateral[3](c3, B, h3, w3, res=lat4, res_mode=2, plan_rows=self._pr(h3 * w3))
+        bb.output[3](lat3, B, h3, w3, out=views[0], plan_rows=self._pr(h3 * w3))
 
     def _enqueue_trunk_ahead(self, frames: List[dict], H: int, W: int):
         if self._trunk_stream is None:
@@ -241,8 +260,10 @@ class LockstepScenes:
         if nxt in self._pyr_reader:
             ts.wait_event(self._pyr_reader[nxt])            # a trailing detection pass may still read that set
         with torch.cuda.stream(ts):
+            self._mark("trunk_lookahead_begin", ts)
             self._trunk(frames, H, W, nxt)
             self._ev_trunk.record(ts)
+            self._mark("trunk_lookahead", ts)
         self._prefetched = tuple(id(f["image"]) for f in frames)
 
     # ---- one step: one frame of every scene ----------------------------------------------------------------------------------
@@ -259,6 +280,7 @@ class LockstepScenes:
         cur = torch.cuda.current_stream(dev)
         R, D, C1 = self.R, self.D, m.C1
         self._step_no += 1
+        self._mark("start")
         for b, f in enumerate(frames):
             p = m._device_proj(f)
             if tuple(p.shape) != (H, W):
@@ -292,18 +314,19 @@ class LockstepScenes:
                                    batch=B)
             bb.merge(d["pooled"], feats, H, W, bb.map_feature_weight, bb.feat_fusion, batch=B)
         (h5, w5), (h6, w6), (h7, w7) = shapes[2], shapes[3], shapes[4]
-        bb.p6(views[2], B, h5, w5, out=views[3], plan_rows=h6 * w6)
-        bb.p7(views[3], B, h6, w6, in_relu=True, out=views[4], plan_rows=h7 * w7)
+        bb.p6(views[2], B, h5, w5, out=views[3], plan_rows=self._pr(h6 * w6))
+        bb.p7(views[3], B, h6, w6, in_relu=True, out=views[4], plan_rows=self._pr(h7 * w7))
 
         # CenterNet tower + proposals (centernet_head.py:141-161, centernet.py:603-745)
         lv = (d["offB"], d["shapesB"])
         src = feats
         for (conv, gamma, beta) in pg.tower:
-            conv(src, 1, 0, 0, out=d["tower_a"], levels=lv, plan_rows=P)
+            conv(src, 1, 0, 0, out=d["tower_a"], levels=lv, plan_rows=self._pr(P))
             ops.groupnorm_relu(d["tower_a"], gamma, beta, d["offB"], 256, d["gn_ws"], out=d["tower_b"])
             src = d["tower_b"]
-        pg.out_conv(src, 1, 0, 0, out=d["head"], levels=lv, plan_rows=P)
+        pg.out_conv(src, 1, 0, 0, out=d["head"], levels=lv, plan_rows=self._pr(P))
         prop_boxes, prop_scores, prop_count = d["dec"](d["head"])
+        self._mark("proposals")
         if look:
             self._enqueue_trunk_ahead(next_frames, H, W)
 
@@ -314,7 +337,7 @@ class LockstepScenes:
             cur.wait_event(self._ev_det[k])                     # detection list set k is still read by the pass of RESULT_SETS steps ago
         update_mem = use_mem or m.always_update_memory
         boxes = prop_boxes
-        seg = dict(m_count=prop_count, m_unit=1, m_segments=B, plan_rows=R)
+        seg = dict(m_count=prop_count, m_unit=1, m_segments=B, plan_rows=self._pr(R))
         for s_i, st in enumerate(rh.stages):
             ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, prop_count, B * R, 7, out=self.pool7, batch=B, boxes_per_image=R)
             st["fc1"](self.pool7, B * R, 1, 1, relu=True, out=self.h1, **seg)
@@ -340,6 +363,7 @@ class LockstepScenes:
                     s_raw = torch.cuda.current_stream(dev).cuda_stream
                     _lib.check(_lib.load().eod_fill_i32(mem_cnt[b:b + 1].data_ptr(), 0, 1, s_raw), "fill")
                     _lib.check(_lib.load().eod_fill_i32(msel.uniq_count[b:b + 1].data_ptr(), 0, 1, s_raw), "fill")
+        self._mark("cascade+mem_select")
         sel = self.selectors[k]
         det_boxes, det_scores, det_classes, det_rows, det_count = sel(boxes, self.prob, prop_count, float(W), float(H), rh.score_thresh,
                                                                      rh.nms_thresh)
@@ -354,8 +378,10 @@ class LockstepScenes:
             ds = self._det_stream
             ds.wait_event(self._ev_box)
             with torch.cuda.stream(ds):
+                self._mark("det_pass_begin", ds)
                 self._detection_pass(views, h3, w3, sel, k, H, W, post)
                 self._ev_det[k].record(ds)
+                self._mark("det_pass", ds)
             self._pyr_reader[which] = self._ev_det[k]
         else:
             self._detection_pass(views, h3, w3, sel, k, H, W, post)
@@ -365,6 +391,7 @@ class LockstepScenes:
             ops.concat_lists(msel.uniq_rows, msel.uniq_count, R, R, B, self.glist_p, self.total_p)
             self._mask_pass(views, h3, w3, prop_boxes, self.glist_p, self.total_p, B * self.Pcap, R, self.prop_masks, self.pm_bufs,
                             plan_rois=self.Pcap, tag=("prop", self._step_no))
+            self._mark("prop_masks")
             follow = m.snapshot_follows_write if m.snapshot_follows_write is not None else m.test_type in ("default", "episodic")
             wr = d["writer"]
             if follow and self._f16_valid and not self._dirty_pending:
@@ -374,6 +401,7 @@ class LockstepScenes:
                 wr(self.featn0, prop_boxes, self.prop_masks, mem_rows, mem_cnt, d["proj"], self.implicit_memory, self.observations,
                    dirty=self._dirty, err=self._err)
                 self._dirty_pending = True
+            self._mark("mem_write")
         if self.trail_detection_pass and not trailing:
             cur.wait_event(self._ev_det[k])
         if self.stats_log is not None:
@@ -395,10 +423,10 @@ class LockstepScenes:
                       boxes_per_image=boxes_per_image)
         for conv in rh.mask_convs:
             conv.event_tag = tag
-            conv(src, cap, 14, 14, relu=True, m_count=total, m_unit=196, out=dst, plan_rows=plan_rois * 196)
+            conv(src, cap, 14, 14, relu=True, m_count=total, m_unit=196, out=dst, plan_rows=self._pr(plan_rois * 196))
             src, dst = dst, src
         rh.deconv(src, cap, 14, 14, relu=True, m_count=total, m_unit=196, out=out, fuse=(rh.pred_w, rh.pred_b, glist),
-                  plan_rows=plan_rois * 196)
+                  plan_rows=self._pr(plan_rois * 196))
 
     def _detection_pass(self, views, h3, w3, sel, k, H, W, post):
         m, B, D, dev = self.model, self.B, self.D, self.device

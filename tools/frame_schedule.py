@@ -17,26 +17,49 @@ from embodied_object_detection_amd.data.synthetic import SyntheticSequence
 H = W = 640
 dev = torch.device("cuda:0")
 cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5])
-model = build_model(cfg, synthetic_state_dict(0))
+LOCKSTEP = int(os.environ.get("LOCKSTEP", 0))      # B > 1: the schedule of a LockstepScenes step (B frames) instead of a frame
+if LOCKSTEP > 1:
+    from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+    model = LockstepScenes(cfg, LOCKSTEP, synthetic_state_dict(0))
+else:
+    model = build_model(cfg, synthetic_state_dict(0))
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     setattr(model, k, eval(v))
-seq = SyntheticSequence(0, H=H, W=W, n_frames=60)
-frames = []
-for i in range(60):
-    f = seq.frame(i)
-    f["image"] = f["image"].to(dev)
-    f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
-    frames.append(f)
-model([frames[:20]])
-torch.cuda.synchronize()
-model.trace = []
+
+
+def resident(seed):
+    seq = SyntheticSequence(seed, H=H, W=W, n_frames=60)
+    out = []
+    for i in range(60):
+        f = seq.frame(i)
+        f["image"] = f["image"].to(dev)
+        f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
+        out.append(f)
+    return out
+
+
 import time
-t0 = time.perf_counter()
-model([frames[20:40]])
-model([frames[40:60]])
-torch.cuda.synchronize()
-print(f"{40 / (time.perf_counter() - t0):.1f} frames/s with the trace events in")
+if LOCKSTEP > 1:
+    eps = [resident(b) for b in range(LOCKSTEP)]
+    model([e[:20] for e in eps])
+    torch.cuda.synchronize()
+    model.trace = []
+    t0 = time.perf_counter()
+    model([e[20:40] for e in eps])
+    model([e[40:60] for e in eps])
+    torch.cuda.synchronize()
+    print(f"{40 * LOCKSTEP / (time.perf_counter() - t0):.1f} frames/s with the trace events in ({LOCKSTEP} scenes in lock-step: times per STEP)")
+else:
+    frames = resident(0)
+    model([frames[:20]])
+    torch.cuda.synchronize()
+    model.trace = []
+    t0 = time.perf_counter()
+    model([frames[20:40]])
+    model([frames[40:60]])
+    torch.cuda.synchronize()
+    print(f"{40 / (time.perf_counter() - t0):.1f} frames/s with the trace events in")
 by = collections.defaultdict(dict)
 for fr, name, ev in model.trace:
     by[fr][name] = ev

@@ -756,10 +756,20 @@ def main():
             sel = [by_wg[w_] for w_ in (3676, 1568) if w_ in by_wg]
             if sel:
                 n_ = sum(s_["launches"] for s_ in sel)
+                tags_ = [t_[0] for (_s, _e, t_) in ev]
+                mean_flop = {3676: [f_ for f_, g_ in zip(flops, tags_) if g_ == "det"], 1568: [f_ for f_, g_ in zip(flops, tags_) if g_ != "det"]}
+                # this run's mean FLOPs per launch of each pass over the committed trace's mean kernel duration of that launch shape
+                fl_ = sum((sum(mean_flop[s_["workgroups"]]) / max(1, len(mean_flop[s_["workgroups"]]))) * s_["launches"] for s_ in sel)
+                us_ = sum(s_["avg_us"] * s_["launches"] for s_ in sel)
                 roofline["rocprof"] = {"file": "profiles/r03_dominant_kernel_rocprof.json",
-                                       "avg_launch_ms": round(sum(s_["avg_us"] * s_["launches"] for s_ in sel) / n_ * 1e-3, 4),
+                                       "avg_launch_ms": round(us_ / n_ * 1e-3, 4),
+                                       "achieved": round(fl_ / (us_ * 1e-6) / 1e12, 3), "frac": round(fl_ / (us_ * 1e-6) / 1e12 / peak, 4),
                                        "by_workgroups": {str(s_["workgroups"]): {"launches": s_["launches"], "avg_us": s_["avg_us"],
-                                                                                 "min_us": s_["min_us"]} for s_ in sel}}
+                                                                                 "min_us": s_["min_us"]} for s_ in sel},
+                                       "note": "rocprofv3 --kernel-trace of this command: a kernel's duration from its first wave to its "
+                                               "last; the event brackets above also contain the launch's wait for workgroup slots beside "
+                                               "the other streams' kernels (the detection pass runs at normal priority under three "
+                                               "high-priority chains), which is why they are ~15 % longer"}
         if ev_excl:
             d2 = [s_.elapsed_time(e_) for (s_, e_, _c) in ev_excl]
             f2 = [2.0 * r_ * 196 * 256 * 2304 for r_ in rows_of(ev_excl, excl_counts)]

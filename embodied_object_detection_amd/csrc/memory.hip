@@ -10,6 +10,7 @@
 // Detic/detic/modeling/meta_arch/custom_rcnn.py:884-936); here the gather is fused with the pooling and the
 // write works on the sparse set of selected pixels only.
 #include "eod_common.h"
+#include <cstdlib>
 #include "memory_rows.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
@@ -396,13 +397,31 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* box
   if (((first + 7) & ~7) >= first + total) return;           // block-uniform
   const int nc = block_band_candidates(boxes, rows_s, K, W, P, cand_s, box_s, &ncand_s);
   const int rank = first + local;
-  if (cv == 0 || (rank & 7) != 0) return;                    // every 8th observed pixel, row-major (custom_rcnn.py:913-914)
-  const int y = p / W, x = p - y * W;
+  // every 8th observed pixel, row-major (custom_rcnn.py:913-914): at most SCAN_ELEMS / 8 of the block's pixels.  They are compacted
+  // into a list, and EIGHT lanes share one sampled pixel: lane j tests band candidates j, j + 8, ... (the mask gathers of one pixel
+  // against ~40 candidates were a serial chain on one lane in eight), the hit sets are OR-ed over the eight lanes.
+  __shared__ int samp_s[SCAN_ELEMS / 8];
+  __shared__ int nsamp_s;
+  if (threadIdx.x == 0) nsamp_s = 0;
+  __syncthreads();
+  {
+    const bool mine = cv != 0 && (rank & 7) == 0;
+    const unsigned long long bal = __ballot(mine);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && bal) base = atomicAdd(&nsamp_s, __popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (mine) samp_s[base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull))] = p;
+  }
+  __syncthreads();
+  const int slot = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  if (slot >= nsamp_s) return;              // uniform over the 8 lanes of a slot; no barrier follows
+  const int sp = samp_s[slot];
+  const int y = sp / W, x = sp - y * W;
   const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
-  const int cell = clamp_cell(proj[p], n_cells);
-  // the instances that cover this pixel (bit i = band candidate i; MW_MAX_K <= 128 candidates), then 1 / cover to each of them
+  const int cell = clamp_cell(proj[sp], n_cells);
+  // bit i = band candidate i covers this pixel (MW_MAX_K <= 128 candidates)
   unsigned long long hit0 = 0, hit1 = 0;
-  for (int i = 0; i < nc; ++i) {
+  for (int i = sub; i < nc; i += 8) {
     const float x0 = box_s[i * 4 + 0], y0 = box_s[i * 4 + 1], x1 = box_s[i * 4 + 2], y1 = box_s[i * 4 + 3];
     const float mx = (x1 - x0) * (1.0f / 14.0f), my = (y1 - y0) * (1.0f / 14.0f);
     if (fxp < x0 - mx || fxp > x1 + mx || fyp < y0 - my || fyp > y1 + my) continue;
@@ -412,30 +431,39 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* box
       else hit1 |= 1ull << (i - 64);
     }
   }
+  const unsigned long long mine0 = hit0, mine1 = hit1;      // the hits this lane found: it also adds their shares
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    hit0 |= __shfl_xor(hit0, off, 64);
+    hit1 |= __shfl_xor(hit1, off, 64);
+  }
   const int ncov = __popcll(hit0) + __popcll(hit1);          // >= 1: the pixel is observed
   const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)ncov);
   long long* dst = wtab + (size_t)cell * K_cap;
-  atomicAdd(cell_cnt + cell, 1);
-  while (hit0) {
-    const int i = (int)__ffsll((long long)hit0) - 1;
-    hit0 &= hit0 - 1;
+  if (sub == 0) atomicAdd(cell_cnt + cell, 1);
+  unsigned long long m0 = mine0, m1 = mine1;
+  while (m0) {
+    const int i = (int)__ffsll((long long)m0) - 1;
+    m0 &= m0 - 1;
     atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
   }
-  while (hit1) {
-    const int i = (int)__ffsll((long long)hit1) - 1;
-    hit1 &= hit1 - 1;
+  while (m1) {
+    const int i = (int)__ffsll((long long)m1) - 1;
+    m1 &= m1 - 1;
     atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[64 + i]), share);
   }
 }
 
-// Launch 3.  The 4 waves of a workgroup share one 64-cell group and split its hit cells (bit index mod 4); one wave per cell,
+// Launch 3.  The NW (4 or 16) waves of a workgroup share one 64-cell group and split its hit cells (bit index mod NW): the cells a
+// frame writes are a few compact regions of the map, i.e. a few groups with many hit cells each, and a cell is a dependent chain
+// (weight row -> instance rows -> memory row) of ~1.5 us: 16 waves per group shorten the longest chain 4x.  One wave per cell,
 // 8 consecutive channels per lane.  For a cell with sampled pixels: mean = (sum_k W_k f_k) / n in f64 (instance order),
 // mem[cell] += mean (custom_rcnn.py:738-743).  Every hit cell: observation counter + 1 (custom_rcnn.py:699-701,743) and either its
 // row of the fp16 snapshot (`snapshot`: the table the next frame's gather reads -- what eod_memory_normalize_dirty_f16 would do
 // at the start of the next frame, without its launch and its scan of the flags) or its `dirty` mark.  Resets the per-frame
 // tables it consumed (flags, counts, weight-table entries).
-template <bool SNAPSHOT>
-__global__ __launch_bounds__(256) void mw_commit_kernel(int* cell_flag, int* cell_cnt, long long* wtab, const int* k_u, const int* inst_rows,
+template <bool SNAPSHOT, int NW>
+__global__ __launch_bounds__(64 * NW) void mw_commit_kernel(int* cell_flag, int* cell_cnt, long long* wtab, const int* k_u, const int* inst_rows,
                                                          const float* featn, int K_cap, int N, float* obs, float* mem, __half* snapshot,
                                                          int* dirty, int R_cap, size_t ws_stride) {
   EOD_CHAIN_PRIO();
@@ -469,7 +497,8 @@ __global__ __launch_bounds__(256) void mw_commit_kernel(int* cell_flag, int* cel
       if (n) cell_cnt[c] = 0;
       if (!SNAPSHOT && dirty) dirty[c] = 1;
     }
-    unsigned long long bal = __ballot(f != 0) & (0x1111111111111111ull << wave);
+    // wave w takes the hit cells whose bit index is w modulo NW
+    unsigned long long bal = __ballot(f != 0) & ((NW == 4 ? 0x1111111111111111ull : 0x0001000100010001ull) << wave);
     while (bal) {
       const int bit = (int)__ffsll((long long)bal) - 1;
       bal &= bal - 1;
@@ -620,12 +649,24 @@ extern "C" int eod_memory_write(const EodMemWriteDesc* d, eod_stream_t stream) {
   int groups = (d->n_cells + 63) / 64;
   if (groups > 256) groups = 256;
   if (nb > 1 && groups > 256 / nb) groups = 256 / nb;
-  if (d->snapshot_f16)
-    hipLaunchKernelGGL(mw_commit_kernel<true>, dim3(groups, nb), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
-                       d->K_cap, d->n_cells, d->obs, d->mem, reinterpret_cast<__half*>(d->snapshot_f16), (int*)nullptr, d->R_cap, wss);
+  static const int commit_waves = [] {
+    const char* e = getenv("EOD_MW_COMMIT_WAVES");
+    return (e && atoi(e) == 4) ? 4 : 16;
+  }();
+  const dim3 cg(groups, nb);
+  __half* snap = reinterpret_cast<__half*>(d->snapshot_f16);
+  if (d->snapshot_f16 && commit_waves == 16)
+    hipLaunchKernelGGL((mw_commit_kernel<true, 16>), cg, dim3(1024), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, snap, (int*)nullptr, d->R_cap, wss);
+  else if (d->snapshot_f16)
+    hipLaunchKernelGGL((mw_commit_kernel<true, 4>), cg, dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, snap, (int*)nullptr, d->R_cap, wss);
+  else if (commit_waves == 16)
+    hipLaunchKernelGGL((mw_commit_kernel<false, 16>), cg, dim3(1024), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty, d->R_cap, wss);
   else
-    hipLaunchKernelGGL(mw_commit_kernel<false>, dim3(groups, nb), dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows,
-                       d->featn, d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty, d->R_cap, wss);
+    hipLaunchKernelGGL((mw_commit_kernel<false, 4>), cg, dim3(256), 0, s, w.cell_flag, w.cell_cnt, w.wtab, w.k_u, w.inst_rows, d->featn,
+                       d->K_cap, d->n_cells, d->obs, d->mem, (__half*)nullptr, d->dirty, d->R_cap, wss);
   return eod_launch_status();
 }
 

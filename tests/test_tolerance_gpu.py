@@ -27,7 +27,7 @@ from oracle import ops as OO
 import _write_parity as WP
 
 TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 on box coords/scores"
-CASES = [(128, 160, 24, 4), (480, 640, 60, 2), (640, 640, 200, 2)]
+CASES = [(128, 160, 24, 3), (480, 640, 60, 2), (640, 640, 200, 2)]
 
 
 def _cfg():

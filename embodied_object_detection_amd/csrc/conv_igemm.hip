@@ -132,6 +132,14 @@ struct Plan {
   int wavek;  // 0, or the number of waves (4 / 8) of the 32x32-tile kernel that splits K over the waves of a workgroup
 };
 
+inline int midsplit_env() {          // experiment knob: EOD_CONV_MIDSPLIT=0 turns the 256..1024-tile split-K rule off
+  static const int v = [] {
+    const char* e = getenv("EOD_CONV_MIDSPLIT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 inline int wavek_env() {
   static const int v = [] {
     const char* e = getenv("EOD_CONV_WAVEK");
@@ -208,7 +216,7 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
     int maxs = nchunks / 4;
     splitk = want < maxs ? want : maxs;
     if (splitk < 1) splitk = 1;
-  } else if (tiles >= 256 && tiles <= 1024 && d->m_count == nullptr && nchunks >= 18) {
+  } else if (tiles >= 256 && tiles <= 1024 && d->m_count == nullptr && nchunks >= 18 && midsplit_env()) {
     // A few hundred tiles on 256 CUs: every workgroup is resident at once and a CU works through its workgroups' MFMAs one
     // after the other, so the launch takes ceil(tiles / 256) tile times -- the CenterNet tower's 536 tiles take 3 where 2.09
     // would do.  Split-K makes the units finer: time ~ ceil(tiles * s / 256) / s (+ ~0.12 of a tile for the slab reduce).

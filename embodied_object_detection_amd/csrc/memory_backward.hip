@@ -23,6 +23,7 @@
 #include "eod_common.h"
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
+#include <cmath>
 
 namespace {
 
@@ -132,7 +133,42 @@ __global__ __launch_bounds__(256) void pool_backward_kernel(PoolBwdArgs a) {
   }
 }
 
+// torch.optim.AdamW, single-tensor form (the reference trains with SOLVER.OPTIMIZER ADAMW, Base-C2_L_R5021k_640b64_4x_recurrent.yaml:69),
+// preceded by detectron2's per-parameter clip_grad_value_ (SOLVER.CLIP_GRADIENTS.ENABLED, CLIP_TYPE "value"):
+//   g = clamp(g, -clip, clip);  p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;
+//   p += -step_size * (m / (sqrt(v) / bc2_sqrt + eps)),   step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t) (host, double)
+__global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, size_t n, float decay, float one_minus_b1, float b2,
+                                                          float one_minus_b2, float step_size, float bc2_sqrt, float eps, float clip) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    float pi = p[i] * decay;
+    float mi = m[i];
+    mi = mi + (gi - mi) * one_minus_b1;
+    const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi + (-step_size) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace
+
+extern "C" int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int step, double clip_value, eod_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return EOD_ERR_NULL;
+  if (n == 0 || step < 1 || !(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return EOD_ERR_BAD_DIMS;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                     (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
+                     (float)sqrt(bc2), (float)eps, (float)clip_value);
+  return eod_launch_status();
+}
 
 extern "C" int eod_memory_project_backward_weights(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
                                                    int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,

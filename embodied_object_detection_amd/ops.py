@@ -533,6 +533,34 @@ class MemoryProjectorBackward:
         return dict(dW=dW, db=db, gE=gE, gE2=gE2, dEc=dec)
 
 
+class AdamW:
+    """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
+    tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).
+    `groups`: what `solver.build_param_groups` returns (each with its own `lr`); state = exp_avg / exp_avg_sq per tensor."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, clip_value: float = 0.0):
+        self.groups = groups
+        self.betas, self.eps, self.weight_decay, self.clip_value = betas, eps, weight_decay, clip_value
+        self.state = [(torch.zeros_like(g["param"]), torch.zeros_like(g["param"])) for g in groups]
+        self.steps = [0] * len(groups)
+        self.lib = _lib.load()
+
+    def step(self, grads: Sequence[Optional[torch.Tensor]], lr_factor: float = 1.0):
+        """`grads[i]`: gradient of group i's tensor (None: no gradient this iteration, the tensor is skipped as torch does)."""
+        for i, (g, grad) in enumerate(zip(self.groups, grads)):
+            if grad is None:
+                continue
+            p = g["param"]
+            _need_cuda(p, grad)
+            assert p.dtype == torch.float32 and grad.dtype == torch.float32 and p.is_contiguous() and grad.is_contiguous()
+            assert grad.shape == p.shape
+            self.steps[i] += 1
+            m, v = self.state[i]
+            check(self.lib.eod_adamw_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), g["lr"] * lr_factor,
+                                          self.betas[0], self.betas[1], self.eps, g.get("weight_decay", self.weight_decay), self.steps[i],
+                                          self.clip_value, _stream()), "eod_adamw_step")
+
+
 class MemoryWriter:
     """a16-a19 write path (custom_rcnn.py:681-760) on device."""
 

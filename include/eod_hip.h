@@ -322,6 +322,14 @@ int eod_memory_project_backward_weights(const float* g3, const float* g4, const 
 int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* dec5, int H, int W, uint16_t* ge3_f16, uint16_t* ge4_f16,
                              uint16_t* ge5_f16, float* ge2, eod_stream_t stream);
 
+/* Optimizer step of the reference's training configuration for ONE parameter tensor (second slice): detectron2's
+ * per-parameter gradient clipping by value (SOLVER.CLIP_GRADIENTS.ENABLED, CLIP_TYPE "value"; clip_value <= 0: off) followed by
+ * torch.optim.AdamW's single-tensor update (SOLVER.OPTIMIZER ADAMW, Base-C2_L_R5021k_640b64_4x_recurrent.yaml:68-74; built by
+ * Detic/detic/custom_solver.py:19-79 with lr = BASE_LR x CUSTOM_MULTIPLIER for the `map_merge` parameters).  step >= 1 is the
+ * 1-based update count of this tensor; exp_avg / exp_avg_sq are its state, zero before the first step.  In place, elementwise. */
+int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, double clip_value, eod_stream_t stream);
+
 /* a16-a19 write path (custom_rcnn.py:681-760,875-936) */
 typedef struct EodMemWriteDesc {
   const float* featn;       /* [R,512] normalised x50 proposal features */

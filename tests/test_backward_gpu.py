@@ -61,3 +61,61 @@ def test_memory_read_backward_matches_autograd(H, W, n_cells):
     got_g2 = out["gE2"].cpu()
     assert bool(((got_g2 - ref_g2).abs() <= 2.0 ** -10 * float(ref_g2.abs().max())).all())
     assert float((got_g2 == ref_g2).float().mean()) > 0.99
+
+
+def test_memory_read_training_steps_match_torch(tmp_path):
+    """Second slice: three TRAINING steps of the memory-specific parameters (`map_merge_projection{1,2,3}`: weights and biases) as the
+    reference's configuration runs them -- forward of the memory read + fusion, a loss that is linear in the fused pyramid, backward,
+    gradient clipping by value 1.0, AdamW at BASE_LR x CUSTOM_MULTIPLIER (custom_solver.py:19-79, ..._mp3d_recurrent.yaml:28-38) --
+    entirely on the HIP kernels (gather/pool, project + fuse with re-prepared weights, the backward kernels, `eod_adamw_step`)
+    against torch autograd + `torch.optim.AdamW` on the oracle's forward."""
+    from embodied_object_detection_amd import ops, solver
+    dev = torch.device("cuda:0")
+    H, W, n_cells, weight = 64, 96, 300, 5.0
+    g = torch.Generator().manual_seed(11)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 3).half()
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    W0 = [torch.randn((256, 512, 1, 1), generator=g) * 0.05 for _ in range(3)]
+    b0 = [torch.randn((256,), generator=g) * 0.1 for _ in range(3)]
+    rows = [(H >> (3 + l)) * (W >> (3 + l)) for l in range(3)]
+    base_lr, mult, wd = 1e-3, 10.0, 1e-4           # a larger BASE_LR than the yaml's 1e-5 so that three steps move the weights visibly
+    names = [f"backbone.map_merge_projection{l + 1}.{k}" for l in range(3) for k in ("weight", "bias")]
+    # ---- torch reference
+    Wt = [w.clone().requires_grad_() for w in W0]
+    bt = [b.clone().requires_grad_() for b in b0]
+    topt = torch.optim.AdamW([{"params": [t], "lr": base_lr * mult} for pair in zip(Wt, bt) for t in pair], base_lr, weight_decay=wd)
+    # ---- HIP side: fp32 master parameters on the device
+    Wd = [w.reshape(256, 512).contiguous().to(dev) for w in W0]
+    bd = [b.clone().to(dev) for b in b0]
+    groups = solver.build_param_groups(list(zip(names, [t for pair in zip(Wd, bd) for t in pair])), base_lr, wd, "ADAMW", 1.0, mult, ["map_merge"])
+    assert [gr["lr"] for gr in groups] == [base_lr * mult] * 6
+    opt = ops.AdamW(groups, weight_decay=wd, clip_value=1.0)
+    pooled_d = ops.memory_gather_pool(mem16.to(dev), proj.int().to(dev), H, W, torch_order=True)
+    pooled_ref = [p.to(torch.float32) for p in M.memory_read_pooled(mem16, proj)]
+    for it in range(3):
+        res = [torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) for l in range(3)]
+        G = [torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) * 0.02 for l in range(3)]      # some |grad| above the clip, most below
+        # torch: forward, loss, backward, clip, step
+        topt.zero_grad()
+        loss = sum(((F.conv2d(pooled_ref[l], Wt[l], bt[l]) * weight + res[l]) * G[l]).sum() for l in range(3))
+        loss.backward()
+        for t in Wt + bt:
+            t.grad.clamp_(-1.0, 1.0)
+        topt.step()
+        # HIP: forward (weights re-prepared from the fp32 masters), backward, optimizer
+        projector = ops.MemoryProjector([w.reshape(256, 512, 1, 1) for w in Wd], bd, dev)
+        feats = torch.cat([res[l][0].permute(1, 2, 0).reshape(-1, 256) for l in range(3)]).contiguous().to(dev)
+        projector(pooled_d, feats, H, W, weight, "sum")
+        loss_hip = float((feats.cpu() * torch.cat([G[l][0].permute(1, 2, 0).reshape(-1, 256) for l in range(3)])).sum())
+        assert abs(loss_hip - float(loss.detach())) <= 1e-4 * max(1.0, abs(float(loss.detach()))), (it, loss_hip, float(loss.detach()))
+        grads_in = [G[l][0].permute(1, 2, 0).reshape(-1, 256).contiguous().to(dev) for l in range(3)]
+        out = ops.MemoryProjectorBackward([w.reshape(256, 512, 1, 1) for w in Wd], dev)(grads_in, pooled_d, H, W, weight)
+        opt.step([t for l in range(3) for t in (out["dW"][l], out["db"][l])])
+        for l in range(3):
+            for got, ref, what in ((Wd[l], Wt[l].detach().reshape(256, 512), "weight"), (bd[l], bt[l].detach(), "bias")):
+                err = float((got.cpu() - ref).abs().max())
+                # AdamW's first steps move every element by ~lr whatever the gradient's size: a gradient that differs in the last
+                # bits moves m / sqrt(v) by ~1e-6 relative, far below this bound; an element whose clipped / unclipped state differed
+                # would show up as ~lr
+                assert err <= 2e-6, (it, l, what, err)
+        assert float((Wd[0].cpu() - W0[0].reshape(256, 512)).abs().max()) > 0.5 * base_lr * mult * (it + 1) * 0.5

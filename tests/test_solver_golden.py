@@ -1,0 +1,87 @@
+"""Optimizer set-up (second slice) against fixtures produced by the reference's own `build_custom_optimizer`
+(`Detic/detic/custom_solver.py:19-79`; tests/golden/gen_golden_solver.py): parameter groups on the CPU, the update rule of the
+recurrent configuration (clip by value + AdamW) through `eod_adamw_step` on the GPU."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "solver.json")) as fh:
+        return json.load(fh)
+
+
+class _P:
+    def __init__(self, requires_grad=True):
+        self.requires_grad = requires_grad
+
+
+def _named(golden):
+    ps = [_P(n not in golden["frozen"]) for n in golden["names"]]
+    return list(zip(golden["names"], ps)) + [("alias.of.conv1.weight", ps[0])]
+
+
+@pytest.mark.parametrize("case", ["recurrent_yaml", "sgd_backbone_multiplier", "adamw_full_model_clip"])
+def test_param_groups_match_the_reference(golden, case):
+    from embodied_object_detection_amd import solver
+    c = golden["cases"][case]
+    s = c["solver"]
+    groups = solver.build_param_groups(_named(golden), s["BASE_LR"], s["WEIGHT_DECAY"], s["OPTIMIZER"], s["BACKBONE_MULTIPLIER"],
+                                       s["CUSTOM_MULTIPLIER"], s["CUSTOM_MULTIPLIER_NAME"])
+    assert [g["name"] for g in groups] == [g["name"] for g in c["groups"]]           # frozen and aliased tensors skipped, order kept
+    for g, r in zip(groups, c["groups"]):
+        assert g["lr"] == r["lr"], (g["name"], g["lr"], r["lr"])                      # the same float products in the same order
+        # ADAMW groups carry no weight_decay of their own: the optimizer's default (the reference passes SOLVER.WEIGHT_DECAY) applies
+        assert g.get("weight_decay", c["defaults"]["weight_decay"]) == r["weight_decay"]
+        assert ("weight_decay" in g) == (s["OPTIMIZER"] != "ADAMW")
+
+
+def test_unknown_optimizer_is_refused():
+    from embodied_object_detection_amd import solver
+    with pytest.raises(NotImplementedError):
+        solver.build_param_groups([("a", _P())], 0.1, 0.0, "LAMB")
+
+
+def test_warmup_cosine_schedule():
+    """detectron2 WarmupCosineLR with the recurrent yaml's numbers (MAX_ITER 10000, WARMUP_ITERS 1000, WARMUP_FACTOR 0.001)."""
+    from embodied_object_detection_amd.solver import warmup_cosine_lr_factor as f
+    assert f(0, 10000, 1000, 0.001) == pytest.approx(0.001)
+    assert f(500, 10000, 1000, 0.001) == pytest.approx((0.001 * 0.5 + 0.5) * 0.5 * (1 + math.cos(math.pi * 0.05)))
+    assert f(1000, 10000, 1000, 0.001) == pytest.approx(0.5 * (1 + math.cos(math.pi * 0.1)))
+    assert f(10000, 10000, 1000, 0.001) == pytest.approx(0.0, abs=1e-12)
+    assert f(3, 10, 5, 0.2, "constant") == pytest.approx(0.2 * 0.5 * (1 + math.cos(math.pi * 0.3)))
+
+
+@pytest.mark.gpu
+def test_adamw_step_matches_the_reference_optimizer(golden):
+    """Two steps of the reference's optimizer (AdamW, per-parameter clip by value 1.0, map_merge at 10 x the base rate) on seeded
+    gradients with |g| up to ~9: `eod_adamw_step` reproduces the parameters to fp32 rounding."""
+    from embodied_object_detection_amd import ops, solver
+    dev = torch.device("cuda:0")
+    c = golden["cases"]["recurrent_yaml"]
+    s = c["solver"]
+    shapes = [tuple(x) for x in golden["shapes"]]
+    params = [torch.tensor(v, dtype=torch.float32).reshape(sh).to(dev) for v, sh in zip(c["params_before"], shapes)]
+    named = list(zip(golden["names"], params))
+    groups = solver.build_param_groups(named, s["BASE_LR"], s["WEIGHT_DECAY"], s["OPTIMIZER"], s["BACKBONE_MULTIPLIER"], s["CUSTOM_MULTIPLIER"],
+                                       s["CUSTOM_MULTIPLIER_NAME"], frozen=golden["frozen"])
+    opt = ops.AdamW(groups, betas=tuple(c["defaults"]["betas"]), eps=c["defaults"]["eps"], weight_decay=c["defaults"]["weight_decay"],
+                    clip_value=s["CLIP_GRADIENTS"]["CLIP_VALUE"])
+    by_name = dict(zip(golden["names"], zip(c["grads"], shapes)))
+    grads = [torch.tensor(by_name[g["name"]][0], dtype=torch.float32).reshape(by_name[g["name"]][1]).to(dev) for g in groups]
+    opt.step(grads)
+    opt.step(grads)
+    torch.cuda.synchronize()
+    for n, p, want, sh in zip(golden["names"], params, c["params_after_two_steps"], shapes):
+        ref = torch.tensor(want, dtype=torch.float32).reshape(sh)
+        if n in golden["frozen"]:
+            assert torch.equal(p.cpu(), ref)
+        else:
+            assert float((p.cpu() - ref).abs().max()) <= 2e-7 * max(1.0, float(ref.abs().max())), n
+            assert not torch.equal(p.cpu(), torch.tensor(c["params_before"][golden["names"].index(n)]).reshape(sh))

@@ -177,6 +177,34 @@ def test_lockstep_longterm_two_calls_equal_single_runs(synthetic_sd):
         torch.cuda.empty_cache()
 
 
+def test_lockstep_schedules_are_bitwise_identical(synthetic_sd):
+    """The step's streams (look-ahead trunk one step ahead, detection pass trailing under the next step) are a scheduling change only:
+    with and without them, over two calls of 6 steps, every output and the final state of every scene are bitwise the same."""
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+    B, T = 3, 12
+    seqs = [SyntheticSequence(80 + b, H=128, W=160, n_frames=T, map_w=24, map_h=24, cell=0.5) for b in range(B)]
+    eps = [[s.frame(i) for i in range(T)] for s in seqs]
+    ref = None
+    for look, trail in ((False, False), (True, True), (True, False), (False, True)):
+        ls = LockstepScenes(_cfg(), B, synthetic_sd)
+        ls.trunk_lookahead, ls.trail_detection_pass = look, trail
+        outs = [a + b for a, b in zip(ls([e[:6] for e in eps]), ls([e[6:] for e in eps]))]
+        got = [[(o["instances"].pred_boxes.tensor.clone(), o["instances"].scores.clone(), o["instances"].pred_classes.clone(),
+                 o["instances"].pred_masks.clone()) for o in ob] for ob in outs]
+        state = (ls.implicit_memory.clone(), ls.observations.clone())
+        if ref is None:
+            ref = (got, state)
+        else:
+            for a, b in zip(ref[0], got):
+                assert len(a) == len(b) == T
+                for x, y in zip(a, b):
+                    assert all(torch.equal(u, v) for u, v in zip(x, y)), (look, trail)
+            assert torch.equal(ref[1][0], state[0]) and torch.equal(ref[1][1], state[1]), (look, trail)
+        del ls
+        torch.cuda.empty_cache()
+
+
 def test_lockstep_planned_for_the_batch_agrees_within_tolerance(synthetic_sd):
     """`plan_like_single = False`: the layers are planned for the rows the batched launches really have (other split-K / tile
     choices: the same fp32 arithmetic in another summation order).  Per frame -- the state before every frame set to the single-scene

@@ -25,6 +25,35 @@ __device__ __forceinline__ bool row_has_work(const int* count, int R_cap, int ro
 // strided global loads behind a dependent chain (80 / 37 us -> a few us on the cascade's critical path).  Same arithmetic and
 // summation order as before: per lane 8 products in channel order, then the wave butterfly.
 constexpr int ZS_MAX_C = 24;
+
+// zs [512][C1] (global, 16-byte aligned) -> zt [C1][512] (LDS) by the 256 threads of a workgroup.  All of a thread's 16-byte loads are
+// issued before the first LDS write: the first version's loop (load one float, write it, 42 times) was a chain of 42 dependent L2
+// round trips -- 20 of the kernel's 29 us.
+__device__ __forceinline__ void stage_class_matrix(const float* __restrict__ zs, float* zt, int n, int C1) {
+  constexpr int PER = ZS_MAX_C * 512 / 4 / 256;           // 12 float4 per thread cover the largest class matrix
+  const int n4 = n >> 2;                                   // n = 512 C1 is a multiple of 4
+  f32x4 buf[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i4 = threadIdx.x + 256 * j;
+    if (i4 < n4) buf[j] = *reinterpret_cast<const f32x4*>(zs + 4 * i4);
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i4 = threadIdx.x + 256 * j;
+    if (i4 < n4) {
+      int k = (4 * i4) / C1, c = 4 * i4 - k * C1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        zt[c * 512 + k] = buf[j][e];
+        if (++c == C1) {
+          c = 0;
+          ++k;
+        }
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
                                                            const int* __restrict__ count, int R_cap, int D, int C1, float temp,
@@ -34,10 +63,7 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
   // R_cap % 4 == 0 whenever the rows are a batch of lists: a workgroup's four rows belong to one list
   if (!row_has_work(count, R_cap, (int)(blockIdx.x * 4))) return;    // whole workgroup beyond its list's count
-  for (int i = threadIdx.x; i < D * C1; i += blockDim.x) {
-    const int k = i / C1, c = i - k * C1;    // coalesced read of zs[k][c]
-    zt[c * 512 + k] = zs[i];
-  }
+  stage_class_matrix(zs, zt, D * C1, C1);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,6 +89,12 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
       *reinterpret_cast<f32x4*>(featn_out + (size_t)row * D + lane * 8 + 4) = f32x4{x[4], x[5], x[6], x[7]};
     }
     const float ps = (final_inv_stages > 0.f && prop_scores) ? prop_scores[row] : 0.f;
+    // lane c owns class c: the row's accumulated probabilities are read with ONE coalesced load before the loop and written with one
+    // store after it (lane 0 reading and writing them one by one inside the loop was a chain of C1 dependent global round trips: 29 us
+    // for a launch of 5 MFLOP).  The butterfly leaves the identical sum in every lane, so lane c's logit is lane 0's.
+    float* o = prob_acc + (size_t)row * C1 + lane;
+    const float old = (accumulate && lane < C1) ? *o : 0.f;
+    float logit = 0.f;
     for (int c = 0; c < C1; ++c) {
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
@@ -70,26 +102,24 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
       s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
       s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
       s = wave_reduce_sum(s);
-      if (lane == 0) {
-        const float p = eod_sigmoid_precise(s);
-        float* o = prob_acc + (size_t)row * C1 + c;
-        float v = accumulate ? (*o + p) : p;
-        if (final_inv_stages > 0.f) v = sqrtf(v * final_inv_stages * ps);       // cascade score fusion (detic_roi_heads.py:164-173)
-        *o = v;
-      }
+      if (lane == c) logit = s;
+    }
+    if (lane < C1) {
+      const float p = eod_sigmoid_precise(logit);
+      float v = accumulate ? (old + p) : p;
+      if (final_inv_stages > 0.f) v = sqrtf(v * final_inv_stages * ps);         // cascade score fusion (detic_roi_heads.py:164-173)
+      *o = v;
     }
   }
   if (!zs_mem) return;
   // memory-side CLIP re-score (custom_rcnn.py:838-861) with the meta-architecture's own class matrix: same staging, same
   // per-lane channel order and butterfly as eod_memory_scores on feat_norm_out
   __syncthreads();
-  for (int i = threadIdx.x; i < D * C1; i += blockDim.x) {
-    const int k = i / C1, c = i - k * C1;
-    zt[c * 512 + k] = zs_mem[i];
-  }
+  stage_class_matrix(zs_mem, zt, D * C1, C1);
   __syncthreads();
   if (!active) return;
   const float p = prop_scores[row];
+  float logit = 0.f;
   for (int c = 0; c < C1; ++c) {
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8);
     const f32x4 w1 = *reinterpret_cast<const f32x4*>(zt + c * 512 + lane * 8 + 4);
@@ -97,8 +127,9 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
     s += x[0] * w0.x; s += x[1] * w0.y; s += x[2] * w0.z; s += x[3] * w0.w;
     s += x[4] * w1.x; s += x[5] * w1.y; s += x[6] * w1.z; s += x[7] * w1.w;
     s = wave_reduce_sum(s);
-    if (lane == 0) mem_scores[(size_t)row * C1 + c] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(s) * p) : 0.0f;
+    if (lane == c) logit = s;
   }
+  if (lane < C1) mem_scores[(size_t)row * C1 + lane] = (p < 1.0f) ? sqrtf(eod_sigmoid_precise(logit) * p) : 0.0f;
 }
 
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, float* __restrict__ out,
@@ -283,7 +314,8 @@ extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_a
   // with a capacity error that ops.zs_classify words out
   if (D != 512 || C1 < 2 || R_cap <= 0) return EOD_ERR_BAD_DIMS;
   if (C1 > ZS_MAX_C) return EOD_ERR_CAPACITY;
-  if (!eod_aligned16(feat) || (feat_norm_out && !eod_aligned16(feat_norm_out))) return EOD_ERR_ALIGN;
+  if (!eod_aligned16(feat) || (feat_norm_out && !eod_aligned16(feat_norm_out)) || !eod_aligned16(zs) || (zs_mem && !eod_aligned16(zs_mem)))
+    return EOD_ERR_ALIGN;
   if (batch > 1 && (batch > EOD_MAX_BATCH || R_cap % 4 != 0)) return EOD_ERR_BAD_DIMS;
   const int nb = batch > 1 ? batch : 1;
   hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap * nb + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,

@@ -148,6 +148,7 @@ struct NmsSmem {
   int kl[NMS_KEPT_MAX];         // their labels
   int kidx[NMS_KEPT_MAX];       // their position in the sorted list
   float cb[64 * 4];             // the chunk's boxes
+  float cs[64];                 // the chunk's scores (the tie rule of the last chunks reads them one by one)
   int cl[64];
   u64 diag[64];                 // bit c of word i: chunk box c (c > i) is suppressed by chunk box i
   u64 supp;                     // bit i: chunk box i is suppressed by a box kept in an earlier chunk
@@ -170,7 +171,7 @@ __device__ __forceinline__ bool iou_over(float x1, float y1, float x2, float y2,
 // Greedy NMS over the first n entries of a score-sorted list (boxes / scores / labels / rows in global memory, written by this
 // workgroup before the call) + gather of the kept entries.  keep_ties: keep every kept box whose score equals the score of kept
 // box #max_keep (centernet.py:733-741, ">= kth"), else truncate at max_keep.  Block = 1024 threads.
-__device__ void block_greedy_nms(const float* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ labels,
+__device__ bool block_greedy_nms(const float* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ labels,
                                  const int* __restrict__ rows, int n, float thr, int max_keep, int keep_ties, const ScanOut& o,
                                  NmsSmem* S) {
   const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
@@ -181,20 +182,34 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
   }
   __syncthreads();
   const int nchunk = (n + 63) >> 6;
+  // wave 0 holds the NEXT chunk's boxes / scores / labels in registers: its global loads are issued a whole chunk ahead instead of
+  // at the top of the chunk that needs them (one L2 round trip per chunk off the serial path)
+  float nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f, nsc = 0.f;
+  int nlb = 0;
+  auto fetch = [&](int c) {
+    const int j = c * 64 + tid;
+    if (tid < 64 && j < n) {
+      nb0 = boxes[j * 4 + 0]; nb1 = boxes[j * 4 + 1]; nb2 = boxes[j * 4 + 2]; nb3 = boxes[j * 4 + 3];
+      nsc = scores[j];
+      nlb = labels ? labels[j] : 0;
+    }
+  };
+  fetch(0);
   for (int c = 0; c < nchunk; ++c) {
     const int lim = min(64, n - c * 64);
     if (tid < 64) {
       if (tid < lim) {
-        const int j = c * 64 + tid;
-        S->cb[tid * 4 + 0] = boxes[j * 4 + 0];
-        S->cb[tid * 4 + 1] = boxes[j * 4 + 1];
-        S->cb[tid * 4 + 2] = boxes[j * 4 + 2];
-        S->cb[tid * 4 + 3] = boxes[j * 4 + 3];
-        S->cl[tid] = labels ? labels[j] : 0;
+        S->cb[tid * 4 + 0] = nb0;
+        S->cb[tid * 4 + 1] = nb1;
+        S->cb[tid * 4 + 2] = nb2;
+        S->cb[tid * 4 + 3] = nb3;
+        S->cl[tid] = nlb;
+        S->cs[tid] = nsc;
       }
       S->diag[tid] = 0;
       if (tid == 0) S->supp = 0;
     }
+    if (c + 1 < nchunk) fetch(c + 1);
     __syncthreads();
     const int total0 = S->total;
     const int nk = total0 < NMS_KEPT_MAX ? total0 : NMS_KEPT_MAX;
@@ -240,8 +255,9 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
       u64 cur = S->supp;
       u64 kept = 0;
       for (int i = 0; i < lim; ++i) {
-        const unsigned lo = __shfl((unsigned)(diag & 0xFFFFFFFFull), i, 64);
-        const unsigned hi = __shfl((unsigned)(diag >> 32), i, 64);
+        // i is wave-uniform: v_readlane into scalar registers instead of an LDS-crossbar shuffle per step
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag & 0xFFFFFFFFull), i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), i);
         if (!((cur >> i) & 1ull)) {
           kept |= (1ull << i);
           cur |= ((u64)hi << 32) | lo;
@@ -270,7 +286,7 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
           bool take = false;
           if (total < max_keep) {
             take = true;
-          } else if (keep_ties && scores[idx] >= kth) {
+          } else if (keep_ties && S->cs[i] >= kth) {
             take = true;
           } else {
             // boxes after this one have lower-or-equal score; with ties they may still be equal only if scores[idx] >= kth,
@@ -286,7 +302,7 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
               S->kidx[total] = idx;
             }
             ++total;
-            if (total == max_keep) kth = scores[idx];
+            if (total == max_keep) kth = S->cs[i];
           }
         }
         S->total = total;
@@ -300,9 +316,14 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
       }
     }
     __syncthreads();
+#ifdef EOD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) eod_stamps[6] = (unsigned long long)(c + 1);      // chunks walked
+#endif
     if (S->stop) break;
   }
   __syncthreads();
+  EOD_STAMP(5);
+  const bool stopped = S->stop != 0;      // the walk ended on its own rule, not because the list ran out
   int total = S->total;
   if (total > o.cap) total = o.cap;
   if (total > NMS_KEPT_MAX) total = NMS_KEPT_MAX;
@@ -382,6 +403,33 @@ __device__ void block_greedy_nms(const float* __restrict__ boxes, const float* _
     }
     if (tid == 0 && o.uniq_count) *o.uniq_count = all < o.uniq_cap ? all : o.uniq_cap;
   }
+  __syncthreads();
+  return stopped;
+}
+
+__device__ __forceinline__ int score_bin(unsigned bits) {
+  int bin = (int)(bits >> 14) - (int)(0x3C000000u >> 14);
+  return bin < 0 ? 0 : (bin > 4095 ? 4095 : bin);
+}
+
+// sort the n keys of `buf` (n <= 1024 E) descending and leave them there in sorted order
+template <int E>
+__device__ __forceinline__ void sort_in_place(u64* buf, int n) {
+  u64 v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = threadIdx.x * E + e;
+    v[e] = i < n ? buf[i] : 0ull;
+  }
+  __syncthreads();                     // every thread holds its keys: the buffer becomes the sort's exchange buffer
+  block_sort_desc_reg<E>(v, buf);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int q = threadIdx.x * E + e;
+    if (q < n) buf[q] = v[e];
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -560,15 +608,10 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
     v[e] = i < total_slots ? p.cand_keys[i] : 0ull;
   }
   EOD_STAMP(1);
-  block_sort_desc_reg<E>(v, xch);
-  EOD_STAMP(2);
   int n = 0;
   for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int r = threadIdx.x * E + e;
-    if (r >= n) continue;
-    const u64 k = v[e];
+  // Decode the boxes of the sorted keys held in `keys` (registers of a full sort, or the sorted LDS list of the best candidates)
+  auto decode = [&](int r, u64 k) {
     const int g = (int)key_index(k);
     int level = 0;
     while (level + 1 < p.levels && g >= p.level_off[level + 1]) ++level;
@@ -594,6 +637,80 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
     sorted_boxes[r * 4 + 2] = x2;
     sorted_boxes[r * 4 + 3] = y2;
     sorted_scores[r] = key_score(k);
+  };
+  // Fast path: NMS 0.9 keeps nearly every candidate, so the post-NMS cut (256 + ties) is reached inside the best few hundred of
+  // the up to 4096.  A histogram of the score bits (as in cn_level_topk_kernel) picks the lowest bin whose suffix holds >= 1024
+  // candidates; only those are sorted (1024-2048 keys instead of 4096: 35 us of this kernel were the sort) and walked.  If the
+  // walk runs out of them before it stops by its own rule, the full list is sorted and walked instead (same results either way).
+  __shared__ int hist[4096];
+  __shared__ int wsum[16];
+  __shared__ int sh_cut, sh_n2;
+  if (n > 1024) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+    if (tid == 0) {
+      sh_cut = 0;
+      sh_n2 = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (v[e]) atomicAdd(&hist[score_bin((unsigned)(v[e] >> 32))], 1);
+    __syncthreads();
+    {
+      const int want = 1024;
+      const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int inc = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(inc, off, 64);
+        if (lane + off < 64) inc += t;
+      }
+      if (lane == 0) wsum[wave] = inc;
+      __syncthreads();
+      int after = 0;
+      for (int w = wave + 1; w < 16; ++w) after += wsum[w];
+      const int above = after + inc - mine;
+      const int s3 = above + h3, s2 = s3 + h2, s1 = s2 + h1, s0 = s1 + h0;
+      if (above < want && s3 >= want) sh_cut = 4 * tid + 3;
+      else if (s3 < want && s2 >= want) sh_cut = 4 * tid + 2;
+      else if (s2 < want && s1 >= want) sh_cut = 4 * tid + 1;
+      else if (s1 < want && s0 >= want) sh_cut = 4 * tid;
+    }
+    __syncthreads();
+    const int cut = sh_cut;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool in = v[e] != 0 && score_bin((unsigned)(v[e] >> 32)) >= cut;
+      const u64 bal = __ballot(in);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&sh_n2, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (in) xch[base + __popcll(bal & ((1ull << lane) - 1ull))] = v[e];
+    }
+    __syncthreads();
+    const int n2 = sh_n2;                            // 1024 <= n2 <= n
+    if (n2 < n && n2 <= 4096) {
+      if (n2 <= 1024) sort_in_place<1>(xch, n2);
+      else if (n2 <= 2048) sort_in_place<2>(xch, n2);
+      else sort_in_place<(E >= 4 ? 4 : E)>(xch, n2);
+      EOD_STAMP(2);
+      for (int r = tid; r < n2; r += 1024) decode(r, xch[r]);
+      __syncthreads();
+      EOD_STAMP(3);
+      const bool stopped = block_greedy_nms(sorted_boxes, sorted_scores, nullptr, nullptr, n2, nms_thresh, post_topk, 1, o,
+                                            reinterpret_cast<NmsSmem*>(xch));
+      EOD_STAMP(4);
+      if (stopped) return;                           // workgroup-uniform
+    }
+  }
+  block_sort_desc_reg<E>(v, xch);
+  EOD_STAMP(2);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = threadIdx.x * E + e;
+    if (r < n) decode(r, v[e]);
   }
   __syncthreads();          // the sorted list (global) and the end of the sort's use of xch
   EOD_STAMP(3);
@@ -614,31 +731,6 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
 #define DET_MAX_R 512
 #define DET_WORDS (DET_MAX_R / 64)
 #define DET_MAX_C 24
-
-__device__ __forceinline__ int score_bin(unsigned bits) {
-  int bin = (int)(bits >> 14) - (int)(0x3C000000u >> 14);
-  return bin < 0 ? 0 : (bin > 4095 ? 4095 : bin);
-}
-
-// sort the n keys of `buf` (n <= 1024 E) descending and leave them there in sorted order
-template <int E>
-__device__ __forceinline__ void sort_in_place(u64* buf, int n) {
-  u64 v[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int i = threadIdx.x * E + e;
-    v[e] = i < n ? buf[i] : 0ull;
-  }
-  __syncthreads();                     // every thread holds its keys: the buffer becomes the sort's exchange buffer
-  block_sort_desc_reg<E>(v, buf);
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int q = threadIdx.x * E + e;
-    if (q < n) buf[q] = v[e];
-  }
-  __syncthreads();
-}
 
 __global__ __launch_bounds__(1024) void det_select_kernel(const float* boxes, const float* scores, const int* count, int R_cap, int C1,
                                                            float img_w, float img_h, float thr, float nms_thresh, int topk, ScanOut o) {

@@ -40,8 +40,8 @@ for i in range(12):
     rows.append(np.array(list(buf), dtype=np.int64))
 a = np.stack(rows[4:])                 # steady state
 us = lambda i, j: np.median((a[:, j] - a[:, i]) / 100.0)
-print("cn_merge_nms_kernel: load keys %.1f | sort %.1f | decode %.1f | nms + outputs %.1f | total %.1f us"
-      % (us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4)))
+print("cn_merge_nms_kernel: load keys %.1f | prefilter + sort %.1f | decode %.1f | nms walk %.1f (%d chunks) | outputs %.1f | total %.1f us"
+      % (us(0, 1), us(1, 2), us(2, 3), us(3, 5), int(np.median(a[:, 6])), us(5, 4), us(0, 4)))
 for name, sb in (("det_select_kernel (memory selection, topk 100)", 8), ("det_select_kernel (detections, topk 300)", 24)):
     print("%s: rows+scores %.1f | IoU matrix %.1f | histogram+cut %.1f | batch 0 compaction+sort %.1f | batch 0 walk %.1f | "
           "outputs %.1f | total %.1f us   (candidates %d, kept %d)"

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libeod_hip.so")
+LIB_PATH = os.environ.get("EOD_LIB_PATH") or os.path.join(HERE, "libeod_hip.so")     # EOD_LIB_PATH: A/B of two builds (tools/)
 
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p

@@ -30,7 +30,16 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
     const float* src = p.partial + (size_t)m * p.Cout + n;
     if (VEC == 4) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4*>(src + z * slab);
+      // four slabs at a time: independent loads in flight together, added in slab order
+      for (int zb = 0; zb < p.splitk; zb += 4) {
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (zb + j < p.splitk) t[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(zb + j) * slab);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (zb + j < p.splitk) v += t[j];
+      }
       epilogue_store(p, v.x, (int)m, (int)n);
       epilogue_store(p, v.y, (int)m, (int)n + 1);
       epilogue_store(p, v.z, (int)m, (int)n + 2);

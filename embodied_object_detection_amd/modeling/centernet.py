@@ -46,7 +46,7 @@ class CenterNet:
         self.out_conv = ops.Conv(w, b, pad=1, device=device, name="agn_hm+bbox_pred")
         self.scales = [float(sd[f"{h}.scales.{l}.scale"].item()) for l in range(5)]
         self._plans = {}
-        self.fuse_gn_stats = False
+        self.fuse_gn_stats = True
 
     def _plan(self, shapes: List[Tuple[int, int]], off: List[int]):
         key = tuple(shapes)
@@ -69,9 +69,10 @@ class CenterNet:
         a, b, head, dec, gn_ws = self._plan(shapes, off)
         src = feats
         for (conv, gamma, beta) in self.tower:
-            # `fuse_gn_stats`: the conv's slab reduce also writes GroupNorm's partial sums (one launch less per tower layer).  Measured
-            # at 640x640 (rocprofv3, stand-alone): the fused reduce 44 us against 12 (reduce) + 11 (statistics) -- its one-channel-
-            # per-thread walk over 32 rows x 4 slabs runs at one workgroup per CU; off by default.
+            # `fuse_gn_stats`: the conv's slab reduce also writes GroupNorm's partial sums (one launch less per tower layer on the
+            # frame's critical chain: +0.6 % frames/s in a same-call A/B, tools/knob_ab.py).  The reduce keeps its coalesced float4
+            # mapping and accumulates the sums per thread in double (a first version that walked one channel per thread took 44 us
+            # against 12 + 11 for the separate launches and was off).
             self._per_level(conv, src, a, shapes, off, 256, gn_stats=gn_ws if self.fuse_gn_stats else None)
             ops.groupnorm_relu(a, gamma, beta, off, 256, gn_ws, out=b, partial_ready=conv.gn_fused)   # stream order: `a` is free again
             src = b

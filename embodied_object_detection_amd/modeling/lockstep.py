@@ -321,8 +321,8 @@ class LockstepScenes:
         lv = (d["offB"], d["shapesB"])
         src = feats
         for (conv, gamma, beta) in pg.tower:
-            conv(src, 1, 0, 0, out=d["tower_a"], levels=lv, plan_rows=self._pr(P))
-            ops.groupnorm_relu(d["tower_a"], gamma, beta, d["offB"], 256, d["gn_ws"], out=d["tower_b"])
+            conv(src, 1, 0, 0, out=d["tower_a"], levels=lv, plan_rows=self._pr(P), gn_stats=d["gn_ws"] if pg.fuse_gn_stats else None)
+            ops.groupnorm_relu(d["tower_a"], gamma, beta, d["offB"], 256, d["gn_ws"], out=d["tower_b"], partial_ready=conv.gn_fused)
             src = d["tower_b"]
         pg.out_conv(src, 1, 0, 0, out=d["head"], levels=lv, plan_rows=self._pr(P))
         prop_boxes, prop_scores, prop_count = d["dec"](d["head"])

@@ -408,7 +408,8 @@ def test_groupnorm_relu_multilevel(dev):
 
 def test_groupnorm_statistics_ride_on_the_conv_slab_reduce(dev):
     """A pyramid-mode conv whose plan reduces split-K slabs (the CenterNet tower at 640x640: 536 tiles) also writes GroupNorm's
-    partial sums: conv output and GroupNorm output are bitwise those of the separate statistics launch."""
+    partial sums: the conv output is bitwise that of the plain reduce; the statistics are the same double sums in another
+    association (per-thread row subsets combined through LDS), so the GroupNorm output agrees to the last float bits."""
     from embodied_object_detection_amd import ops
     hw = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
     Cc = 256
@@ -429,7 +430,9 @@ def test_groupnorm_statistics_ride_on_the_conv_slab_reduce(dev):
     conv(x, 1, 0, 0, out=yb, levels=(off, hw), gn_stats=stats_b)
     assert conv.gn_fused, "this layer's plan has a slab reduce"
     gb = ops.groupnorm_relu(yb, gamma, beta, off, Cc, stats_b, partial_ready=True)
-    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    assert torch.equal(ya, yb)
+    close(gb, ga, rtol=2e-6, atol=2e-6)
+    assert float((ga == gb).float().mean()) > 0.999
     # a small pyramid has no slab reduce to ride on: the statistics launch stays
     hs = [(8, 12), (4, 6)]
     offs = [0, 96, 120]

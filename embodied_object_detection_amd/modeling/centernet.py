@@ -47,6 +47,9 @@ class CenterNet:
         self.scales = [float(sd[f"{h}.scales.{l}.scale"].item()) for l in range(5)]
         self._plans = {}
         self.fuse_gn_stats = True
+        # EodConvDesc.force_tile of the 5-channel output conv: 6 / 7 = K over 4 / 8 waves, no slab reduce launch -- measured in the frame
+        # (tools/knob_ab.py, same call): 288.6 frames/s with the planner's slabs + reduce, 287.7 / 287.2 with 6 / 7: stays 0
+        self.out_conv_tile = 0
 
     def _plan(self, shapes: List[Tuple[int, int]], off: List[int]):
         key = tuple(shapes)
@@ -60,9 +63,9 @@ class CenterNet:
             self._plans[key] = (a, b, head, dec, ops.groupnorm_workspace(off, self.device))
         return self._plans[key]
 
-    def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int, gn_stats=None):
+    def _per_level(self, conv, src: torch.Tensor, dst: torch.Tensor, shapes, off, cout: int, gn_stats=None, force_tile: int = 0):
         # one launch over the whole pyramid (weights are shared across levels, centernet_head.py:144-160)
-        conv(src, 1, 0, 0, out=dst, levels=(off, shapes), gn_stats=gn_stats)
+        conv(src, 1, 0, 0, out=dst, levels=(off, shapes), gn_stats=gn_stats, force_tile=force_tile)
 
     def forward(self, feats: torch.Tensor, shapes, off):
         """feats [P_total,256] -> (boxes [cap,4], scores [cap], count [1]) device buffers, sorted by score."""
@@ -76,5 +79,5 @@ class CenterNet:
             self._per_level(conv, src, a, shapes, off, 256, gn_stats=gn_ws if self.fuse_gn_stats else None)
             ops.groupnorm_relu(a, gamma, beta, off, 256, gn_ws, out=b, partial_ready=conv.gn_fused)   # stream order: `a` is free again
             src = b
-        self._per_level(self.out_conv, src, head, shapes, off, 5)
+        self._per_level(self.out_conv, src, head, shapes, off, 5, force_tile=self.out_conv_tile)
         return dec(head)

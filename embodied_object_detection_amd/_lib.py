@@ -43,6 +43,11 @@ class EodConvDesc(C.Structure):
     ]
 
 
+class EodBoxRefine(C.Structure):
+    _fields_ = [("deltas", C.c_void_p), ("ld", C.c_int32), ("wx", C.c_float), ("wy", C.c_float), ("ww", C.c_float), ("wh", C.c_float),
+                ("clip", C.c_int32), ("img_w", C.c_float), ("img_h", C.c_float), ("boxes_out", C.c_void_p)]
+
+
 class EodProposalDesc(C.Structure):
     _fields_ = [
         ("head_out", C.c_void_p), ("head_stride", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 6),
@@ -95,7 +100,7 @@ SIGNATURES = {
     "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "eod_roi_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),

@@ -31,6 +31,29 @@ __device__ __forceinline__ float eod_sigmoid(float x) { return 1.0f / (1.0f + __
 // exact-ish sigmoid used where scores are compared against thresholds / sorted: expf, IEEE divide
 __device__ __forceinline__ float eod_sigmoid_precise(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Box2BoxTransform.apply_deltas on one box (detic_roi_heads.py:121-122,314), shared by apply_deltas_kernel and by roi_align_kernel's
+// refine-on-load form: the same instructions in both, hence the same bits.
+__device__ __forceinline__ void eod_apply_deltas_one(const float* __restrict__ d, float x1, float y1, float x2, float y2, float wx, float wy,
+                                                     float ww, float wh, int clip, float img_w, float img_h, float& ox1, float& oy1,
+                                                     float& ox2, float& oy2) {
+  const float w = x2 - x1, h = y2 - y1;
+  const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
+  const float clampv = 4.135166556742356f;  // log(1000/16)
+  const float dx = d[0] / wx;
+  const float dy = d[1] / wy;
+  const float dw = fminf(d[2] / ww, clampv);
+  const float dh = fminf(d[3] / wh, clampv);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  ox1 = pcx - 0.5f * pw; oy1 = pcy - 0.5f * ph; ox2 = pcx + 0.5f * pw; oy2 = pcy + 0.5f * ph;
+  if (clip) {
+    ox1 = fminf(fmaxf(ox1, 0.f), img_w);
+    oy1 = fminf(fmaxf(oy1, 0.f), img_h);
+    ox2 = fminf(fmaxf(ox2, 0.f), img_w);
+    oy2 = fminf(fmaxf(oy2, 0.f), img_h);
+  }
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -139,22 +139,8 @@ __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int ld, co
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R_cap * batch || !row_has_work(count, R_cap, r)) return;
   const float x1 = boxes[r * 4 + 0], y1 = boxes[r * 4 + 1], x2 = boxes[r * 4 + 2], y2 = boxes[r * 4 + 3];
-  const float w = x2 - x1, h = y2 - y1;
-  const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
-  const float clampv = 4.135166556742356f;  // log(1000/16)
-  const float dx = deltas[(size_t)r * ld + 0] / wx;
-  const float dy = deltas[(size_t)r * ld + 1] / wy;
-  const float dw = fminf(deltas[(size_t)r * ld + 2] / ww, clampv);
-  const float dh = fminf(deltas[(size_t)r * ld + 3] / wh, clampv);
-  const float pcx = dx * w + cx, pcy = dy * h + cy;
-  const float pw = expf(dw) * w, ph = expf(dh) * h;
-  float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
-  if (clip) {
-    ox1 = fminf(fmaxf(ox1, 0.f), img_w);
-    oy1 = fminf(fmaxf(oy1, 0.f), img_h);
-    ox2 = fminf(fmaxf(ox2, 0.f), img_w);
-    oy2 = fminf(fmaxf(oy2, 0.f), img_h);
-  }
+  float ox1, oy1, ox2, oy2;
+  eod_apply_deltas_one(deltas + (size_t)r * ld, x1, y1, x2, y2, wx, wy, ww, wh, clip, img_w, img_h, ox1, oy1, ox2, oy2);
   out[r * 4 + 0] = ox1;
   out[r * 4 + 1] = oy1;
   out[r * 4 + 2] = ox2;

@@ -23,6 +23,11 @@ struct RoiArgs {
   int S;
   float* out;
   int batch, boxes_per_image;   // batch > 1: feat[l] holds `batch` images; box j belongs to image j / boxes_per_image
+  // optional refine-on-load (EodBoxRefine): the ROI's box is apply_deltas(boxes[br], deltas[br]); the wave of bin 0 also stores it
+  const float* deltas;
+  int ld, clip;
+  float wx, wy, ww, wh, img_w, img_h;
+  float* boxes_out;
   FastDiv div_bins, div_s;   // wave id -> (roi, bin) -> (ph, pw) without integer division sequences
 };
 
@@ -48,7 +53,16 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
       img = br / p.boxes_per_image;
       if (segmented && p.count && br - img * p.boxes_per_image >= p.count[img]) continue;
     }
-    const float bx1 = p.boxes[br * 4 + 0], by1 = p.boxes[br * 4 + 1], bx2 = p.boxes[br * 4 + 2], by2 = p.boxes[br * 4 + 3];
+    float bx1 = p.boxes[br * 4 + 0], by1 = p.boxes[br * 4 + 1], bx2 = p.boxes[br * 4 + 2], by2 = p.boxes[br * 4 + 3];
+    if (p.deltas) {
+      float ox1, oy1, ox2, oy2;
+      eod_apply_deltas_one(p.deltas + (size_t)br * p.ld, bx1, by1, bx2, by2, p.wx, p.wy, p.ww, p.wh, p.clip, p.img_w, p.img_h, ox1, oy1, ox2,
+                           oy2);
+      bx1 = ox1; by1 = oy1; bx2 = ox2; by2 = oy2;
+      if (b == 0 && lane == 0) {
+        p.boxes_out[br * 4 + 0] = bx1; p.boxes_out[br * 4 + 1] = by1; p.boxes_out[br * 4 + 2] = bx2; p.boxes_out[br * 4 + 3] = by2;
+      }
+    }
     // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [3,5]
     const float area = (bx2 - bx1) * (by2 - by1);
     float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
 
 extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C, const float* boxes,
                              const int32_t* box_rows, const int32_t* count, int R_cap, int out_size, float* out, int batch,
-                             int boxes_per_image, eod_stream_t stream) {
+                             int boxes_per_image, const EodBoxRefine* refine, eod_stream_t stream) {
   if (!p3 || !p4 || !p5 || !boxes || !out) return EOD_ERR_NULL;
   if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
   if ((long)R_cap * out_size * out_size >= (1L << 30)) return EOD_ERR_BAD_DIMS;
@@ -140,6 +154,11 @@ extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, 
   a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
   a.C = C; a.boxes = boxes; a.box_rows = box_rows; a.count = count; a.R_cap = R_cap; a.S = out_size; a.out = out;
   a.batch = batch > 1 ? batch : 1; a.boxes_per_image = boxes_per_image;
+  if (refine) {
+    if (!refine->deltas || !refine->boxes_out || refine->ld < 4 || box_rows) return EOD_ERR_BAD_DIMS;      // list form: boxes are final
+    a.deltas = refine->deltas; a.ld = refine->ld; a.clip = refine->clip; a.boxes_out = refine->boxes_out;
+    a.wx = refine->wx; a.wy = refine->wy; a.ww = refine->ww; a.wh = refine->wh; a.img_w = refine->img_w; a.img_h = refine->img_h;
+  }
   a.div_bins = eod_make_fastdiv((unsigned)(out_size * out_size));
   a.div_s = eod_make_fastdiv((unsigned)out_size);
   const long waves = (long)R_cap * out_size * out_size;

@@ -338,8 +338,16 @@ class LockstepScenes:
         update_mem = use_mem or m.always_update_memory
         boxes = prop_boxes
         seg = dict(m_count=prop_count, m_unit=1, m_segments=B, plan_rows=self._pr(R))
+        pending = None
         for s_i, st in enumerate(rh.stages):
-            ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, prop_count, B * R, 7, out=self.pool7, batch=B, boxes_per_image=R)
+            if pending is None:
+                ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, prop_count, B * R, 7, out=self.pool7, batch=B,
+                              boxes_per_image=R)
+            else:       # the previous stage's deltas are applied by the ROIAlign launch itself (roi_heads.fold_deltas)
+                ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, prop_count, B * R, 7, out=self.pool7, batch=B,
+                              boxes_per_image=R, refine=(self.deltas, 4, pending, True, float(W), float(H), self.boxes[s_i]))
+                boxes = self.boxes[s_i]
+                pending = None
             st["fc1"](self.pool7, B * R, 1, 1, relu=True, out=self.h1, **seg)
             st["fc2"](self.h1, B * R, 1, 1, relu=True, out=self.h2, **seg)
             feat = self.feat0 if s_i == 0 else self.feat
@@ -351,9 +359,12 @@ class LockstepScenes:
                             mem_scores_out=self.mem_scores if rescore else None,
                             final_inv_stages=1.0 / rh.num_stages if last else 0.0, batch=B)
             st["bb2"](self.hb, B * R, 1, 1, out=self.deltas, **seg)
-            ops.apply_deltas(self.deltas, 4, boxes, self.boxes[s_i + 1], prop_count, R, rh.cascade_weights[s_i], not last, float(W),
-                             float(H), batch=B)
-            boxes = self.boxes[s_i + 1]
+            if rh.fold_deltas and not last:
+                pending = rh.cascade_weights[s_i]
+            else:
+                ops.apply_deltas(self.deltas, 4, boxes, self.boxes[s_i + 1], prop_count, R, rh.cascade_weights[s_i], not last, float(W),
+                                 float(H), batch=B)
+                boxes = self.boxes[s_i + 1]
         # memory selection first: the step's critical chain waits for it (custom_rcnn.py:825-875)
         msel = self.mem_selector
         if update_mem:

@@ -99,6 +99,10 @@ class DeticCascadeROIHeads:
         # the two-launch form (used by the tests as the cross-check)
         self.fuse_mask_tail = True
         self.merge_cls_bb0 = True     # False: the two linear layers as two launches (tests: bitwise the same results)
+        # True: the next stage's ROIAlign applies the deltas on load (EodBoxRefine: one launch less per stage, bitwise the same
+        # results).  Measured in the frame (tools/knob_ab.py, same call): 287.1 frames/s against 288.6 with apply_deltas as its own
+        # 5 us launch -- every one of the ROIAlign's 12 544 waves redoes the box arithmetic behind a dependent load: off.
+        self.fold_deltas = False
         # three detection-list sets: the detection mask pass of frame t may still read set t % 3 while the cascades of the next
         # frames write the others (meta_arch.py, pipeline_detection_pass / RESULT_SETS)
         # LDS reserve of the DETECTION mask pass's launches (the pass that trails under the frame's / the next frame's latency-bound
@@ -120,8 +124,17 @@ class DeticCascadeROIHeads:
         H, W = image_hw
         R = self.R
         boxes = prop_boxes
+        pending = None      # `fold_deltas`: regression weights of the deltas that the next ROIAlign applies to `boxes` on load
         for k, st in enumerate(self.stages):
-            ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, R, 7, out=self.pool7)
+            if pending is None:
+                ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, R, 7, out=self.pool7)
+            else:
+                # next-stage proposals = apply_deltas(boxes, deltas) clipped to the image (detic_roi_heads.py:314): computed by the
+                # ROIAlign launch itself (EodBoxRefine) and stored to boxes[k] -- one launch less per stage on the frame's chain
+                ops.roi_align(views[0], views[1], views[2], h3, w3, 256, boxes, count, R, 7, out=self.pool7,
+                              refine=(self.deltas, 4, pending, True, float(W), float(H), self.boxes[k]))
+                boxes = self.boxes[k]
+                pending = None
             st["fc1"](self.pool7, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h1)
             st["fc2"](self.h1, R, 1, 1, relu=True, m_count=count, m_unit=1, out=self.h2)
             feat = self.feat0 if k == 0 else self.feat
@@ -143,8 +156,11 @@ class DeticCascadeROIHeads:
             st["bb2"](self.hb, R, 1, 1, m_count=count, m_unit=1, out=self.deltas)
             # next-stage proposals are clipped to the image (detic_roi_heads.py:314); the final boxes are clipped by
             # fast_rcnn_inference itself
-            ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
-            boxes = self.boxes[k + 1]
+            if self.fold_deltas and not last:
+                pending = self.cascade_weights[k]
+            else:
+                ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
+                boxes = self.boxes[k + 1]
         if after_cascade is not None:
             after_cascade()
         self.last_selector = self.selectors[sel]

@@ -275,12 +275,20 @@ def mask_predictor_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: float, rows: 
 
 def roi_align(p3, p4, p5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count: Optional[torch.Tensor], R_cap: int, S: int,
               out: Optional[torch.Tensor] = None, box_rows: Optional[torch.Tensor] = None, batch: int = 1,
-              boxes_per_image: int = 0) -> torch.Tensor:
-    """`batch` > 1: p3..p5 are [batch,h,w,C]; box j is pooled from image j // boxes_per_image (include/eod_hip.h)."""
+              boxes_per_image: int = 0, refine=None) -> torch.Tensor:
+    """`batch` > 1: p3..p5 are [batch,h,w,C]; box j is pooled from image j // boxes_per_image (include/eod_hip.h).
+    `refine = (deltas, ld, weights, clip, img_w, img_h, boxes_out)`: the ROI boxes are apply_deltas(boxes, deltas), also written to
+    `boxes_out` (EodBoxRefine: the cascade's next-stage proposals without their own launch)."""
     if out is None:
         out = torch.empty((R_cap, S, S, Cc), dtype=torch.float32, device=p3.device)
+    ref = None
+    if refine is not None:
+        deltas, ld, (wx, wy, ww, wh), clip, img_w, img_h, boxes_out = refine
+        _need_cuda(deltas, boxes_out)
+        ref = _lib.EodBoxRefine(deltas.data_ptr(), ld, wx, wy, ww, wh, int(clip), img_w, img_h, boxes_out.data_ptr())
     check(_lib.load().eod_roi_align(p3.data_ptr(), p4.data_ptr(), p5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(box_rows),
-                                    _ptr(count), R_cap, S, out.data_ptr(), batch, boxes_per_image, _stream()), "eod_roi_align")
+                                    _ptr(count), R_cap, S, out.data_ptr(), batch, boxes_per_image, None if ref is None else C.byref(ref),
+                                    _stream()), "eod_roi_align")
     return out
 
 

@@ -163,10 +163,21 @@ int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float
  * batch > 1: p3..p5 hold `batch` images ([batch,h,w,C]), boxes holds batch x boxes_per_image boxes and box j is pooled from image
  * j / boxes_per_image.  Without box_rows: R_cap = batch x boxes_per_image ROIs, one list per image, count[batch].  With box_rows:
  * ONE compact list of box indices over all images (eod_concat_lists), count[1]. */
+/* refine (optional, NULL = off; not with box_rows): ROI r pools the box apply_deltas(boxes[r], deltas[r]) -- the cascade's next-stage
+ * proposals (Box2BoxTransform.apply_deltas + clip, detic_roi_heads.py:121-122,314) without a launch of their own -- and the refined
+ * boxes are also written to boxes_out [R,4] (bitwise what eod_apply_deltas writes). */
+typedef struct EodBoxRefine {
+  const float* deltas; /* [R, ld] */
+  int32_t ld;
+  float wx, wy, ww, wh;
+  int32_t clip;
+  float img_w, img_h;
+  float* boxes_out;    /* [R,4] */
+} EodBoxRefine;
 int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C,
                   const float* boxes /*[R,4]*/, const int32_t* box_rows /* optional gather: ROI r pools boxes[box_rows[r]] */,
                   const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/, int batch, int boxes_per_image,
-                  eod_stream_t stream);
+                  const EodBoxRefine* refine, eod_stream_t stream);
 
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {

@@ -285,6 +285,26 @@ def test_lazy_proposal_masks_give_identical_results(setup):
         assert torch.equal(a.pred_masks, b.pred_masks)
 
 
+def test_cascade_deltas_applied_by_the_next_roi_align_give_identical_results(setup):
+    """`roi_heads.fold_deltas`: the next-stage proposals (apply_deltas + clip, detic_roi_heads.py:314) computed by the next stage's
+    ROIAlign launch instead of a launch of their own: boxes, scores, masks and memory state are bitwise the same."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    outs = []
+    for fold in (False, True):
+        model = build_model(_cfg(), sd)
+        model.roi_heads.fold_deltas = fold
+        res = [model([[f]])[0]["instances"] for f in frames[:3]]
+        outs.append((res, model.implicit_memory.cpu().clone(), model.observations.cpu().clone(),
+                     [b.clone() for b in model.roi_heads.boxes]))
+    (ra, ma, oa, ba), (rb, mb, ob, bb) = outs
+    assert torch.equal(oa, ob) and torch.equal(ma, mb)
+    assert all(torch.equal(x, y) for x, y in zip(ba[1:], bb[1:])), "the refined boxes of every stage are stored as before"
+    for a, b in zip(ra, rb):
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+        assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_masks, b.pred_masks)
+
+
 def test_detection_mask_groups_give_identical_results(setup):
     """Detections of one proposal share one class-agnostic box, hence one mask: running the mask head once per distinct box must
     not change anything (boxes, scores, classes, pasted masks, memory state: bitwise), and it must really save ROIs."""

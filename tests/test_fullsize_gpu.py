@@ -177,6 +177,30 @@ def test_lockstep_longterm_two_calls_equal_single_runs(synthetic_sd):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("over", [{}, {"MODEL.MEMORY_TYPE": "image_only"}, {"MODEL.MAP_FEAT_FUSION": "mem_only"}])
+def test_lockstep_of_one_and_other_memory_modes_equal_single_runs(synthetic_sd, over):
+    """B = 1 (the batch convention's degenerate case) and the other MEMORY_TYPE / fusion modes through LockstepScenes: bitwise the
+    single-scene model's outputs and state (the write-back runs for every MEMORY_TYPE, custom_rcnn.py:515)."""
+    from embodied_object_detection_amd import build_model
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
+    B = 1 if not over else 2
+    seqs = [SyntheticSequence(30 + b, H=128, W=160, n_frames=3, map_w=24, map_h=24, cell=0.5) for b in range(B)]
+    eps = [[s.frame(i) for i in range(3)] for s in seqs]
+    ls = LockstepScenes(_cfg(**over), B, synthetic_sd)
+    outs = ls(eps)
+    for b in range(B):
+        single = build_model(_cfg(**over), synthetic_sd)
+        ref = single([eps[b]])
+        for t in range(3):
+            a, r = outs[b][t]["instances"], ref[t]["instances"]
+            assert torch.equal(a.pred_boxes.tensor, r.pred_boxes.tensor) and torch.equal(a.scores, r.scores), (b, t)
+            assert torch.equal(a.pred_classes, r.pred_classes) and torch.equal(a.pred_masks, r.pred_masks), (b, t)
+        assert torch.equal(ls.scenes[b].implicit_memory, single.implicit_memory) and torch.equal(ls.scenes[b].observations, single.observations)
+        del single
+        torch.cuda.empty_cache()
+
+
 def test_lockstep_schedules_are_bitwise_identical(synthetic_sd):
     """The step's streams (look-ahead trunk one step ahead, detection pass trailing under the next step) are a scheduling change only:
     with and without them, over two calls of 6 steps, every output and the final state of every scene are bitwise the same."""

@@ -155,7 +155,136 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, 
   }
 }
 
+// Third slice: backward of a stride-1 'same' convolution layer (FPN output convs timm.py:118-136, CenterNet tower
+// centernet_head.py:141-161, mask head convs: KH x KW taps, NHWC).  Weight gradient in the layout of the packed forward weights:
+//   dW[co][(ky, kx, ci)] = sum over positions (n, oy, ox) of G[pos][co] * X[n][oy + ky - pad][ox + kx - pad][ci]      (0 outside the image)
+//   db[co] = sum over positions of G[pos][co]
+// Same scheme as proj_backward_weights_kernel: no LDS staging, the MFMA operand layout of v_mfma_f32_32x32x2_f32 reads 32 consecutive
+// channels of one position per half wave (coalesced as the NHWC rows lie in memory); a workgroup owns one 32 (co) x 32 (ci) tile of
+// one tap, its four waves take a quarter of the positions each and are added in wave order (deterministic).  The gradient with
+// respect to the input is a convolution of G with the 180-degree rotated, in/out-transposed weights: eod_conv2d (ops.ConvBackward).
+struct ConvBwdArgs {
+  const float* x;   // [N,H,W,Cin]
+  const float* g;   // [N,H,W,Cout]
+  float* dw;        // [Cout][KH*KW*Cin]
+  float* db;        // [Cout] or null
+  int N, H, W, Cin, Cout, KH, KW, pad;
+  FastDiv div_w, div_h;
+};
+
+__global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs a) {
+  const int ci_tiles = a.Cin >> 5;
+  const int tile = blockIdx.x;                       // (co tile, ci tile)
+  const int co0 = (tile / ci_tiles) * 32, ci0 = (tile % ci_tiles) * 32;
+  const int tap = blockIdx.y;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int P = a.N * a.H * a.W;
+  const int steps = (P + 7) / 8;
+  const int spw = (steps + 3) / 4;
+  const int s_begin = wave * spw;
+  int s_end = s_begin + spw;
+  if (s_end > steps) s_end = steps;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = s * 8 + 2 * t + kh;            // instruction t contracts positions 8 s + 2 t and 8 s + 2 t + 1
+      float gv = 0.f, xv = 0.f;
+      if (pos < P) {
+        gv = a.g[(size_t)pos * a.Cout + co0 + col];
+        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * H + oy
+        const int ox = pos - row * a.W;
+        const int n = (int)fdiv((unsigned)row, a.div_h);
+        const int oy = row - n * a.H;
+        const int iy = oy + ky - a.pad, ix = ox + kx - a.pad;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          xv = a.x[((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + col];
+      }
+      av[t] = gv;
+      bv[t] = xv;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      bsum += av[t];
+    }
+  }
+  __shared__ float red[3 * 16 * 64];
+  __shared__ float bred[4 * 64];
+  bred[wave * 64 + lane] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
+  // C/D layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int Ktot = a.KH * a.KW * a.Cin;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    a.dw[(size_t)co * Ktot + (size_t)tap * a.Cin + ci0 + col] = acc[r];
+  }
+  if (a.db && tap == 0 && (tile % ci_tiles) == 0 && lane < 32) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += bred[w * 64 + lane] + bred[w * 64 + 32 + lane];    // even + odd positions, wave order
+    a.db[co0 + lane] = v;
+  }
+}
+
+// dL/d(pre-activation) of a ReLU layer from dL/d(output): g where the output was positive
+__global__ __launch_bounds__(256) void relu_backward_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
+                                                             size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 o;
+    o.x = yv.x > 0.f ? gv.x : 0.f;
+    o.y = yv.y > 0.f ? gv.y : 0.f;
+    o.z = yv.z > 0.f ? gv.z : 0.f;
+    o.w = yv.w > 0.f ? gv.w : 0.f;
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                           float* dw, float* db, eod_stream_t stream) {
+  if (!x || !g || !dw) return EOD_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || (Cout & 31) || KH <= 0 || KW <= 0 || KH * KW > 64 ||
+      2 * pad != KH - 1 || KH != KW)
+    return EOD_ERR_BAD_DIMS;                        // stride 1, 'same': the output grid is the input grid
+  if ((long)N * H * W >= (1L << 28)) return EOD_ERR_BAD_DIMS;
+  ConvBwdArgs a{};
+  a.x = x; a.g = g; a.dw = dw; a.db = db;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.pad = pad;
+  a.div_w = eod_make_fastdiv((unsigned)W);
+  a.div_h = eod_make_fastdiv((unsigned)H);
+  hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_relu_backward(const float* g, const float* y, float* out, size_t n, eod_stream_t stream) {
+  if (!g || !y || !out) return EOD_ERR_NULL;
+  if (n == 0 || (n & 3)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(g) || !eod_aligned16(y) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, y, out, n / 4);
+  return eod_launch_status();
+}
 
 extern "C" int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                               double beta2, double eps, double weight_decay, int step, double clip_value, eod_stream_t stream) {

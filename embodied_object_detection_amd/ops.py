@@ -541,6 +541,51 @@ class MemoryProjectorBackward:
         return dict(dW=dW, db=db, gE=gE, gE2=gE2, dEc=dec)
 
 
+class ConvBackward:
+    """Backward of a stride-1 'same' `Conv` layer with bias and optional ReLU (third slice): the layers downstream
+    of the memory fusion (CenterNet tower, FPN output convs, mask head convs).  `__call__(x, y, g_out)` with the forward's input `x`
+    [N,H,W,Cin], output `y` [N,H,W,Cout] (post-ReLU, only read when `relu`) and dL/dy -> dict(dx, dw [Cout, KH*KW*Cin] in the packed
+    layout of `Conv.w`, db).  dx = `eod_conv2d` of the pre-activation gradient with the 180-degree rotated, in/out-transposed
+    weights; dw / db = `eod_conv2d_backward_weights`."""
+
+    def __init__(self, conv: "Conv"):
+        if conv.stride != 1 or conv.KH != conv.KW or conv.pad * 2 != conv.KH - 1 or conv.out_mode != 0 or conv.tap4:
+            raise ValueError("ConvBackward covers stride-1 'same' convolutions")
+        self.conv = conv
+        self.lib = _lib.load()
+        self._flipped = None
+        self._flipped_of = None
+
+    def _dgrad_conv(self) -> "Conv":
+        # rebuilt when the forward weights have been replaced / updated in place (an optimizer step): keyed by the tensor's version
+        key = (self.conv.w.data_ptr(), self.conv.w._version)
+        if self._flipped is None or self._flipped_of != key:
+            c = self.conv
+            K = c.KH * c.KW * c.Cin
+            w = c.w[:, :K].reshape(c.Cout, c.KH, c.KW, c.Cin)                       # [co, ky, kx, ci]
+            wt = w.flip(1, 2).permute(3, 0, 1, 2).contiguous()                     # [ci, co, ky', kx'] = OIHW of the transposed conv
+            self._flipped = Conv(wt.cpu(), None, stride=1, pad=c.pad, device=c.w.device, name=c.name + "^T")
+            self._flipped_of = key
+        return self._flipped
+
+    def __call__(self, x: torch.Tensor, y: Optional[torch.Tensor], g_out: torch.Tensor, relu: bool = False, need_dx: bool = True):
+        c = self.conv
+        _need_cuda(x, y, g_out)
+        N, H, W, _ = x.shape
+        assert tuple(g_out.shape) == (N, H, W, c.Cout) and x.is_contiguous() and g_out.is_contiguous()
+        g = g_out
+        if relu:
+            g = torch.empty_like(g_out)
+            check(self.lib.eod_relu_backward(g_out.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "eod_relu_backward")
+        K = c.KH * c.KW * c.Cin
+        dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
+        db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
+        check(self.lib.eod_conv2d_backward_weights(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, dw.data_ptr(),
+                                                   db.data_ptr(), _stream()), "eod_conv2d_backward_weights")
+        dx = self._dgrad_conv()(g, N, H, W) if need_dx else None
+        return dict(dx=dx, dw=dw, db=db)
+
+
 class AdamW:
     """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
     tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).

@@ -119,3 +119,38 @@ def test_memory_read_training_steps_match_torch(tmp_path):
                 # would show up as ~lr
                 assert err <= 2e-6, (it, l, what, err)
         assert float((Wd[0].cpu() - W0[0].reshape(256, 512)).abs().max()) > 0.5 * base_lr * mult * (it + 1) * 0.5
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,relu", [(1, 20, 28, 256, 256, 3, True), (2, 14, 14, 256, 256, 3, True), (1, 10, 12, 64, 96, 1, False),
+                                                   (1, 9, 7, 32, 64, 5, True)])
+def test_conv_layer_backward_matches_autograd(N, H, W, Cin, Cout, k, relu):
+    """Third slice: dX, dW, db of a stride-1 'same' conv + bias (+ ReLU) layer -- the tower / FPN output / mask head layers downstream of
+    the memory fusion -- against torch autograd on the CPU in fp32."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * (0.5 / (Cin * k * k) ** 0.5)).requires_grad_()
+    b = (torch.randn((Cout,), generator=g) * 0.1).requires_grad_()
+    x = torch.randn((N, Cin, H, W), generator=g).requires_grad_()
+    go = torch.randn((N, Cout, H, W), generator=g)
+    y = F.conv2d(x, w, b, padding=k // 2)
+    if relu:
+        y = F.relu(y)
+    (y * go).sum().backward()
+    conv = ops.Conv(w.detach(), b.detach(), pad=k // 2, device=dev)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    yd = conv(xd, N, H, W, relu=relu)
+    out = ops.ConvBackward(conv)(xd, yd, go.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)                      # [co, (ky, kx, ci)]
+    for name, got, ref in (("dW", out["dw"].cpu(), ref_dw), ("db", out["db"].cpu(), b.grad),
+                           ("dX", out["dx"].cpu(), x.grad.permute(0, 2, 3, 1))):
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 3e-5 * scale, f"{name}: {err:.3e} at scale {scale:.3e}"
+    # the weight gradient feeds the optimizer in the packed layout of the forward weights
+    K = Cin * k * k
+    opt = ops.AdamW([{"name": "w", "param": conv.w[:, :K].contiguous(), "lr": 1e-3}], weight_decay=0.0)
+    before = opt.groups[0]["param"].clone()
+    opt.step([out["dw"]])
+    moved = (opt.groups[0]["param"] - before).abs()
+    assert float(moved.max()) <= 1.01e-3 and float(moved.mean()) > 0.9e-3      # AdamW's first step: ~lr per element

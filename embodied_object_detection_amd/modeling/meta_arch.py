@@ -507,7 +507,7 @@ class CustomRCNNRecurrent:
                 if update_mem:
                     self._mem_scores_frame = self._frame_no          # written by stage 0 of the cascade below
                 det = self.roi_heads.forward_box(views, shapes, prop_boxes, prop_scores, prop_count, (H, W), sel=k,
-                                                 stage0_event=self._ev_s0 if lazy else None,
+                                                 stage0_event=self._ev_s0 if (lazy and self.early_memory_selection) else None,
                                                  mem_rescore=(self.zs_weight, self.mem_scores) if update_mem else None,
                                                  after_cascade=_select_memory if sel_first else None)
                 det_boxes, det_scores, det_classes, det_rows, det_count = det

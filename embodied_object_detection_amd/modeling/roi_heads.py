@@ -103,6 +103,11 @@ class DeticCascadeROIHeads:
         # results).  Measured in the frame (tools/knob_ab.py, same call): 287.1 frames/s against 288.6 with apply_deltas as its own
         # 5 us launch -- every one of the ROIAlign's 12 544 waves redoes the box arithmetic behind a dependent load: off.
         self.fold_deltas = False
+        # experiment: the cascade's 21 launches as a captured hipGraph, replayed (see forward_box).  Measured in the frame
+        # (tools/knob_ab.py, same call): 286.0 frames/s against 286.1 with stream launches -- the launch boundaries on the GPU are
+        # drain + dispatch beside the other streams' kernels, which a graph does not remove, and the host is not the limit: off.
+        self.graph_cascade = False
+        self._graphs = {}
         # three detection-list sets: the detection mask pass of frame t may still read set t % 3 while the cascades of the next
         # frames write the others (meta_arch.py, pipeline_detection_pass / RESULT_SETS)
         # LDS reserve of the DETECTION mask pass's launches (the pass that trails under the frame's / the next frame's latency-bound
@@ -120,6 +125,31 @@ class DeticCascadeROIHeads:
         stage 0's classifier launch also writes the memory update's CLIP re-score of the proposals (custom_rcnn.py:838-861).
         `after_cascade` (optional callable): enqueued between the cascade and the detection selection (the frame's critical chain
         waits for the memory selection, not for the detections)."""
+        h3, w3 = shapes[0]
+        H, W = image_hw
+        R = self.R
+        if self.graph_cascade and stage0_event is None:
+            # Experiment (`graph_cascade`): the cascade's 21 launches as ONE hipGraph per (pyramid set, inputs) combination, captured on
+            # first use and replayed.  Every buffer of the segment is static; the events around it stay outside the graph.
+            key = (views[0].data_ptr(), prop_boxes.data_ptr(), prop_scores.data_ptr(), count.data_ptr(), mem_rescore is not None, H, W)
+            g = self._graphs.get(key)
+            if g is None:
+                self._cascade(views, shapes, prop_boxes, prop_scores, count, image_hw, None, mem_rescore)     # eager once: workspaces exist
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._cascade(views, shapes, prop_boxes, prop_scores, count, image_hw, None, mem_rescore)
+                self._graphs[key] = g
+            g.replay()
+            boxes = self.boxes[self.num_stages]
+        else:
+            boxes = self._cascade(views, shapes, prop_boxes, prop_scores, count, image_hw, stage0_event, mem_rescore)
+        if after_cascade is not None:
+            after_cascade()
+        self.last_selector = self.selectors[sel]
+        return self.selectors[sel](boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
+
+    def _cascade(self, views, shapes, prop_boxes, prop_scores, count, image_hw, stage0_event, mem_rescore):
+        """The three cascade stages (detic_roi_heads.py:88-175) -> the final boxes buffer; scores land in `self.prob`."""
         h3, w3 = shapes[0]
         H, W = image_hw
         R = self.R
@@ -161,10 +191,7 @@ class DeticCascadeROIHeads:
             else:
                 ops.apply_deltas(self.deltas, 4, boxes, self.boxes[k + 1], count, R, self.cascade_weights[k], not last, float(W), float(H))
                 boxes = self.boxes[k + 1]
-        if after_cascade is not None:
-            after_cascade()
-        self.last_selector = self.selectors[sel]
-        return self.selectors[sel](boxes, self.prob, count, float(W), float(H), self.score_thresh, self.nms_thresh)
+        return boxes
 
     # ---- mask head ----------------------------------------------------------------------------------
     def forward_mask(self, views, shapes, boxes: torch.Tensor, count: torch.Tensor, cap: int, out: torch.Tensor,

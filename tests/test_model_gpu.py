@@ -305,6 +305,26 @@ def test_cascade_deltas_applied_by_the_next_roi_align_give_identical_results(set
         assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_masks, b.pred_masks)
 
 
+def test_cascade_replayed_from_a_hipgraph_gives_identical_results(setup):
+    """`roi_heads.graph_cascade` (experiment): the cascade's 21 launches captured as a hipGraph per buffer combination and replayed --
+    same kernels, same buffers, bitwise the same results (frames 0-3 capture, the second pass over the episode replays)."""
+    from embodied_object_detection_amd import build_model
+    frames, sd = setup["frames"], setup["sd"]
+    outs = []
+    for graph in (False, True):
+        model = build_model(_cfg(), sd)
+        model.roi_heads.graph_cascade = graph
+        res = [o["instances"] for o in model([frames[:4]])] + [o["instances"] for o in model([frames[:4]])]
+        outs.append((res, model.implicit_memory.cpu().clone(), model.observations.cpu().clone()))
+        if graph:
+            assert len(model.roi_heads._graphs) >= 1
+    (ra, ma, oa), (rb, mb, ob) = outs
+    assert torch.equal(oa, ob) and torch.equal(ma, mb)
+    for a, b in zip(ra, rb):
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+        assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_masks, b.pred_masks)
+
+
 def test_detection_mask_groups_give_identical_results(setup):
     """Detections of one proposal share one class-agnostic box, hence one mask: running the mask head once per distinct box must
     not change anything (boxes, scores, classes, pasted masks, memory state: bitwise), and it must really save ROIs."""

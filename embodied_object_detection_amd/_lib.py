@@ -97,6 +97,9 @@ SIGNATURES = {
     "eod_groupnorm_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "eod_groupnorm_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                      C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "eod_groupnorm_backward_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int32), C.c_int, C.c_int]),
+    "eod_groupnorm_relu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                              C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_mask_predictor_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "eod_roi_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

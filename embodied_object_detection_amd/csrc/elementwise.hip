@@ -287,6 +287,173 @@ extern "C" int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, i
   return eod_launch_status();
 }
 
+// ---- GroupNorm(32) + ReLU backward (training slices): the tower layers downstream of the memory fusion --------
+// y = relu(xhat * gamma + beta), xhat = (x - mean) * rstd per (level image, group).  With dyr = dy * [y > 0], n = rows_l * C / groups:
+//   dbeta_c = sum dyr, dgamma_c = sum dyr * xhat (over all rows of all levels: the layer's parameters are shared by the levels)
+//   dx = rstd * (dyr * gamma_c - s1_g / n - xhat * s2_g / n),  s1_g = sum_{c in g} gamma_c a_c, s2_g = sum_{c in g} gamma_c b_c,
+//   a_c / b_c = the level's sums of dyr / dyr * xhat for channel c.
+// Three launches: per 32-row chunk the per-channel sums (double, row order); one workgroup adds them per level in chunk order and
+// over the levels in level order (deterministic); the apply pass.  mean / rstd are recomputed from the forward's own partial sums.
+struct GnStats {
+  float mean, rstd;
+};
+__device__ __forceinline__ void gn_level_stats(const double* __restrict__ fwd_partial, int first_chunk, int nch, int rows, int C,
+                                               int groups, float eps, float (*s_stats)[2]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = wave; g < groups; g += 4) {
+    double s = 0.0, q = 0.0;
+    for (int c = lane; c < nch; c += 64) {
+      s += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
+      q += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    if (lane == 0) {
+      const double n = (double)rows * (C / groups);
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stats[g][0] = (float)mean;
+      s_stats[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void gn_chunk_of_block(const LevelOff& lo, int& level, int& first_chunk) {
+  level = 0;
+  first_chunk = 0;
+  for (;;) {
+    const int rows_l = lo.off[level + 1] - lo.off[level];
+    const int nch_l = (rows_l + GN_ROWS - 1) / GN_ROWS;
+    if ((int)blockIdx.x < first_chunk + nch_l || level + 1 >= lo.levels) break;
+    first_chunk += nch_l;
+    ++level;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, LevelOff lo, int C, int groups, float eps,
+                                                              const double* __restrict__ fwd_partial, double* __restrict__ part) {
+  __shared__ float s_stats[64][2];
+  int level, first_chunk;
+  gn_chunk_of_block(lo, level, first_chunk);
+  const int rows = lo.off[level + 1] - lo.off[level];
+  gn_level_stats(fwd_partial, first_chunk, (rows + GN_ROWS - 1) / GN_ROWS, rows, C, groups, eps, s_stats);
+  const int r0 = lo.off[level] + ((int)blockIdx.x - first_chunk) * GN_ROWS;
+  const int r1 = min(r0 + GN_ROWS, lo.off[level + 1]);
+  const int cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mean = s_stats[c / cpg][0], rstd = s_stats[c / cpg][1];
+    double a = 0.0, b = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const size_t o = (size_t)r * C + c;
+      const float dyr = y[o] > 0.f ? dy[o] : 0.f;
+      const float xh = (x[o] - mean) * rstd;
+      a += (double)dyr;
+      b += (double)dyr * (double)xh;
+    }
+    part[((size_t)blockIdx.x * C + c) * 2 + 0] = a;
+    part[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+// one workgroup: per level the chunk sums in chunk order -> level totals [levels][C][2]; over the levels -> dgamma, dbeta
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const double* __restrict__ part, LevelOff lo, int C, double* __restrict__ level_tot,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double ga = 0.0, gb = 0.0;
+    int chunk = 0;
+    for (int l = 0; l < lo.levels; ++l) {
+      const int nch = (lo.off[l + 1] - lo.off[l] + GN_ROWS - 1) / GN_ROWS;
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < nch; ++k, ++chunk) {
+        a += part[((size_t)chunk * C + c) * 2 + 0];
+        b += part[((size_t)chunk * C + c) * 2 + 1];
+      }
+      level_tot[((size_t)l * C + c) * 2 + 0] = a;
+      level_tot[((size_t)l * C + c) * 2 + 1] = b;
+      ga += a;
+      gb += b;
+    }
+    dbeta[c] = (float)ga;
+    dgamma[c] = (float)gb;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, LevelOff lo, int C, int groups, float eps,
+                                                            const double* __restrict__ fwd_partial, const double* __restrict__ level_tot,
+                                                            float* __restrict__ dx) {
+  __shared__ float s_stats[64][2];
+  __shared__ double s_sum[64][2];
+  int level, first_chunk;
+  gn_chunk_of_block(lo, level, first_chunk);
+  const int rows = lo.off[level + 1] - lo.off[level];
+  gn_level_stats(fwd_partial, first_chunk, (rows + GN_ROWS - 1) / GN_ROWS, rows, C, groups, eps, s_stats);
+  const int cpg = C / groups;
+  // s1_g, s2_g of this level: gamma-weighted sums of the level totals over the group's channels, in channel order
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      const int c = g * cpg + j;
+      s1 += (double)gamma[c] * level_tot[((size_t)level * C + c) * 2 + 0];
+      s2 += (double)gamma[c] * level_tot[((size_t)level * C + c) * 2 + 1];
+    }
+    s_sum[g][0] = s1;
+    s_sum[g][1] = s2;
+  }
+  __syncthreads();
+  const int r0 = lo.off[level] + ((int)blockIdx.x - first_chunk) * GN_ROWS;
+  const int r1 = min(r0 + GN_ROWS, lo.off[level + 1]);
+  const double inv_n = 1.0 / ((double)rows * cpg);
+  const int total = (r1 - r0) * C;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int c = i % C;
+    const size_t o = (size_t)(r0 + i / C) * C + c;
+    const int g = c / cpg;
+    const float mean = s_stats[g][0], rstd = s_stats[g][1];
+    const float dyr = y[o] > 0.f ? dy[o] : 0.f;
+    const float xh = (x[o] - mean) * rstd;
+    const float m1 = (float)(s_sum[g][0] * inv_n), m2 = (float)(s_sum[g][1] * inv_n);
+    dx[o] = rstd * (dyr * gamma[c] - m1 - xh * m2);
+  }
+}
+
+extern "C" size_t eod_groupnorm_backward_workspace_bytes(const int32_t* level_off_host, int levels, int C) {
+  if (!level_off_host || levels < 1 || levels > EOD_MAX_LEVELS || C <= 0) return 0;
+  size_t chunks = 0;
+  for (int i = 0; i < levels; ++i) chunks += (size_t)(level_off_host[i + 1] - level_off_host[i] + GN_ROWS - 1) / GN_ROWS;
+  return (chunks + (size_t)levels) * C * 2 * sizeof(double);
+}
+
+extern "C" int eod_groupnorm_relu_backward(const float* x, const float* y, const float* dy, const float* gamma, const int32_t* level_off_host,
+                                           int levels, int C, int groups, float eps, const float* fwd_stats, void* workspace, float* dx,
+                                           float* dgamma, float* dbeta, eod_stream_t stream) {
+  if (!x || !y || !dy || !gamma || !level_off_host || !fwd_stats || !workspace || !dx || !dgamma || !dbeta) return EOD_ERR_NULL;
+  if (levels < 1 || levels > EOD_MAX_LEVELS || groups < 1 || groups > 64 || C % groups != 0) return EOD_ERR_BAD_DIMS;
+  LevelOff lo{};
+  lo.levels = levels;
+  for (int i = 0; i <= levels; ++i) lo.off[i] = level_off_host[i];
+  int chunks = 0;
+  for (int i = 0; i < levels; ++i) {
+    if (lo.off[i + 1] <= lo.off[i]) return EOD_ERR_BAD_DIMS;
+    chunks += (lo.off[i + 1] - lo.off[i] + GN_ROWS - 1) / GN_ROWS;
+  }
+  // the forward's workspace: [2 * levels * groups floats | pad to 8 B | chunks * groups * 2 doubles]
+  const double* fwd_partial = reinterpret_cast<const double*>(reinterpret_cast<const char*>(fwd_stats) +
+                                                              ((size_t)2 * levels * groups * sizeof(float) + 7) / 8 * 8);
+  double* part = static_cast<double*>(workspace);
+  double* level_tot = part + (size_t)chunks * C * 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks), dim3(256), 0, s, x, y, dy, lo, C, groups, eps, fwd_partial, part);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(1), dim3(256), 0, s, part, lo, C, level_tot, dgamma, dbeta);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, s, x, y, dy, gamma, lo, C, groups, eps, fwd_partial, level_tot, dx);
+  return eod_launch_status();
+}
+
 extern "C" size_t eod_groupnorm_workspace_bytes(const int32_t* level_off_host, int levels, int groups) {
   if (!level_off_host || levels < 1 || levels > EOD_MAX_LEVELS) return 0;
   size_t chunks = 0;

@@ -264,6 +264,22 @@ def groupnorm_relu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, lev
     return out
 
 
+def groupnorm_relu_backward(x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, level_off: Sequence[int], Cc: int,
+                            fwd_stats: torch.Tensor, groups: int = 32, eps: float = 1e-5):
+    """Backward of `groupnorm_relu` (its input `x`, output `y`, the `stats` workspace of that call) -> (dx, dgamma, dbeta)."""
+    _need_cuda(x, y, dy, gamma, fwd_stats)
+    lo = (C.c_int32 * len(level_off))(*level_off)
+    lib = _lib.load()
+    ws = torch.empty((lib.eod_groupnorm_backward_workspace_bytes(lo, len(level_off) - 1, Cc) // 8,), dtype=torch.float64, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    check(lib.eod_groupnorm_relu_backward(x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(), lo, len(level_off) - 1, Cc, groups, eps,
+                                          fwd_stats.data_ptr(), ws.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+          "eod_groupnorm_relu_backward")
+    return dx, dgamma, dbeta
+
+
 def mask_predictor_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: float, rows: int, Cc: int, count: Optional[torch.Tensor],
                            unit_rows: int, out: Optional[torch.Tensor] = None, out_units: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:

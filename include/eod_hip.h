@@ -153,6 +153,13 @@ int eod_groupnorm_relu(const float* x, float* y, const float* gamma, const float
 /* byte offset of the per-chunk partial sums inside `stats` (EodConvDesc.gn_partial points there); partial_ready = 1: the producing
  * eod_conv2d wrote them, the statistics launch is skipped */
 size_t eod_groupnorm_partial_offset(int levels, int groups);
+/* Backward of eod_groupnorm_relu (training slices): x / y the forward's input / output, dy = dL/dy, fwd_stats the
+ * forward call's `stats` workspace (its partial sums give mean / rstd); -> dx [P,C], dgamma [C], dbeta [C] (sums over all levels: the
+ * parameters are shared).  workspace >= eod_groupnorm_backward_workspace_bytes(); three launches, deterministic summation order. */
+size_t eod_groupnorm_backward_workspace_bytes(const int32_t* level_off_host, int levels, int C);
+int eod_groupnorm_relu_backward(const float* x, const float* y, const float* dy, const float* gamma, const int32_t* level_off_host,
+                                int levels, int C, int groups, float eps, const float* fwd_stats, void* workspace, float* dx,
+                                float* dgamma, float* dbeta, eod_stream_t stream);
 /* mask predictor 1x1 conv -> 1 channel + sigmoid (d2 mask head predictor + mask_rcnn_inference,
  * custom_rcnn.py:574): x [R*784,C] -> prob [R*784] */
 int eod_mask_predictor_sigmoid(const float* x, const float* w, float bias, float* prob, int rows, int C,

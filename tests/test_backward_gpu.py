@@ -154,3 +154,63 @@ def test_conv_layer_backward_matches_autograd(N, H, W, Cin, Cout, k, relu):
     opt.step([out["dw"]])
     moved = (opt.groups[0]["param"] - before).abs()
     assert float(moved.max()) <= 1.01e-3 and float(moved.mean()) > 0.9e-3      # AdamW's first step: ~lr per element
+
+
+def test_groupnorm_relu_backward_matches_autograd():
+    """GroupNorm(32) + ReLU over a feature pyramid stored as one row list (per level image statistics, parameters shared by the
+    levels: centernet_head.py:76-79): dx, dgamma, dbeta against torch autograd; and a whole tower layer (3x3 conv -> GroupNorm -> ReLU)
+    chained with the conv backward of the third slice."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    shapes = [(12, 16), (6, 8), (3, 4)]
+    off = [0]
+    for h, w in shapes:
+        off.append(off[-1] + h * w)
+    Cc = 256
+    gamma = (torch.rand(Cc, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(Cc, generator=g) * 0.2).requires_grad_()
+    w = (torch.randn((Cc, Cc, 3, 3), generator=g) * 0.02).requires_grad_()
+    b = (torch.randn((Cc,), generator=g) * 0.1).requires_grad_()
+    xs = [torch.randn((1, Cc, h, ww), generator=g).requires_grad_() for h, ww in shapes]
+    gos = [torch.randn((1, Cc, h, ww), generator=g) for h, ww in shapes]
+    # ---- torch: the layer per level (shared parameters), autograd
+    pre, loss = [], 0.0
+    for x, go in zip(xs, gos):
+        c = F.conv2d(x, w, b, padding=1)
+        c.retain_grad()
+        pre.append(c)
+        loss = loss + (F.relu(F.group_norm(c, 32, gamma, beta, eps=1e-5)) * go).sum()
+    loss.backward()
+    rows = lambda ts: torch.cat([t[0].permute(1, 2, 0).reshape(-1, Cc) for t in ts]).contiguous()
+    # ---- HIP forward (pyramid mode), then backward: GroupNorm + ReLU, then the conv
+    conv = ops.Conv(w.detach(), b.detach(), pad=1, device=dev)
+    xd = rows([x.detach() for x in xs]).to(dev)
+    cd = conv(xd, 1, 0, 0, levels=(off, shapes))
+    assert float((cd.cpu() - rows([c.detach() for c in pre])).abs().max()) < 1e-4
+    stats = ops.groupnorm_workspace(off, dev)
+    yd = ops.groupnorm_relu(cd, gamma.detach().to(dev), beta.detach().to(dev), off, Cc, stats)
+    dyd = rows(gos).to(dev)
+    dc, dgamma, dbeta = ops.groupnorm_relu_backward(cd, yd, dyd, gamma.detach().to(dev), off, Cc, stats)
+    ref_dc = rows([c.grad for c in pre])
+    for name, got, ref in (("d(pre-norm)", dc.cpu(), ref_dc), ("dgamma", dgamma.cpu(), gamma.grad), ("dbeta", dbeta.cpu(), beta.grad)):
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 5e-5 * scale, f"{name}: {err:.3e} at scale {scale:.3e}"
+    # the conv of the layer, level by level (the weight gradients of the levels add up: shared weights)
+    bwd = ops.ConvBackward(conv)
+    dw = torch.zeros((Cc, 9 * Cc), device=dev)
+    db = torch.zeros((Cc,), device=dev)
+    dxs = []
+    for l, (h, ww) in enumerate(shapes):
+        xl = xd[off[l]:off[l + 1]].view(1, h, ww, Cc)
+        gl = dc[off[l]:off[l + 1]].view(1, h, ww, Cc).contiguous()
+        o = bwd(xl, None, gl)
+        dw += o["dw"]
+        db += o["db"]
+        dxs.append(o["dx"].reshape(-1, Cc))
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Cc, -1)
+    assert float((dw.cpu() - ref_dw).abs().max()) <= 5e-5 * float(ref_dw.abs().max())
+    assert float((db.cpu() - b.grad).abs().max()) <= 5e-5 * float(b.grad.abs().max())
+    ref_dx = rows([x.grad for x in xs])
+    assert float((torch.cat(dxs).cpu() - ref_dx).abs().max()) <= 5e-5 * float(ref_dx.abs().max())

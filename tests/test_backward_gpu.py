@@ -214,3 +214,88 @@ def test_groupnorm_relu_backward_matches_autograd():
     assert float((db.cpu() - b.grad).abs().max()) <= 5e-5 * float(b.grad.abs().max())
     ref_dx = rows([x.grad for x in xs])
     assert float((torch.cat(dxs).cpu() - ref_dx).abs().max()) <= 5e-5 * float(ref_dx.abs().max())
+
+
+def test_head_loss_gradient_reaches_the_memory_projections():
+    """End to end through the training slices: a loss on the CenterNet head's outputs (agn_hm + bbox_pred logits of P3..P5) is
+    back-propagated on the HIP kernels through the 5-channel output conv, the four tower layers (3x3 conv -> GroupNorm -> ReLU, shared
+    over the levels) and the memory fusion down to the `map_merge_projection` weights and biases -- the parameters the recurrent
+    configuration trains at 10 x the base rate -- and compared with torch autograd on the oracle's forward (timm.py:142-192,
+    centernet_head.py:141-161)."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    H, W, n_cells, weight, Cc = 64, 96, 300, 5.0, 256
+    g = torch.Generator().manual_seed(41)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 3).half()
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    shapes = [(H >> (3 + l), W >> (3 + l)) for l in range(3)]
+    off = [0]
+    for h, w in shapes:
+        off.append(off[-1] + h * w)
+    Wm = [(torch.randn((256, 512, 1, 1), generator=g) * 0.02).requires_grad_() for _ in range(3)]
+    bm = [(torch.randn((256,), generator=g) * 0.1).requires_grad_() for _ in range(3)]
+    Wt = [(torch.randn((Cc, Cc, 3, 3), generator=g) * 0.03).requires_grad_() for _ in range(4)]
+    bt = [(torch.randn((Cc,), generator=g) * 0.1).requires_grad_() for _ in range(4)]
+    gam = [(torch.rand(Cc, generator=g) + 0.5).requires_grad_() for _ in range(4)]
+    bet = [(torch.randn(Cc, generator=g) * 0.2).requires_grad_() for _ in range(4)]
+    Wo = (torch.randn((5, Cc, 3, 3), generator=g) * 0.03).requires_grad_()
+    bo = (torch.randn((5,), generator=g) * 0.1).requires_grad_()
+    res = [torch.randn((1, Cc, h, w), generator=g) for h, w in shapes]
+    Go = [torch.randn((1, 5, h, w), generator=g) for h, w in shapes]
+    # ---- torch autograd on the oracle's forward
+    pooled_ref = [p.to(torch.float32) for p in M.memory_read_pooled(mem16, proj)]
+    loss = 0.0
+    for l in range(3):
+        t = F.conv2d(pooled_ref[l], Wm[l], bm[l]) * weight + res[l]
+        for i in range(4):
+            t = F.relu(F.group_norm(F.conv2d(t, Wt[i], bt[i], padding=1), 32, gam[i], bet[i], eps=1e-5))
+        loss = loss + (F.conv2d(t, Wo, bo, padding=1) * Go[l]).sum()
+    loss.backward()
+    rows = lambda ts: torch.cat([t[0].permute(1, 2, 0).reshape(-1, t.shape[1]) for t in ts]).contiguous()
+    # ---- HIP forward, every layer's input / pre-norm / output kept
+    pooled_d = ops.memory_gather_pool(mem16.to(dev), proj.int().to(dev), H, W, torch_order=True)
+    feats = rows(res).to(dev)
+    ops.MemoryProjector([w.detach() for w in Wm], [b.detach() for b in bm], dev)(pooled_d, feats, H, W, weight, "sum")
+    tower = [ops.Conv(Wt[i].detach(), bt[i].detach(), pad=1, device=dev) for i in range(4)]
+    # the output conv padded to 32 channels (zero rows): the backward kernels work on 32-channel tiles
+    Wo32 = torch.zeros((32, Cc, 3, 3)); Wo32[:5] = Wo.detach()
+    bo32 = torch.zeros((32,)); bo32[:5] = bo.detach()
+    outc = ops.Conv(Wo32, bo32, pad=1, device=dev)
+    keep, x = [], feats
+    for i in range(4):
+        c = tower[i](x, 1, 0, 0, levels=(off, shapes))
+        st = ops.groupnorm_workspace(off, dev)
+        y = ops.groupnorm_relu(c, gam[i].detach().to(dev), bet[i].detach().to(dev), off, Cc, st)
+        keep.append((x, c, st, y))
+        x = y
+    head = outc(x, 1, 0, 0, levels=(off, shapes))
+    # ---- HIP backward
+    def conv_bwd(conv, xin, gout):
+        bwd = ops.ConvBackward(conv)
+        dw = torch.zeros((conv.Cout, conv.KH * conv.KW * conv.Cin), device=dev)
+        db = torch.zeros((conv.Cout,), device=dev)
+        dxs = []
+        for l, (h, w) in enumerate(shapes):
+            o = bwd(xin[off[l]:off[l + 1]].view(1, h, w, conv.Cin), None, gout[off[l]:off[l + 1]].view(1, h, w, conv.Cout).contiguous())
+            dw += o["dw"]
+            db += o["db"]
+            dxs.append(o["dx"].reshape(-1, conv.Cin))
+        return torch.cat(dxs).contiguous(), dw, db
+    G32 = torch.zeros((off[-1], 32), device=dev)
+    G32[:, :5] = rows(Go).to(dev)
+    gx, dWo, dbo = conv_bwd(outc, x, G32)
+    ref = Wo.grad.permute(0, 2, 3, 1).reshape(5, -1)
+    assert float((dWo[:5].cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    for i in reversed(range(4)):
+        xin, c, st, y = keep[i]
+        dc, dga, dbe = ops.groupnorm_relu_backward(c, y, gx, gam[i].detach().to(dev), off, Cc, st)
+        gx, dw, db = conv_bwd(tower[i], xin, dc)
+        for name, got, r in (("tower dW", dw.cpu(), Wt[i].grad.permute(0, 2, 3, 1).reshape(Cc, -1)), ("tower db", db.cpu(), bt[i].grad),
+                             ("dgamma", dga.cpu(), gam[i].grad), ("dbeta", dbe.cpu(), bet[i].grad)):
+            assert float((got - r).abs().max()) <= 2e-4 * float(r.abs().max()), (i, name, float((got - r).abs().max()), float(r.abs().max()))
+    # gx = dL/d(fused P3..P5): into the backward of the memory read (first slice)
+    out = ops.MemoryProjectorBackward([w.detach() for w in Wm], dev)([gx[off[l]:off[l + 1]].contiguous() for l in range(3)], pooled_d, H, W, weight)
+    for l in range(3):
+        rdw, rdb = Wm[l].grad.reshape(256, 512), bm[l].grad
+        assert float((out["dW"][l].cpu() - rdw).abs().max()) <= 3e-4 * float(rdw.abs().max()), l
+        assert float((out["db"][l].cpu() - rdb).abs().max()) <= 3e-4 * float(rdb.abs().max()), l

@@ -168,8 +168,8 @@ struct ConvBwdArgs {
   const float* g;   // [N,H,W,Cout]
   float* dw;        // [Cout][KH*KW*Cin]
   float* db;        // [Cout] or null
-  int N, H, W, Cin, Cout, KH, KW, pad;
-  FastDiv div_w, div_h;
+  int N, H, W, Cin, Cout, KH, KW, pad, stride, OH, OW;
+  FastDiv div_w, div_h;     // by OW, OH
 };
 
 __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs a) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
   const int ky = tap / a.KW, kx = tap - ky * a.KW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, kh = lane >> 5;
-  const int P = a.N * a.H * a.W;
+  const int P = a.N * a.OH * a.OW;            // positions of the OUTPUT grid
   const int steps = (P + 7) / 8;
   const int spw = (steps + 3) / 4;
   const int s_begin = wave * spw;
@@ -198,11 +198,11 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
       float gv = 0.f, xv = 0.f;
       if (pos < P) {
         gv = a.g[(size_t)pos * a.Cout + co0 + col];
-        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * H + oy
-        const int ox = pos - row * a.W;
+        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * OH + oy
+        const int ox = pos - row * a.OW;
         const int n = (int)fdiv((unsigned)row, a.div_h);
-        const int oy = row - n * a.H;
-        const int iy = oy + ky - a.pad, ix = ox + kx - a.pad;
+        const int oy = row - n * a.OH;
+        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
           xv = a.x[((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + col];
       }
@@ -243,6 +243,35 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
   }
 }
 
+// Input gradient of a STRIDED convolution (P6 / P7, timm.py:359-364; the trunk's stride-2 layers), gather form: one workgroup per
+// input position, thread = input channel; dX[n][iy][ix][ci] = sum over the taps (ky, kx) with (iy + pad - ky) and (ix + pad - kx)
+// multiples of the stride of sum_co G[n][(iy + pad - ky) / s][(ix + pad - kx) / s][co] * W[co][(ky, kx, ci)].  Weight reads are
+// coalesced over ci, G values are broadcasts.  (Stride-1 layers use eod_conv2d with the rotated weights: matrix cores.)
+__global__ __launch_bounds__(256) void conv_backward_input_kernel(ConvBwdArgs a, const float* __restrict__ w, int Kpad, float* __restrict__ dx) {
+  const int pos = blockIdx.x;                         // (n, iy, ix)
+  const int ix = pos % a.W, t = pos / a.W;
+  const int iy = t % a.H, n = t / a.H;
+  for (int ci = threadIdx.x; ci < a.Cin; ci += blockDim.x) {
+    float acc = 0.f;
+    for (int ky = 0; ky < a.KH; ++ky) {
+      const int ny = iy + a.pad - ky;
+      if (ny < 0 || ny % a.stride != 0) continue;
+      const int oy = ny / a.stride;
+      if (oy >= a.OH) continue;
+      for (int kx = 0; kx < a.KW; ++kx) {
+        const int nx = ix + a.pad - kx;
+        if (nx < 0 || nx % a.stride != 0) continue;
+        const int ox = nx / a.stride;
+        if (ox >= a.OW) continue;
+        const float* gp = a.g + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout;
+        const float* wp = w + (size_t)(ky * a.KW + kx) * a.Cin + ci;
+        for (int co = 0; co < a.Cout; ++co) acc += gp[co] * wp[(size_t)co * Kpad];
+      }
+    }
+    dx[(size_t)pos * a.Cin + ci] = acc;
+  }
+}
+
 // dL/d(pre-activation) of a ReLU layer from dL/d(output): g where the output was positive
 __global__ __launch_bounds__(256) void relu_backward_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
                                                              size_t n4) {
@@ -260,19 +289,39 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
-                                           float* dw, float* db, eod_stream_t stream) {
-  if (!x || !g || !dw) return EOD_ERR_NULL;
+static int conv_bwd_args(ConvBwdArgs& a, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || (Cout & 31) || KH <= 0 || KW <= 0 || KH * KW > 64 ||
-      2 * pad != KH - 1 || KH != KW)
-    return EOD_ERR_BAD_DIMS;                        // stride 1, 'same': the output grid is the input grid
+      pad < 0 || stride < 1 || H + 2 * pad < KH || W + 2 * pad < KW)
+    return EOD_ERR_BAD_DIMS;
   if ((long)N * H * W >= (1L << 28)) return EOD_ERR_BAD_DIMS;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.pad = pad; a.stride = stride;
+  a.OH = (H + 2 * pad - KH) / stride + 1;
+  a.OW = (W + 2 * pad - KW) / stride + 1;
+  a.div_w = eod_make_fastdiv((unsigned)a.OW);
+  a.div_h = eod_make_fastdiv((unsigned)a.OH);
+  return EOD_OK;
+}
+
+extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                           int stride, float* dw, float* db, eod_stream_t stream) {
+  if (!x || !g || !dw) return EOD_ERR_NULL;
   ConvBwdArgs a{};
+  const int st = conv_bwd_args(a, N, H, W, Cin, Cout, KH, KW, pad, stride);
+  if (st != EOD_OK) return st;
   a.x = x; a.g = g; a.dw = dw; a.db = db;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.pad = pad;
-  a.div_w = eod_make_fastdiv((unsigned)W);
-  a.div_h = eod_make_fastdiv((unsigned)H);
   hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                         int pad, int stride, float* dx, eod_stream_t stream) {
+  if (!g || !w || !dx) return EOD_ERR_NULL;
+  ConvBwdArgs a{};
+  const int st = conv_bwd_args(a, N, H, W, Cin, Cout, KH, KW, pad, stride);
+  if (st != EOD_OK) return st;
+  if (Kpad < KH * KW * Cin) return EOD_ERR_BAD_DIMS;
+  a.g = g;
+  hipLaunchKernelGGL(conv_backward_input_kernel, dim3(N * H * W), dim3(256), 0, (hipStream_t)stream, a, w, Kpad, dx);
   return eod_launch_status();
 }
 

@@ -565,8 +565,10 @@ class ConvBackward:
     weights; dw / db = `eod_conv2d_backward_weights`."""
 
     def __init__(self, conv: "Conv"):
-        if conv.stride != 1 or conv.KH != conv.KW or conv.pad * 2 != conv.KH - 1 or conv.out_mode != 0 or conv.tap4:
-            raise ValueError("ConvBackward covers stride-1 'same' convolutions")
+        if conv.out_mode != 0 or conv.tap4:
+            raise ValueError("ConvBackward covers plain convolutions (no deconv, no 4-channel stem)")
+        # stride-1 'same' layers: dX on the matrix cores (eod_conv2d with rotated weights); anything else: the gather kernel
+        self.same = conv.stride == 1 and conv.KH == conv.KW and conv.pad * 2 == conv.KH - 1
         self.conv = conv
         self.lib = _lib.load()
         self._flipped = None
@@ -588,7 +590,8 @@ class ConvBackward:
         c = self.conv
         _need_cuda(x, y, g_out)
         N, H, W, _ = x.shape
-        assert tuple(g_out.shape) == (N, H, W, c.Cout) and x.is_contiguous() and g_out.is_contiguous()
+        OH, OW = c.out_hw(H, W)
+        assert tuple(g_out.shape) == (N, OH, OW, c.Cout) and x.is_contiguous() and g_out.is_contiguous()
         g = g_out
         if relu:
             g = torch.empty_like(g_out)
@@ -596,9 +599,15 @@ class ConvBackward:
         K = c.KH * c.KW * c.Cin
         dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
         db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
-        check(self.lib.eod_conv2d_backward_weights(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, dw.data_ptr(),
-                                                   db.data_ptr(), _stream()), "eod_conv2d_backward_weights")
-        dx = self._dgrad_conv()(g, N, H, W) if need_dx else None
+        check(self.lib.eod_conv2d_backward_weights(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
+                                                   dw.data_ptr(), db.data_ptr(), _stream()), "eod_conv2d_backward_weights")
+        dx = None
+        if need_dx and self.same:
+            dx = self._dgrad_conv()(g, N, H, W)
+        elif need_dx:
+            dx = torch.empty_like(x)
+            check(self.lib.eod_conv2d_backward_input(g.data_ptr(), c.w.data_ptr(), c.Kpad, N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
+                                                     dx.data_ptr(), _stream()), "eod_conv2d_backward_input")
         return dict(dx=dx, dw=dw, db=db)
 
 

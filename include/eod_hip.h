@@ -340,13 +340,17 @@ int eod_memory_project_backward_weights(const float* g3, const float* g4, const 
 int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* dec5, int H, int W, uint16_t* ge3_f16, uint16_t* ge4_f16,
                              uint16_t* ge5_f16, float* ge2, eod_stream_t stream);
 
-/* Third slice: backward of a stride-1 'same' convolution layer (KH = KW odd, pad = KH / 2; NHWC fp32, Cin and Cout multiples of
- * 32): the layers downstream of the memory fusion -- CenterNet tower (centernet_head.py:141-161), FPN output convs (timm.py:118-136),
+/* Third slice: backward of a convolution layer (NHWC fp32, Cin and Cout multiples of 32; g on the layer's output grid
+ * [N,OH,OW,Cout], OH = (H + 2 pad - KH) / stride + 1): the layers downstream of the memory fusion -- CenterNet tower (centernet_head.py:141-161), FPN output convs (timm.py:118-136),
  * mask head convs (detic_roi_heads.py:257-268).  x [N,H,W,Cin] the layer's input, g [N,H,W,Cout] dL/d(pre-activation output).
  * dw [Cout][KH*KW*Cin] in the layout of the packed forward weights (k = (ky, kx, ci), ci fastest), db [Cout] or NULL (fp32 MFMA,
  * deterministic summation order).  The gradient with respect to x is eod_conv2d of g with the rotated / transposed weights. */
 int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
-                                float* dw, float* db, eod_stream_t stream);
+                                int stride, float* dw, float* db, eod_stream_t stream);
+/* Input gradient of a strided convolution (stride >= 2: P6 / P7, timm.py:359-364; g is [N,OH,OW,Cout]), gather form, w = the
+ * forward's packed weights [Cout][Kpad]; dx [N,H,W,Cin].  Stride-1 'same' layers use eod_conv2d with the rotated weights instead. */
+int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                              int stride, float* dx, eod_stream_t stream);
 /* out = g where y > 0, else 0 (backward of the ReLU epilogue); n % 4 == 0, 16-byte aligned */
 int eod_relu_backward(const float* g, const float* y, float* out, size_t n, eod_stream_t stream);
 

@@ -121,23 +121,26 @@ def test_memory_read_training_steps_match_torch(tmp_path):
         assert float((Wd[0].cpu() - W0[0].reshape(256, 512)).abs().max()) > 0.5 * base_lr * mult * (it + 1) * 0.5
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,k,relu", [(1, 20, 28, 256, 256, 3, True), (2, 14, 14, 256, 256, 3, True), (1, 10, 12, 64, 96, 1, False),
-                                                   (1, 9, 7, 32, 64, 5, True)])
-def test_conv_layer_backward_matches_autograd(N, H, W, Cin, Cout, k, relu):
-    """Third slice: dX, dW, db of a stride-1 'same' conv + bias (+ ReLU) layer -- the tower / FPN output / mask head layers downstream of
-    the memory fusion -- against torch autograd on the CPU in fp32."""
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,relu,stride", [(1, 20, 28, 256, 256, 3, True, 1), (2, 14, 14, 256, 256, 3, True, 1),
+                                                          (1, 10, 12, 64, 96, 1, False, 1), (1, 9, 7, 32, 64, 5, True, 1),
+                                                          (1, 20, 20, 256, 256, 3, False, 2), (1, 10, 10, 256, 256, 3, False, 2),
+                                                          (2, 13, 9, 64, 32, 3, True, 2), (1, 16, 16, 64, 128, 1, False, 2)])
+def test_conv_layer_backward_matches_autograd(N, H, W, Cin, Cout, k, relu, stride):
+    """Third slice: dX, dW, db of a conv + bias (+ ReLU) layer -- stride 1 'same' (tower / FPN output / mask head: dX on the matrix
+    cores) and stride 2 (P6 / P7 and the trunk's down-sampling layers: dX by the gather kernel) -- against torch autograd."""
     from embodied_object_detection_amd import ops
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(21)
     w = (torch.randn((Cout, Cin, k, k), generator=g) * (0.5 / (Cin * k * k) ** 0.5)).requires_grad_()
     b = (torch.randn((Cout,), generator=g) * 0.1).requires_grad_()
     x = torch.randn((N, Cin, H, W), generator=g).requires_grad_()
-    go = torch.randn((N, Cout, H, W), generator=g)
-    y = F.conv2d(x, w, b, padding=k // 2)
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    go = torch.randn((N, Cout, OH, OW), generator=g)
+    y = F.conv2d(x, w, b, padding=k // 2, stride=stride)
     if relu:
         y = F.relu(y)
     (y * go).sum().backward()
-    conv = ops.Conv(w.detach(), b.detach(), pad=k // 2, device=dev)
+    conv = ops.Conv(w.detach(), b.detach(), stride=stride, pad=k // 2, device=dev)
     xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
     yd = conv(xd, N, H, W, relu=relu)
     out = ops.ConvBackward(conv)(xd, yd, go.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)

@@ -47,9 +47,13 @@ def main():
                      "lane) coalesced reads of MI355X_MICROARCH.md's HBM section; the launches run in the default multi-stream schedule",
            "detection_pass_launch": det, "proposal_pass_launch": prop,
            "note": "the grid is the launch's capacity (300 / 128 ROIs); the ROIs really computed are the frame's distinct detection "
-                   "boxes (~90) / memory instances (~43): algorithmic bytes per launch = rois * 196 * 256 * 4 * 2 + 256 * 2304 * 4"}
-    for key, rois in (("detection_pass_launch", float(os.environ.get("DET_ROIS", 90))), ("proposal_pass_launch", float(os.environ.get("PROP_ROIS", 43)))):
+                   "boxes / memory instances, here taken from the launches' own WRITE_SIZE (rois_mean = write bytes / (196 * 256 * 4)): "
+                   "algorithmic bytes per launch = rois * 196 * 256 * 4 * 2 + 256 * 2304 * 4"}
+    for key in ("detection_pass_launch", "proposal_pass_launch"):
         if out[key]:
+            # the ROIs these launches really computed: every ROI writes 196 x 256 fp32 outputs, so the WRITE_SIZE counter gives the
+            # mean count of the profiled frames themselves (the short profiling run is not the bench's 60-frame average)
+            rois = round(out[key]["write_bytes"] / (196 * 256 * 4), 1)
             alg = rois * 196 * 256 * 4 * 2 + 256 * 2304 * 4
             out[key]["rois_mean"] = rois
             out[key]["algorithmic_bytes_per_launch"] = round(alg, 1)

@@ -272,6 +272,77 @@ __global__ __launch_bounds__(256) void conv_backward_input_kernel(ConvBwdArgs a,
   }
 }
 
+// FPN top-down add (timm.py:128-133: lateral + nearest x2 of the coarser level): the coarser level's gradient is the sum over each
+// 2x2 block of the finer level's gradient (the lateral branch gets the gradient itself).  g [N,2h,2w,C] -> out [N,h,w,C] (+= when
+// accumulate: the coarser level also has its own output-conv branch).
+__global__ __launch_bounds__(256) void upsample2_backward_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int h, int w,
+                                                                  int C4, int accumulate) {
+  const size_t total = (size_t)N * h * w * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h), n = (int)(t / h);
+    const f32x4* gp = reinterpret_cast<const f32x4*>(g);
+    const size_t r0 = ((size_t)(n * 2 * h + 2 * y) * (2 * w) + 2 * x) * C4 + c, r1 = r0 + (size_t)2 * w * C4;
+    f32x4 v = gp[r0];
+    v += gp[r0 + C4];
+    v += gp[r1];
+    v += gp[r1 + C4];
+    f32x4* op = reinterpret_cast<f32x4*>(out) + i;
+    if (accumulate) v += *op;
+    *op = v;
+  }
+}
+
+// timm ResNet maxpool 3x3 s2 p1 (timm.py:281) backward: every input position collects the gradient of the output windows whose
+// maximum it is -- the FIRST maximum of a window in row-major tap order, as torch's max_pool2d backward routes it.  Gather form
+// (no atomics): x [N,H,W,C], y / g [N,OH,OW,C] -> dx [N,H,W,C].
+__global__ __launch_bounds__(256) void maxpool3x3s2_backward_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                     const float* __restrict__ g, float* __restrict__ dx, int N, int H, int W,
+                                                                     int C, int OH, int OW) {
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H), n = (int)(t / H);
+    const float xv = x[i];
+    float acc = 0.f;
+    // output windows that contain (iy, ix): oy in {ceil((iy - 1) / 2) .. floor((iy + 1) / 2)}: one for an even row, two for an odd one
+    for (int oy = (iy + 1) / 2 - (iy & 1); oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      for (int ox = (ix + 1) / 2 - (ix & 1); ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        const size_t o = ((size_t)(n * OH + oy) * OW + ox) * C + c;
+        if (y[o] != xv) continue;
+        // am I the first tap of this window (row-major) that holds the maximum?
+        bool first = true;
+        for (int ky = 0; ky < 3 && first; ++ky) {
+          const int yy = oy * 2 - 1 + ky;
+          if (yy < 0 || yy >= H) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = ox * 2 - 1 + kx;
+            if (xx < 0 || xx >= W) continue;
+            if (yy == iy && xx == ix) {
+              ky = 3;
+              break;
+            }
+            if (x[((size_t)(n * H + yy) * W + xx) * C + c] == xv) {
+              first = false;
+              break;
+            }
+          }
+        }
+        if (first) acc += g[o];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
 // dL/d(pre-activation) of a ReLU layer from dL/d(output): g where the output was positive
 __global__ __launch_bounds__(256) void relu_backward_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
                                                              size_t n4) {
@@ -322,6 +393,28 @@ extern "C" int eod_conv2d_backward_input(const float* g, const float* w, int Kpa
   if (Kpad < KH * KW * Cin) return EOD_ERR_BAD_DIMS;
   a.g = g;
   hipLaunchKernelGGL(conv_backward_input_kernel, dim3(N * H * W), dim3(256), 0, (hipStream_t)stream, a, w, Kpad, dx);
+  return eod_launch_status();
+}
+
+extern "C" int eod_upsample2_sum_backward(const float* g, float* out, int N, int h, int w, int C, int accumulate, eod_stream_t stream) {
+  if (!g || !out) return EOD_ERR_NULL;
+  if (N <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(g) || !eod_aligned16(out)) return EOD_ERR_ALIGN;
+  const size_t total = (size_t)N * h * w * (C >> 2);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(upsample2_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, N, h, w, C >> 2, accumulate);
+  return eod_launch_status();
+}
+
+extern "C" int eod_maxpool3x3s2_backward(const float* x, const float* y, const float* g, float* dx, int N, int H, int W, int C, int OH,
+                                         int OW, eod_stream_t stream) {
+  if (!x || !y || !g || !dx) return EOD_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1) return EOD_ERR_BAD_DIMS;
+  const size_t total = (size_t)N * H * W * C;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(maxpool3x3s2_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, g, dx, N, H, W, C, OH, OW);
   return eod_launch_status();
 }
 

@@ -351,6 +351,13 @@ int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, in
  * forward's packed weights [Cout][Kpad]; dx [N,H,W,Cin].  Stride-1 'same' layers use eod_conv2d with the rotated weights instead. */
 int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                               int stride, float* dx, eod_stream_t stream);
+/* Backward of the FPN top-down add (res_mode 2 of eod_conv2d: + nearest-x2 of the coarser level, timm.py:128-133): out [N,h,w,C]
+ * (+)= the sum of each 2x2 block of g [N,2h,2w,C].  C % 4 == 0. */
+int eod_upsample2_sum_backward(const float* g, float* out, int N, int h, int w, int C, int accumulate, eod_stream_t stream);
+/* Backward of eod_maxpool3x3s2 (timm.py:281): the gradient of an output window goes to the first maximum of the window in row-major
+ * order (torch's max_pool2d backward); gather form, no atomics. */
+int eod_maxpool3x3s2_backward(const float* x, const float* y, const float* g, float* dx, int N, int H, int W, int C, int OH, int OW,
+                              eod_stream_t stream);
 /* out = g where y > 0, else 0 (backward of the ReLU epilogue); n % 4 == 0, 16-byte aligned */
 int eod_relu_backward(const float* g, const float* y, float* out, size_t n, eod_stream_t stream);
 

@@ -302,3 +302,39 @@ def test_head_loss_gradient_reaches_the_memory_projections():
         rdw, rdb = Wm[l].grad.reshape(256, 512), bm[l].grad
         assert float((out["dW"][l].cpu() - rdw).abs().max()) <= 3e-4 * float(rdw.abs().max()), l
         assert float((out["db"][l].cpu() - rdb).abs().max()) <= 3e-4 * float(rdb.abs().max()), l
+
+
+def test_fpn_add_and_maxpool_backward_match_autograd():
+    """The two non-conv pieces of the backbone's backward: the FPN top-down add (nearest x2 of the coarser level, timm.py:128-133) and
+    the trunk's 3x3 stride-2 max pool (timm.py:281; ties go to the first maximum of a window, as torch routes them)."""
+    import ctypes as C
+    from embodied_object_detection_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(51)
+    # nearest x2 add
+    coarse = torch.randn((2, 64, 5, 7), generator=g).requires_grad_()
+    fine = torch.randn((2, 64, 10, 14), generator=g).requires_grad_()
+    go = torch.randn((2, 64, 10, 14), generator=g)
+    ((fine + F.interpolate(coarse, scale_factor=2.0, mode="nearest")) * go).sum().backward()
+    gd = go.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.full((2, 5, 7, 64), 1.5, device=dev)
+    _lib.check(lib.eod_upsample2_sum_backward(gd.data_ptr(), out.data_ptr(), 2, 5, 7, 64, 1, s), "up")
+    ref = coarse.grad.permute(0, 2, 3, 1) + 1.5
+    assert float((out.cpu() - ref).abs().max()) <= 1e-5
+    _lib.check(lib.eod_upsample2_sum_backward(gd.data_ptr(), out.data_ptr(), 2, 5, 7, 64, 0, s), "up")
+    assert float((out.cpu() - coarse.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-5
+    # max pool, odd and even sizes, with ties (quantised values)
+    for (H, W) in ((12, 16), (11, 9)):
+        x = (torch.randn((2, 32, H, W), generator=g) * 2).round().requires_grad_()      # many equal values: ties inside the windows
+        y = F.max_pool2d(x, 3, 2, 1)
+        go = torch.randn(y.shape, generator=g)
+        (y * go).sum().backward()
+        OH, OW = y.shape[2], y.shape[3]
+        xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        yd = y.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        gd = go.permute(0, 2, 3, 1).contiguous().to(dev)
+        dx = torch.empty_like(xd)
+        _lib.check(lib.eod_maxpool3x3s2_backward(xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), dx.data_ptr(), 2, H, W, 32, OH, OW, s), "mp")
+        assert float((dx.cpu() - x.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-5, (H, W)

@@ -243,6 +243,41 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
   }
 }
 
+// Weight gradient of the 4-channel stem (tap layout: packed k = (ky, kx, ci), ci < 4; timm.py:279): Cin is too narrow for the
+// matrix-core tiles above.  Workgroup = one tap x 16 output channels; its 16 waves take every 16th output position, lane =
+// (co, ci); the 16 partial sums are added in wave order through LDS (deterministic).  Tap 0's workgroups also write db.
+__global__ __launch_bounds__(1024) void conv_backward_weights_tap4_kernel(ConvBwdArgs a) {
+  __shared__ float part[16][64];
+  __shared__ float partb[16][16];
+  const int tap = blockIdx.x, co0 = blockIdx.y * 16;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  const int t = threadIdx.x, ci = t & 3, col = (t >> 2) & 15, lane_p = t >> 6;
+  const int P = a.N * a.OH * a.OW;
+  float acc = 0.f, accb = 0.f;
+#pragma unroll 4
+  for (int p = lane_p; p < P; p += 16) {
+    const int ox = p % a.OW, r = p / a.OW;
+    const int oy = r % a.OH, n = r / a.OH;
+    const float gv = a.g[(size_t)p * a.Cout + co0 + col];
+    accb += gv;
+    const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) acc += gv * a.x[((size_t)(n * a.H + iy) * a.W + ix) * 4 + ci];
+  }
+  part[lane_p][t & 63] = acc;
+  if (ci == 0) partb[lane_p][col] = accb;
+  __syncthreads();
+  if (t < 64) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += part[i][t];
+    a.dw[(size_t)(co0 + col) * (a.KH * a.KW * 4) + tap * 4 + ci] = s;
+    if (tap == 0 && ci == 0 && a.db) {
+      float sb = 0.f;
+      for (int i = 0; i < 16; ++i) sb += partb[i][col];
+      a.db[co0 + col] = sb;
+    }
+  }
+}
+
 // Input gradient of a STRIDED convolution (P6 / P7, timm.py:359-364; the trunk's stride-2 layers), gather form: one workgroup per
 // input position, thread = input channel; dX[n][iy][ix][ci] = sum over the taps (ky, kx) with (iy + pad - ky) and (ix + pad - kx)
 // multiples of the stride of sum_co G[n][(iy + pad - ky) / s][(ix + pad - kx) / s][co] * W[co][(ky, kx, ci)].  Weight reads are
@@ -377,10 +412,14 @@ extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N
                                            int stride, float* dw, float* db, eod_stream_t stream) {
   if (!x || !g || !dw) return EOD_ERR_NULL;
   ConvBwdArgs a{};
-  const int st = conv_bwd_args(a, N, H, W, Cin, Cout, KH, KW, pad, stride);
+  const int st = conv_bwd_args(a, N, H, W, Cin == 4 ? 32 : Cin, Cout, KH, KW, pad, stride);     // Cin == 4: the stem's tap layout
   if (st != EOD_OK) return st;
+  a.Cin = Cin;
   a.x = x; a.g = g; a.dw = dw; a.db = db;
-  hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
+  if (Cin == 4)
+    hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4), dim3(1024), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
   return eod_launch_status();
 }
 

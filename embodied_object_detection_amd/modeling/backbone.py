@@ -45,17 +45,22 @@ class ResNet50Trunk:
                     ds = ops.Conv(wd, bd, stride=stride, device=device, name=f"{p}.downsample")
                 self.blocks.append((li, c1, c2, c3, ds))
 
-    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, plan_like_single: bool = True):
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, plan_like_single: bool = True, keep: Optional[dict] = None):
         """x4: [N,H,W,4] normalised image(s) -> {'layer3','layer4','layer5'}: (tensor, h, w).  N > 1: every layer is ONE launch
         over the batch, planned like a single image (`plan_rows`), so each image's result is bitwise that of an N = 1 call
-        (`plan_like_single = False`: planned for the rows the launch really has)."""
+        (`plan_like_single = False`: planned for the rows the launch really has).  `keep`: a dict that receives every activation
+        the backward needs (`modeling/backward.py`); the launches are the same."""
         def pr(conv, hh, ww):
             oh, ow = conv.out_hw(hh, ww)
             return oh * ow if (N > 1 and plan_like_single) else 0
 
         x = self.stem(x4, N, H, W, relu=True, plan_rows=pr(self.stem, H, W))
         h, w = self.stem.out_hw(H, W)
+        stem_out, hs, ws = x, h, w
         x, h, w = ops.maxpool3x3s2(x, N, h, w, 64)
+        if keep is not None:
+            keep["stem"] = (stem_out, hs, ws, x, h, w)
+            keep["blocks"] = []
         feats = {}
         cur_layer = 1
         for (li, c1, c2, c3, ds) in self.blocks:
@@ -66,9 +71,13 @@ class ResNet50Trunk:
             if ds is not None:
                 sc = ds(x, N, h, w, plan_rows=pr(ds, h, w))
             o = c1(x, N, h, w, relu=True, plan_rows=pr(c1, h, w))
+            o1 = o
             o = c2(o, N, h, w, relu=True, plan_rows=pr(c2, h, w))
             h2, w2 = c2.out_hw(h, w)
+            x_in = x
             x = c3(o, N, h2, w2, res=sc, res_mode=1, relu=True, plan_rows=pr(c3, h2, w2))
+            if keep is not None:
+                keep["blocks"].append((x_in, o1, o, x, h, w, h2, w2))
             h, w = h2, w2
         feats[f"layer{cur_layer + 1}"] = (x, h, w)
         return feats

@@ -1,0 +1,141 @@
+"""Backward of the backbone (training slices): the chain of the per-layer HIP backward kernels over the
+ResNet-50 trunk (`Detic/detic/modeling/backbone/timm.py:277-299`), the FPN top-down pass (`timm.py:118-136`) and P6 / P7
+(`timm.py:347-364`), driven by the gradients of the five pyramid levels the heads hand back.
+
+Not part of the inference hot path: the forward here launches exactly the layers of `CustomRecurrentFPN.top_down` /
+`fuse_memory_and_top` but keeps every activation the backward reads.  Gradients come back per `ops.Conv` (dW in the layer's
+packed [Cout, KH*KW*Cin] layout, db) -- for the trunk these are the gradients of the FrozenBatchNorm-FOLDED weights: the raw
+conv weight's gradient is dW * gamma / sqrt(var + eps) per output channel and db is the gradient of the norm's bias.  The 7x7
+stem (4-channel tap layout) gets its weight gradient from a kernel of its own and no input gradient (its input is the image).
+Residual sums between the kernels are plain device adds.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _lib, ops
+from .backbone import CustomRecurrentFPN
+
+
+class BackboneBackward:
+    def __init__(self, backbone: CustomRecurrentFPN):
+        if backbone.feat_fusion not in ("sum", "image_only"):
+            raise ValueError("the backbone's backward covers MAP_FEAT_FUSION sum / image_only (mem_only has no image gradient)")
+        self.bb = backbone
+        self.lib = _lib.load()
+        self._bw: Dict[int, ops.ConvBackward] = {}
+
+    def _b(self, conv: ops.Conv) -> ops.ConvBackward:
+        if id(conv) not in self._bw:
+            self._bw[id(conv)] = ops.ConvBackward(conv)
+        return self._bw[id(conv)]
+
+    # ---- forward that keeps its activations -------------------------------------------------------------------------------
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, memory_term: Optional[List[torch.Tensor]] = None):
+        """-> ([P3..P7] as [N,h,w,256] tensors, saved).  `memory_term`: what the memory fusion adds to P3..P5 (weight x
+        projection of the pooled memory, already computed by `eod_memory_project_fuse`'s training form); None = image only."""
+        bb = self.bb
+        keep: dict = {}
+        c = bb.bottom_up.forward(x4, H, W, N, keep=keep)
+        (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
+        lat5 = bb.lateral[5](c5, N, h5, w5)
+        p5 = bb.output[5](lat5, N, h5, w5)
+        lat4 = bb.lateral[4](c4, N, h4, w4, res=lat5, res_mode=2)
+        p4 = bb.output[4](lat4, N, h4, w4)
+        lat3 = bb.lateral[3](c3, N, h3, w3, res=lat4, res_mode=2)
+        p3 = bb.output[3](lat3, N, h3, w3)
+        P = [p3, p4, p5]
+        if memory_term is not None:
+            P = [p + m.view_as(p) for p, m in zip(P, memory_term)]
+        p6 = bb.p6(P[2], N, h5, w5)
+        h6, w6 = bb.p6.out_hw(h5, w5)
+        p7 = bb.p7(p6, N, h6, w6, in_relu=True)
+        keep["fpn"] = dict(c=(c3, c4, c5), lat=(lat3, lat4, lat5), P=P, p6=p6, hw=((h3, w3), (h4, w4), (h5, w5), (h6, w6)))
+        keep["N"] = N
+        keep["x4"] = x4
+        return P + [p6, p7], keep
+
+    # ---- backward ------------------------------------------------------------------------------------------------------------
+    def _relu_bw(self, g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(g)
+        _lib.check(self.lib.eod_relu_backward(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), ops._stream()), "eod_relu_backward")
+        return out
+
+    def _up_bw(self, g_fine: torch.Tensor, out: torch.Tensor, N: int, h: int, w: int):
+        _lib.check(self.lib.eod_upsample2_sum_backward(g_fine.data_ptr(), out.data_ptr(), N, h, w, 256, 1, ops._stream()),
+                   "eod_upsample2_sum_backward")
+
+    def backward(self, saved: dict, dP: List[torch.Tensor], need_stem_grad: bool = True):
+        """dP: dL/d(P3..P7) ([N,h,w,256] each) -> (grads {conv.name: (dw, db)}, dL/d(stem pre-activation) or None; without
+        `need_stem_grad` the chain stops at the max pool and the stem gets no entry)."""
+        bb, N = self.bb, saved["N"]
+        f = saved["fpn"]
+        (c3, c4, c5), (lat3, lat4, lat5), P, p6 = f["c"], f["lat"], f["P"], f["p6"]
+        (h3, w3), (h4, w4), (h5, w5), (h6, w6) = f["hw"]
+        grads: Dict[str, tuple] = {}
+
+        def put(conv, r):
+            if conv.name in grads:
+                raise RuntimeError(f"layer {conv.name} visited twice")
+            grads[conv.name] = (r["dw"], r["db"])
+
+        # P7 = conv(relu(P6)), P6 = conv(P5 fused)
+        x7 = torch.relu(p6)
+        r = self._b(bb.p7)(x7, None, dP[4].contiguous())
+        put(bb.p7, r)
+        g6 = dP[3] + self._relu_bw(r["dx"], p6)
+        r = self._b(bb.p6)(P[2].contiguous(), None, g6.contiguous())
+        put(bb.p6, r)
+        g_out = [dP[0].contiguous(), dP[1].contiguous(), (dP[2] + r["dx"]).contiguous()]      # sum fusion: identity to the image branch
+        # output convs -> gradients of the merged laterals; top-down add: the coarser level also collects the 2x2 block sums
+        r5 = self._b(bb.output[5])(lat5, None, g_out[2])
+        put(bb.output[5], r5)
+        r4 = self._b(bb.output[4])(lat4, None, g_out[1])
+        put(bb.output[4], r4)
+        r3 = self._b(bb.output[3])(lat3, None, g_out[0])
+        put(bb.output[3], r3)
+        g_lat3 = r3["dx"]
+        g_lat4 = r4["dx"]
+        self._up_bw(g_lat3, g_lat4, N, h4, w4)
+        g_lat5 = r5["dx"]
+        self._up_bw(g_lat4, g_lat5, N, h5, w5)
+        gc = {}
+        for l, cx, gl in ((3, c3, g_lat3), (4, c4, g_lat4), (5, c5, g_lat5)):
+            r = self._b(bb.lateral[l])(cx, None, gl)
+            put(bb.lateral[l], r)
+            gc[l] = r["dx"]
+        # trunk, last block first; the exposed stage outputs ('layer3', 'layer4', 'layer5') collect their lateral's gradient
+        blocks = bb.bottom_up.blocks
+        kept = saved["blocks"]
+        g = gc[5]
+        for bi in range(len(blocks) - 1, -1, -1):
+            li, c1, c2, c3b, ds = blocks[bi]
+            x_in, o1, o2, y, h, w, h2, w2 = kept[bi]
+            gp = self._relu_bw(g, y)                          # through the block's final ReLU: gradient of (conv3 + shortcut)
+            r = self._b(c3b)(o2, None, gp)
+            put(c3b, r)
+            r2 = self._b(c2)(o1, o2, r["dx"], relu=True)
+            put(c2, r2)
+            r1 = self._b(c1)(x_in, o1, r2["dx"], relu=True)
+            put(c1, r1)
+            if ds is not None:
+                rd = self._b(ds)(x_in, None, gp)
+                put(ds, rd)
+                g = r1["dx"] + rd["dx"]
+            else:
+                g = r1["dx"] + gp
+            # first block of stage li: its input is stage li-1's output, which the FPN reads as 'layer{li}' (timm.py:379,404)
+            if bi > 0 and blocks[bi - 1][0] != li and li in gc:
+                g = g + gc[li]
+        g_stem = None
+        if need_stem_grad:
+            stem_out, hs, ws, pooled, hp, wp = saved["stem"]
+            dpre = torch.empty_like(stem_out)
+            _lib.check(self.lib.eod_maxpool3x3s2_backward(stem_out.data_ptr(), pooled.data_ptr(), g.contiguous().data_ptr(), dpre.data_ptr(),
+                                                          N, hs, ws, 64, hp, wp, ops._stream()), "eod_maxpool3x3s2_backward")
+            g_stem = self._relu_bw(dpre, stem_out)
+            x4 = saved["x4"]
+            put(bb.bottom_up.stem, self._b(bb.bottom_up.stem)(x4.view(N, -1, x4.shape[-2], 4), None, g_stem, need_dx=False))
+        return grads, g_stem

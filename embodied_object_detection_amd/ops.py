@@ -558,15 +558,16 @@ class MemoryProjectorBackward:
 
 
 class ConvBackward:
-    """Backward of a stride-1 'same' `Conv` layer with bias and optional ReLU (third slice): the layers downstream
-    of the memory fusion (CenterNet tower, FPN output convs, mask head convs).  `__call__(x, y, g_out)` with the forward's input `x`
+    """Backward of a `Conv` layer with bias and optional ReLU (third slice): stride-1 'same' layers (CenterNet
+    tower, FPN output convs, mask head convs, the trunk's 1x1 / 3x3 convs), strided ones (P6 / P7, the trunk's down-sampling convs)
+    and the weight gradient of the 4-channel stem.  `__call__(x, y, g_out)` with the forward's input `x`
     [N,H,W,Cin], output `y` [N,H,W,Cout] (post-ReLU, only read when `relu`) and dL/dy -> dict(dx, dw [Cout, KH*KW*Cin] in the packed
     layout of `Conv.w`, db).  dx = `eod_conv2d` of the pre-activation gradient with the 180-degree rotated, in/out-transposed
     weights; dw / db = `eod_conv2d_backward_weights`."""
 
     def __init__(self, conv: "Conv"):
-        if conv.out_mode != 0 or conv.tap4:
-            raise ValueError("ConvBackward covers plain convolutions (no deconv, no 4-channel stem)")
+        if conv.out_mode != 0:
+            raise ValueError("ConvBackward covers plain convolutions (no deconv)")
         # stride-1 'same' layers: dX on the matrix cores (eod_conv2d with rotated weights); anything else: the gather kernel
         self.same = conv.stride == 1 and conv.KH == conv.KW and conv.pad * 2 == conv.KH - 1
         self.conv = conv
@@ -589,6 +590,8 @@ class ConvBackward:
     def __call__(self, x: torch.Tensor, y: Optional[torch.Tensor], g_out: torch.Tensor, relu: bool = False, need_dx: bool = True):
         c = self.conv
         _need_cuda(x, y, g_out)
+        if c.tap4 and need_dx:
+            raise ValueError("the 4-channel stem has a weight gradient only (its input is the image): pass need_dx=False")
         N, H, W, _ = x.shape
         OH, OW = c.out_hw(H, W)
         assert tuple(g_out.shape) == (N, OH, OW, c.Cout) and x.is_contiguous() and g_out.is_contiguous()

@@ -340,7 +340,8 @@ int eod_memory_project_backward_weights(const float* g3, const float* g4, const 
 int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* dec5, int H, int W, uint16_t* ge3_f16, uint16_t* ge4_f16,
                              uint16_t* ge5_f16, float* ge2, eod_stream_t stream);
 
-/* Third slice: backward of a convolution layer (NHWC fp32, Cin and Cout multiples of 32; g on the layer's output grid
+/* Third slice: backward of a convolution layer (NHWC fp32, Cin and Cout multiples of 32, or Cin == 4: the stem's tap layout,
+ * timm.py:279; g on the layer's output grid
  * [N,OH,OW,Cout], OH = (H + 2 pad - KH) / stride + 1): the layers downstream of the memory fusion -- CenterNet tower (centernet_head.py:141-161), FPN output convs (timm.py:118-136),
  * mask head convs (detic_roi_heads.py:257-268).  x [N,H,W,Cin] the layer's input, g [N,H,W,Cout] dL/d(pre-activation output).
  * dw [Cout][KH*KW*Cin] in the layout of the packed forward weights (k = (ky, kx, ci), ci fastest), db [Cout] or NULL (fp32 MFMA,

@@ -338,3 +338,85 @@ def test_fpn_add_and_maxpool_backward_match_autograd():
         dx = torch.empty_like(xd)
         _lib.check(lib.eod_maxpool3x3s2_backward(xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), dx.data_ptr(), 2, H, W, 32, OH, OW, s), "mp")
         assert float((dx.cpu() - x.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-5, (H, W)
+
+
+def test_backbone_backward_matches_autograd(synthetic_sd):
+    """The whole backbone's backward as a chain of the per-layer HIP kernels (`modeling/backward.py`): gradients of P3..P7 flow through
+    P7 / P6, the FPN output convs, the top-down adds, the laterals and all 16 bottleneck blocks of the ResNet-50 trunk (residual
+    splits, strided 3x3 and 1x1 convs, ReLU masks, max pool) down to the 7x7 stem -- every conv's dW / db (61 layers) and the gradient of the stem's pre-activation against
+    torch autograd on the oracle's forward (timm.py:277-299, 118-136, 347-364).  The trunk's FrozenBatchNorm is folded into the
+    product's weights: dW_raw = dW_folded * gamma / sqrt(var + eps) per output channel, d(bn.bias) = db_folded."""
+    from embodied_object_detection_amd import build_model, ops, setup_cfg
+    from embodied_object_detection_amd.modeling.backward import BackboneBackward
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5])
+    model = build_model(cfg, synthetic_sd)
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(61)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    # ---- torch autograd on the oracle's forward (no memory term: the sum fusion adds a constant with respect to the backbone)
+    ocfg = M.OracleCfg(memory_type="none")
+    sd = {k: (v.clone().float().requires_grad_() if (k.startswith("backbone.") and v.is_floating_point()
+                                                      and "running_" not in k and "map_merge" not in k) else v)
+          for k, v in synthetic_sd.items()}
+    x = M.preprocess_image(img, ocfg)
+    base = "backbone.bottom_up.base"
+    stem = F.relu(M.frozen_bn(F.conv2d(x, sd[f"{base}.conv1.weight"], stride=2, padding=3), sd, f"{base}.bn1"))
+    stem.retain_grad()
+    t = F.max_pool2d(stem, kernel_size=3, stride=2, padding=1)
+    feats = {}
+    for li, nblk in enumerate((3, 4, 6, 3), start=1):
+        for b in range(nblk):
+            t = M.bottleneck(t, sd, f"{base}.layer{li}.{b}", 2 if (b == 0 and li > 1) else 1)
+        feats[f"layer{li + 1}"] = t
+    ref_P = M.fpn_top_down(feats, sd)
+    ref_P = ref_P + M.top_block(ref_P[2], sd)
+    Go = [torch.randn(p.shape, generator=g) for p in ref_P]
+    sum((p * go).sum() for p, go in zip(ref_P, Go)).backward()
+    # ---- HIP forward keeping the activations, then the chain of backward kernels
+    x4, Hp, Wp = ops.preprocess_image(img.to(dev), model.pixel_mean, model.pixel_std)
+    bw = BackboneBackward(model.backbone)
+    P, saved = bw.forward(x4, Hp, Wp)
+    for l in range(5):
+        ref = ref_P[l].detach().permute(0, 2, 3, 1)
+        assert float((P[l].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), l
+    grads, g_stem = bw.backward(saved, [go.permute(0, 2, 3, 1).contiguous().to(dev) for go in Go])
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+    worst = {}
+
+    def check(name, dw, db, w_raw, b_raw, scale=None):
+        rw = w_raw.grad.permute(0, 2, 3, 1)
+        if rw.shape[-1] == 3:                                   # the stem: 4-channel tap layout, the fourth channel is zero
+            rw = F.pad(rw, (0, 1))
+        rw = rw.reshape(w_raw.shape[0], -1)
+        got = dw.cpu()
+        if scale is not None:
+            got = got * scale[:, None]
+        worst[name] = max(rel(got, rw), rel(db.cpu(), b_raw.grad))
+        assert worst[name] <= 1e-4, (name, worst[name])
+
+    for l in (3, 4, 5):
+        check(f"fpn_lateral{l}", *grads[f"fpn_lateral{l}"], sd[f"backbone.fpn_lateral{l}.weight"], sd[f"backbone.fpn_lateral{l}.bias"])
+        check(f"fpn_output{l}", *grads[f"fpn_output{l}"], sd[f"backbone.fpn_output{l}.weight"], sd[f"backbone.fpn_output{l}.bias"])
+    check("p6", *grads["p6"], sd["backbone.top_block.p6.weight"], sd["backbone.top_block.p6.bias"])
+    check("p7", *grads["p7"], sd["backbone.top_block.p7.weight"], sd["backbone.top_block.p7.bias"])
+    n_trunk = 0
+    for li, nblk in enumerate((3, 4, 6, 3), start=1):
+        for b in range(nblk):
+            p = f"{base}.layer{li}.{b}"
+            pairs = [(f"{p}.conv{i}", f"{p}.conv{i}.weight", f"{p}.bn{i}") for i in (1, 2, 3)]
+            if f"{p}.downsample.0.weight" in sd:
+                pairs.append((f"{p}.downsample", f"{p}.downsample.0.weight", f"{p}.downsample.1"))
+            for name, wk, bnp in pairs:
+                scale = (sd[f"{bnp}.weight"] / torch.sqrt(sd[f"{bnp}.running_var"] + 1e-5)).detach()
+                check(name, *grads[name], sd[wk], sd[f"{bnp}.bias"], scale)
+                n_trunk += 1
+    bn1 = f"{base}.bn1"
+    check("stem", *grads["stem"], sd[f"{base}.conv1.weight"], sd[f"{bn1}.bias"],
+          (sd[f"{bn1}.weight"] / torch.sqrt(sd[f"{bn1}.running_var"] + 1e-5)).detach())
+    assert n_trunk == 52 and len(grads) == 52 + 8 + 1
+    ref_gs = (stem.grad * (stem.detach() > 0)).permute(0, 2, 3, 1)          # through the stem's ReLU: gradient of its pre-activation
+    assert rel(g_stem.cpu(), ref_gs) <= 1e-4
+    print("backbone backward: worst relative error %.2e (%s), stem-output gradient %.2e"
+          % (max(worst.values()), max(worst, key=worst.get), rel(g_stem.cpu(), ref_gs)))

@@ -138,6 +138,94 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs p) {
   }
 }
 
+// Backward of the pooling above (training slices; torchvision's roi_align backward as detectron2's ROIPooler reaches it): the
+// gradient of an output bin, divided by the bin's sample count, is spread over the four bilinear taps of every sample point with
+// hardware fp32 atomics into the gradient of the ROI's pyramid level (dfeat is accumulated into: the three cascade stages and the
+// mask pooler add into the same buffers).  Same wave / lane mapping and the same sample walk as the forward; single image.
+__global__ __launch_bounds__(256) void roi_align_backward_kernel(RoiArgs p, float* d3, float* d4, float* d5, const float* __restrict__ g) {
+  int R = p.R_cap;
+  if (p.count) {
+    const int c = *p.count;
+    R = c < R ? c : R;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int bins = p.S * p.S;
+  const int total = R * bins;
+  for (int wid = blockIdx.x * wpb + (threadIdx.x >> 6); wid < total; wid += gridDim.x * wpb) {
+    const int r = (int)fdiv((unsigned)wid, p.div_bins);
+    const int b = wid - r * bins;
+    const int ph = (int)fdiv((unsigned)b, p.div_s), pw = b - ph * p.S;
+    const float bx1 = p.boxes[r * 4 + 0], by1 = p.boxes[r * 4 + 1], bx2 = p.boxes[r * 4 + 2], by2 = p.boxes[r * 4 + 3];
+    const float area = (bx2 - bx1) * (by2 - by1);
+    float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
+    lv = fminf(fmaxf(lv, 3.0f), 5.0f);
+    const int l = (int)lv - 3;
+    const int H = p.h[l], W = p.w[l];
+    float* dfeat = l == 0 ? d3 : (l == 1 ? d4 : d5);
+    const float sc = p.scale[l];
+    const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f, x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+    const float roi_w = x2 - x1, roi_h = y2 - y1;
+    const float bin_h = roi_h / (float)p.S, bin_w = roi_w / (float)p.S;
+    const float ghf = ceilf(roi_h / (float)p.S), gwf = ceilf(roi_w / (float)p.S);
+    const bool sane = (ghf == ghf) && (gwf == gwf) && ghf < 1.0e6f && gwf < 1.0e6f;
+    const int gh = sane ? (int)ghf : 0;
+    const int gw = sane ? (int)gwf : 0;
+    const float cnt = fmaxf((float)gh * (float)gw, 1.0f);
+    int iy_lo = 0, iy_hi = gh - 1, ix_lo = 0, ix_hi = gw - 1;
+    if (gh > 0) {
+      const float ys = y1 + (float)ph * bin_h, st = bin_h / (float)gh;
+      iy_lo = max(0, (int)floorf((-1.0f - ys) / st - 0.5f) - 1);
+      iy_hi = min(gh - 1, (int)ceilf(((float)H - ys) / st - 0.5f) + 1);
+    }
+    if (gw > 0) {
+      const float xs = x1 + (float)pw * bin_w, st = bin_w / (float)gw;
+      ix_lo = max(0, (int)floorf((-1.0f - xs) / st - 0.5f) - 1);
+      ix_hi = min(gw - 1, (int)ceilf(((float)W - xs) / st - 0.5f) + 1);
+    }
+    for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + ((size_t)r * bins + b) * p.C + c0);
+      gv.x /= cnt; gv.y /= cnt; gv.z /= cnt; gv.w /= cnt;
+      for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        const float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+          float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          float yy = y;
+          if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+          if (yy <= 0.f) yy = 0.f;
+          if (x <= 0.f) x = 0.f;
+          int y_low = (int)yy, x_low = (int)x;
+          int y_high, x_high;
+          if (y_low >= H - 1) {
+            y_high = y_low = H - 1;
+            yy = (float)y_low;
+          } else {
+            y_high = y_low + 1;
+          }
+          if (x_low >= W - 1) {
+            x_high = x_low = W - 1;
+            x = (float)x_low;
+          } else {
+            x_high = x_low + 1;
+          }
+          const float ly = yy - (float)y_low, lx = x - (float)x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const float wt[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+          float* dst[4] = {dfeat + ((size_t)y_low * W + x_low) * p.C + c0, dfeat + ((size_t)y_low * W + x_high) * p.C + c0,
+                           dfeat + ((size_t)y_high * W + x_low) * p.C + c0, dfeat + ((size_t)y_high * W + x_high) * p.C + c0};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(dst[k] + 0, wt[k] * gv.x);
+            unsafeAtomicAdd(dst[k] + 1, wt[k] * gv.y);
+            unsafeAtomicAdd(dst[k] + 2, wt[k] * gv.z);
+            unsafeAtomicAdd(dst[k] + 3, wt[k] * gv.w);
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int w3, int C, const float* boxes,
@@ -165,5 +253,25 @@ extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, 
   long blocks = (waves + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(roi_align_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_roi_align_backward(float* dp3, float* dp4, float* dp5, int h3, int w3, int C, const float* boxes, const int32_t* count,
+                                      int R_cap, int out_size, const float* g, eod_stream_t stream) {
+  if (!dp3 || !dp4 || !dp5 || !boxes || !g) return EOD_ERR_NULL;
+  if (h3 <= 0 || w3 <= 0 || (h3 & 3) || (w3 & 3) || C % 4 != 0 || R_cap <= 0 || out_size <= 0) return EOD_ERR_BAD_DIMS;
+  if ((long)R_cap * out_size * out_size >= (1L << 30)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(g)) return EOD_ERR_ALIGN;
+  RoiArgs a{};
+  a.h[0] = h3; a.w[0] = w3; a.h[1] = h3 / 2; a.w[1] = w3 / 2; a.h[2] = h3 / 4; a.w[2] = w3 / 4;
+  a.scale[0] = 1.0f / 8; a.scale[1] = 1.0f / 16; a.scale[2] = 1.0f / 32;
+  a.C = C; a.boxes = boxes; a.count = count; a.R_cap = R_cap; a.S = out_size;
+  a.batch = 1;
+  a.div_bins = eod_make_fastdiv((unsigned)(out_size * out_size));
+  a.div_s = eod_make_fastdiv((unsigned)out_size);
+  const long waves = (long)R_cap * out_size * out_size;
+  long blocks = (waves + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(roi_align_backward_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, dp3, dp4, dp5, g);
   return eod_launch_status();
 }

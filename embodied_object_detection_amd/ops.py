@@ -308,6 +308,15 @@ def roi_align(p3, p4, p5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count:
     return out
 
 
+def roi_align_backward(dp3, dp4, dp5, h3: int, w3: int, Cc: int, boxes: torch.Tensor, count: Optional[torch.Tensor], R_cap: int, S: int,
+                       g: torch.Tensor):
+    """Adds the pooling's gradient into the pyramid levels' gradients dp3..dp5 ([h,w,C] each, one image); g [R,S,S,C]."""
+    _need_cuda(dp3, dp4, dp5, boxes, g)
+    assert g.is_contiguous() and tuple(g.shape) == (R_cap, S, S, Cc)
+    check(_lib.load().eod_roi_align_backward(dp3.data_ptr(), dp4.data_ptr(), dp5.data_ptr(), h3, w3, Cc, boxes.data_ptr(), _ptr(count),
+                                             R_cap, S, g.data_ptr(), _stream()), "eod_roi_align_backward")
+
+
 def concat_lists(lists: torch.Tensor, counts: torch.Tensor, cap_in: int, id_stride: int, batch: int, out: torch.Tensor,
                  out_count: torch.Tensor):
     """The scene-local index lists of a batch as one list of global indices b * id_stride + lists[b][k] (eod_concat_lists)."""

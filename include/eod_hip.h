@@ -186,6 +186,12 @@ int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int
                   const int32_t* count, int R_cap, int out_size, float* out /*[R,S,S,C]*/, int batch, int boxes_per_image,
                   const EodBoxRefine* refine, eod_stream_t stream);
 
+/* Backward of eod_roi_align for one image (training slices; torchvision roi_align backward under d2's ROIPooler,
+ * detic_roi_heads.py:332,265): g [R,S,S,C] = dL/d(out); the gradient is ADDED into dp3..dp5 (the pyramid levels' gradients,
+ * [h,w,C] each; zero them first or let several poolers accumulate) with fp32 atomics -- summation order is not fixed, as in torch. */
+int eod_roi_align_backward(float* dp3, float* dp4, float* dp5, int h3, int w3, int C, const float* boxes /*[R,4]*/,
+                           const int32_t* count, int R_cap, int out_size, const float* g, eod_stream_t stream);
+
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
   const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */

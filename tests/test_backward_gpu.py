@@ -420,3 +420,36 @@ def test_backbone_backward_matches_autograd(synthetic_sd):
     assert rel(g_stem.cpu(), ref_gs) <= 1e-4
     print("backbone backward: worst relative error %.2e (%s), stem-output gradient %.2e"
           % (max(worst.values()), max(worst, key=worst.get), rel(g_stem.cpu(), ref_gs)))
+
+
+def test_roi_align_backward_matches_autograd():
+    """Backward of the ROI pooler (detic_roi_heads.py:332,265): the gradient of 7x7 and 14x14 pooled features back into P3..P5 against
+    torch autograd on the oracle's ROIAlignV2 (boxes on all three levels, one partly outside the image, one tiny); two poolers
+    accumulate into the same level gradients, as the cascade stages and the mask pooler do."""
+    from embodied_object_detection_amd import ops
+    from oracle import ops as OO
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(71)
+    H, W, Cc = 512, 640, 32
+    shapes = [(H >> (3 + l), W >> (3 + l)) for l in range(3)]
+    feats = [torch.randn((1, Cc, h, w), generator=g).requires_grad_() for h, w in shapes]
+    boxes = torch.tensor([[10.0, 20.0, 60.0, 90.0], [5.5, 3.25, 330.0, 260.0], [100.0, 40.0, 638.0, 500.0], [-20.0, -10.0, 90.0, 70.0],
+                          [200.0, 100.0, 203.0, 102.5], [30.0, 30.0, 150.0, 140.0], [0.0, 0.0, 640.0, 512.0], [450.0, 380.0, 800.0, 600.0]])
+    assert len(set(OO.assign_boxes_to_levels(boxes).tolist())) == 3
+    R = boxes.shape[0]
+    Gs = {S: torch.randn((R, Cc, S, S), generator=g) for S in (7, 14)}
+    loss = sum((OO.roi_pool(feats, boxes, S) * Gs[S]).sum() for S in (7, 14))
+    loss.backward()
+    d = [torch.zeros((h, w, Cc), device=dev) for h, w in shapes]
+    count = torch.tensor([R], dtype=torch.int32, device=dev)
+    for S in (7, 14):
+        ops.roi_align_backward(d[0], d[1], d[2], shapes[0][0], shapes[0][1], Cc, boxes.to(dev), count, R, S,
+                               Gs[S].permute(0, 2, 3, 1).contiguous().to(dev))
+    for l in range(3):
+        ref = feats[l].grad[0].permute(1, 2, 0)
+        assert float((d[l].cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), l
+    # the count caps the list: ROIs beyond it contribute nothing
+    d2 = [torch.zeros_like(t) for t in d]
+    ops.roi_align_backward(d2[0], d2[1], d2[2], shapes[0][0], shapes[0][1], Cc, boxes.to(dev), torch.zeros_like(count), R, 7,
+                           Gs[7].permute(0, 2, 3, 1).contiguous().to(dev))
+    assert all(float(t.abs().max()) == 0.0 for t in d2)

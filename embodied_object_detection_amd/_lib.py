@@ -48,6 +48,17 @@ class EodBoxRefine(C.Structure):
                 ("clip", C.c_int32), ("img_w", C.c_float), ("img_h", C.c_float), ("boxes_out", C.c_void_p)]
 
 
+class EodCenterNetLossDesc(C.Structure):
+    _fields_ = [
+        ("head_out", C.c_void_p), ("head_stride", C.c_int32), ("P", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 9),
+        ("level_scale", C.c_float * 8), ("agn_heatmap", C.c_void_p), ("reg_targets", C.c_void_p), ("pos_inds", C.c_void_p),
+        ("n_pos", C.c_int32), ("hm_focal_alpha", C.c_float), ("hm_focal_beta", C.c_float), ("loss_gamma", C.c_float),
+        ("sigmoid_clamp", C.c_float), ("ignore_high_fp", C.c_float), ("pos_weight", C.c_float), ("neg_weight", C.c_float),
+        ("reg_weight", C.c_float), ("num_pos_avg", C.c_float), ("reg_norm", C.c_float), ("d_head_out", C.c_void_p),
+        ("losses", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class EodProposalDesc(C.Structure):
     _fields_ = [
         ("head_out", C.c_void_p), ("head_stride", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 6),
@@ -106,6 +117,8 @@ SIGNATURES = {
                                 C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "eod_roi_align_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]),
+    "eod_centernet_loss_workspace_bytes": (C.c_size_t, []),
+    "eod_centernet_loss": (C.c_int, [C.POINTER(EodCenterNetLossDesc), C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),

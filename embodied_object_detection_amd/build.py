@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeod_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_fp32.hip", "conv_bf16x3.hip", "elementwise.hip", "roi_align.hip", "select.hip", "heads.hip", "memory.hip", "memory_read.hip", "memory_backward.hip"]
+SOURCES = ["conv_igemm.hip", "conv_fp32.hip", "conv_bf16x3.hip", "elementwise.hip", "roi_align.hip", "select.hip", "heads.hip", "memory.hip", "memory_read.hip", "memory_backward.hip", "train_losses.hip"]
 ARCH = "gfx950"
 
 

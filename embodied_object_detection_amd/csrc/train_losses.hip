@@ -1,0 +1,167 @@
+// Training losses of the proposal generator with their gradients (training slices): CenterNet.losses for the
+// recurrent configuration -- ONLY_PROPOSAL + WITH_AGN_HM, not_norm_reg -- i.e. the class-agnostic heatmap focal loss
+// (binary_heatmap_focal_loss, centernet/modeling/layers/heatmap_focal_loss.py:52-84) and the GIoU regression loss (IOULoss 'giou',
+// layers/iou_loss.py:10-64) as centernet/modeling/dense_heads/centernet.py:241-318 combines them, evaluated on the head's raw
+// output rows [P, stride] (col 0: agnostic logit, cols 1..4: bbox_pred before the level's Scale and the ReLU,
+// centernet_head.py:141-161).  Two launches: a dense pass over the P positions (negative term, regression term, their gradients;
+// per-workgroup partial sums in double) and one workgroup over the positive locations that also adds the partials in a fixed order.
+// Elementwise + reductions: HBM-bound, P x (stride + 5) floats read, P x stride written.
+#include "eod_common.h"
+#include "../../include/eod_hip.h"
+
+namespace {
+
+struct CnLossArgs {
+  const float* head;
+  int stride;
+  const float* heat;    // [P] agnostic heatmap target (flattened_hms.max(dim=1))
+  const float* reg_t;   // [P,4] (l, t, r, b) targets, rows with max < 0: no regression target
+  const int* pos;       // [n_pos]
+  int n_pos, P, levels;
+  int lv_off[9];
+  float lv_scale[8];
+  float alpha, beta, gamma, clampv, ignore_fp;
+  float c_pos, c_neg, c_reg;   // pos_weight / num_pos_avg, neg_weight / num_pos_avg, reg_weight / reg_norm
+  float* d_head;        // [P, stride]
+  double* partial;      // [blocks][2]
+  float* losses;        // [3]: loc, agn_pos, agn_neg
+};
+
+__device__ __forceinline__ float half_on_tie(float a, float b, bool take_less) {
+  // d min(a, b) / da (take_less) or d max(a, b) / da: 1 where a wins, 1/2 on a tie (torch.minimum / maximum backward), else 0
+  if (a == b) return 0.5f;
+  return (take_less ? a < b : a > b) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void centernet_loss_dense_kernel(CnLossArgs a) {
+  __shared__ double red[2][4];
+  double neg_sum = 0.0, loc_sum = 0.0;
+  const float an = a.alpha >= 0.f ? 1.f - a.alpha : 1.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.P; i += gridDim.x * blockDim.x) {
+    const float* h = a.head + (size_t)i * a.stride;
+    float* d = a.d_head + (size_t)i * a.stride;
+    // ---- negative term of the agnostic focal loss
+    const float s = eod_sigmoid_precise(h[0]);
+    const float p = fminf(fmaxf(s, a.clampv), 1.f - a.clampv);
+    const bool inside = s >= a.clampv && s <= 1.f - a.clampv;
+    const float nw = powf(1.f - a.heat[i], a.beta);
+    const bool keep = !(a.ignore_fp > 0.f) || p < a.ignore_fp;
+    float gz = 0.f;
+    if (keep) {
+      const float l1p = logf(1.f - p), pg = powf(p, a.gamma);
+      neg_sum += (double)(l1p * pg * nw);
+      const float dp = (-pg / (1.f - p) + a.gamma * powf(p, a.gamma - 1.f) * l1p) * nw;
+      if (inside) gz = -an * a.c_neg * dp * s * (1.f - s);
+    }
+    d[0] = gz;
+    for (int c = 5; c < a.stride; ++c) d[c] = 0.f;
+    // ---- GIoU regression term
+    const float tl = a.reg_t[i * 4 + 0], tt = a.reg_t[i * 4 + 1], tr = a.reg_t[i * 4 + 2], tb = a.reg_t[i * 4 + 3];
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fmaxf(fmaxf(tl, tt), fmaxf(tr, tb)) >= 0.f) {
+      int l = 0;
+      while (l + 1 < a.levels && i >= a.lv_off[l + 1]) ++l;
+      const float sc = a.lv_scale[l];
+      const float r0 = h[1] * sc, r1 = h[2] * sc, r2 = h[3] * sc, r3 = h[4] * sc;
+      const float pl = fmaxf(r0, 0.f), pt = fmaxf(r1, 0.f), pr = fmaxf(r2, 0.f), pb = fmaxf(r3, 0.f);
+      const float t_area = (tl + tr) * (tt + tb), p_area = (pl + pr) * (pt + pb);
+      const float wi = fminf(pl, tl) + fminf(pr, tr), hi = fminf(pb, tb) + fminf(pt, tt);
+      const float gw = fmaxf(pl, tl) + fmaxf(pr, tr), gh = fmaxf(pb, tb) + fmaxf(pt, tt);
+      const float ac = gw * gh, ai = wi * hi, au = t_area + p_area - ai;
+      const float iou = (ai + 1.f) / (au + 1.f);
+      const float giou = iou - (ac - au) / ac;
+      loc_sum += (double)(1.f - giou);
+      // d giou / d x for x in (pl, pt, pr, pb): through p_area, ai (wi or hi) and ac (gw or gh)
+      const float dpa[4] = {pt + pb, pl + pr, pt + pb, pl + pr};
+      const float dai[4] = {half_on_tie(pl, tl, true) * hi, half_on_tie(pt, tt, true) * wi, half_on_tie(pr, tr, true) * hi,
+                            half_on_tie(pb, tb, true) * wi};
+      const float dac[4] = {half_on_tie(pl, tl, false) * gh, half_on_tie(pt, tt, false) * gw, half_on_tie(pr, tr, false) * gh,
+                            half_on_tie(pb, tb, false) * gw};
+      const float raw[4] = {r0, r1, r2, r3};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dau = dpa[k] - dai[k];
+        const float diou = (dai[k] * (au + 1.f) - (ai + 1.f) * dau) / ((au + 1.f) * (au + 1.f));
+        const float dfrac = (dau * ac - au * dac[k]) / (ac * ac);       // d (au / ac)
+        const float dg = diou + dfrac;
+        g4[k] = raw[k] > 0.f ? -a.c_reg * dg * sc : 0.f;
+      }
+    }
+    d[1] = g4[0]; d[2] = g4[1]; d[3] = g4[2]; d[4] = g4[3];
+  }
+  // workgroup sums, waves added in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) {
+    neg_sum += __shfl_xor(neg_sum, off, 64);
+    loc_sum += __shfl_xor(loc_sum, off, 64);
+  }
+  if (lane == 0) { red[0][wv] = neg_sum; red[1][wv] = loc_sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.partial[blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    a.partial[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void centernet_loss_pos_kernel(CnLossArgs a, int dense_blocks) {
+  __shared__ double red[4];
+  double pos_sum = 0.0;
+  const float ap = a.alpha >= 0.f ? a.alpha : 1.f;
+  for (int j = threadIdx.x; j < a.n_pos; j += blockDim.x) {
+    const int i = a.pos[j];
+    if (i < 0 || i >= a.P) continue;
+    const float s = eod_sigmoid_precise(a.head[(size_t)i * a.stride]);
+    const float p = fminf(fmaxf(s, a.clampv), 1.f - a.clampv);
+    const bool inside = s >= a.clampv && s <= 1.f - a.clampv;
+    const float lp = logf(p), q = powf(1.f - p, a.gamma);
+    pos_sum += (double)(lp * q);
+    if (inside) {
+      const float dp = q / p - a.gamma * lp * powf(1.f - p, a.gamma - 1.f);
+      unsafeAtomicAdd(a.d_head + (size_t)i * a.stride, -ap * a.c_pos * dp * s * (1.f - s));     // a location may be listed twice
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) pos_sum += __shfl_xor(pos_sum, off, 64);
+  if (lane == 0) red[wv] = pos_sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double neg = 0.0, loc = 0.0;
+    for (int b = 0; b < dense_blocks; ++b) { neg += a.partial[b * 2]; loc += a.partial[b * 2 + 1]; }
+    const double pos = red[0] + red[1] + red[2] + red[3];
+    const float an = a.alpha >= 0.f ? 1.f - a.alpha : 1.f;
+    a.losses[0] = (float)((double)a.c_reg * loc);
+    a.losses[1] = (float)(-(double)(ap * a.c_pos) * pos);
+    a.losses[2] = (float)(-(double)(an * a.c_neg) * neg);
+  }
+}
+
+constexpr int kDenseBlocksMax = 512;
+
+}  // namespace
+
+extern "C" size_t eod_centernet_loss_workspace_bytes(void) { return (size_t)kDenseBlocksMax * 2 * sizeof(double); }
+
+extern "C" int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t stream) {
+  if (!d || !d->head_out || !d->agn_heatmap || !d->reg_targets || !d->d_head_out || !d->losses || !d->workspace) return EOD_ERR_NULL;
+  if (d->n_pos > 0 && !d->pos_inds) return EOD_ERR_NULL;
+  if (d->P <= 0 || d->head_stride < 5 || d->levels < 1 || d->levels > 8 || d->n_pos < 0) return EOD_ERR_BAD_DIMS;
+  if (d->level_off[0] != 0 || d->level_off[d->levels] != d->P) return EOD_ERR_BAD_DIMS;
+  for (int l = 0; l < d->levels; ++l)
+    if (d->level_off[l + 1] < d->level_off[l]) return EOD_ERR_BAD_DIMS;
+  if (!(d->num_pos_avg >= 1.f) || !(d->reg_norm >= 1.f) || !(d->sigmoid_clamp > 0.f && d->sigmoid_clamp < 0.5f)) return EOD_ERR_BAD_DIMS;
+  if (d->workspace_bytes < eod_centernet_loss_workspace_bytes()) return EOD_ERR_CAPACITY;
+  CnLossArgs a{};
+  a.head = d->head_out; a.stride = d->head_stride; a.heat = d->agn_heatmap; a.reg_t = d->reg_targets;
+  a.pos = d->pos_inds; a.n_pos = d->n_pos; a.P = d->P; a.levels = d->levels;
+  for (int l = 0; l <= d->levels; ++l) a.lv_off[l] = d->level_off[l];
+  for (int l = 0; l < d->levels; ++l) a.lv_scale[l] = d->level_scale[l];
+  a.alpha = d->hm_focal_alpha; a.beta = d->hm_focal_beta; a.gamma = d->loss_gamma; a.clampv = d->sigmoid_clamp;
+  a.ignore_fp = d->ignore_high_fp;
+  a.c_pos = d->pos_weight / d->num_pos_avg; a.c_neg = d->neg_weight / d->num_pos_avg; a.c_reg = d->reg_weight / d->reg_norm;
+  a.d_head = d->d_head_out; a.partial = static_cast<double*>(d->workspace); a.losses = d->losses;
+  int blocks = (d->P + 255) / 256;
+  if (blocks > kDenseBlocksMax) blocks = kDenseBlocksMax;
+  hipLaunchKernelGGL(centernet_loss_dense_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(centernet_loss_pos_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, blocks);
+  return eod_launch_status();
+}

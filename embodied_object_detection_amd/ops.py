@@ -623,6 +623,48 @@ class ConvBackward:
         return dict(dx=dx, dw=dw, db=db)
 
 
+class CenterNetLoss:
+    """`CenterNet.losses` of the recurrent configuration on the device with its gradient (`eod_centernet_loss`; centernet.py:241-318:
+    agnostic heatmap focal loss + GIoU regression loss).  `__call__(head_out [P, stride], agn_heatmap [P], reg_targets [P,4],
+    pos_inds int32 [N], num_pos_avg, reg_norm)` -> (losses [3] = loc, agn_pos, agn_neg on the device, dL/d(head_out)); the two norms are
+    the all-reduced counts / world size the reference divides by (the caller reduces them over the ranks)."""
+
+    def __init__(self, level_off: Sequence[int], level_scale: Sequence[float], device, head_stride: int = 8, alpha: float = 0.25,
+                 beta: float = 4.0, gamma: float = 2.0, sigmoid_clamp: float = 1e-4, ignore_high_fp: float = 0.85,
+                 pos_weight: float = 0.5, neg_weight: float = 0.5, reg_weight: float = 1.0):
+        self.lib = _lib.load()
+        d = _lib.EodCenterNetLossDesc()
+        L = len(level_scale)
+        assert len(level_off) == L + 1 and L <= 8
+        d.head_stride, d.P, d.levels = head_stride, level_off[-1], L
+        for i, v in enumerate(level_off):
+            d.level_off[i] = v
+        for i, v in enumerate(level_scale):
+            d.level_scale[i] = float(v)
+        d.hm_focal_alpha, d.hm_focal_beta, d.loss_gamma, d.sigmoid_clamp, d.ignore_high_fp = alpha, beta, gamma, sigmoid_clamp, ignore_high_fp
+        d.pos_weight, d.neg_weight, d.reg_weight = pos_weight, neg_weight, reg_weight
+        nbytes = self.lib.eod_centernet_loss_workspace_bytes()
+        self.ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.losses = torch.zeros((3,), dtype=torch.float32, device=device)
+        d.losses = self.losses.data_ptr()
+        self.desc = d
+
+    def __call__(self, head_out: torch.Tensor, agn_heatmap: torch.Tensor, reg_targets: torch.Tensor, pos_inds: torch.Tensor,
+                 num_pos_avg: float, reg_norm: float, out: Optional[torch.Tensor] = None):
+        _need_cuda(head_out, agn_heatmap, reg_targets, pos_inds, out)
+        d = self.desc
+        assert tuple(head_out.shape) == (d.P, d.head_stride) and head_out.is_contiguous() and pos_inds.dtype == torch.int32
+        assert tuple(reg_targets.shape) == (d.P, 4) and reg_targets.is_contiguous() and agn_heatmap.numel() == d.P
+        if out is None:
+            out = torch.empty_like(head_out)
+        d.head_out, d.agn_heatmap, d.reg_targets = head_out.data_ptr(), agn_heatmap.data_ptr(), reg_targets.data_ptr()
+        d.pos_inds, d.n_pos = (pos_inds.data_ptr() if pos_inds.numel() else None), pos_inds.numel()
+        d.num_pos_avg, d.reg_norm, d.d_head_out = float(num_pos_avg), float(reg_norm), out.data_ptr()
+        check(self.lib.eod_centernet_loss(C.byref(d), _stream()), "eod_centernet_loss")
+        return self.losses, out
+
+
 class AdamW:
     """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
     tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).

@@ -192,6 +192,33 @@ int eod_roi_align(const float* p3, const float* p4, const float* p5, int h3, int
 int eod_roi_align_backward(float* dp3, float* dp4, float* dp5, int h3, int w3, int C, const float* boxes /*[R,4]*/,
                            const int32_t* count, int R_cap, int out_size, const float* g, eod_stream_t stream);
 
+/* Training losses of the proposal generator with their gradients (training slices): CenterNet.losses for ONLY_PROPOSAL +
+ * WITH_AGN_HM + NOT_NORM_REG (centernet/modeling/dense_heads/centernet.py:241-318) = binary_heatmap_focal_loss
+ * (layers/heatmap_focal_loss.py:52-84) on the agnostic logits + IOULoss 'giou' (layers/iou_loss.py:10-64) on
+ * relu(scale_l * bbox_pred) (centernet_head.py:141-161).  The targets (centernet.py:137-239) are inputs. */
+typedef struct EodCenterNetLossDesc {
+  const float* head_out;      /* [P, head_stride]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale / relu) -- the rows eod_centernet_proposals reads */
+  int32_t head_stride;        /* >= 5 */
+  int32_t P;
+  int32_t levels;             /* <= 8 */
+  int32_t level_off[9];       /* row offsets of the levels, level_off[levels] == P */
+  float level_scale[8];       /* the levels' Scale parameters */
+  const float* agn_heatmap;   /* [P] flattened_hms.max(dim=1) */
+  const float* reg_targets;   /* [P,4] (left, top, right, bottom); rows whose max is < 0 carry no target (-INF in the reference) */
+  const int32_t* pos_inds;    /* [n_pos] rows of the positive locations (a row may appear more than once) */
+  int32_t n_pos;
+  float hm_focal_alpha, hm_focal_beta, loss_gamma, sigmoid_clamp, ignore_high_fp;    /* MODEL.CENTERNET.* (0.25, 4, 2, 1e-4, 0.85) */
+  float pos_weight, neg_weight, reg_weight;                                          /* 0.5, 0.5, 1 in the recurrent yaml */
+  float num_pos_avg;          /* max(all-reduced n_pos / world size, 1)  (centernet.py:259-265) */
+  float reg_norm;             /* max(all-reduced number of regression rows / world size, 1)  (centernet.py:288-293) */
+  float* d_head_out;          /* [P, head_stride] dL/d(head_out) of loss_centernet_loc + _agn_pos + _agn_neg; every column written */
+  float* losses;              /* [3]: loss_centernet_loc, loss_centernet_agn_pos, loss_centernet_agn_neg */
+  void* workspace;
+  size_t workspace_bytes;     /* >= eod_centernet_loss_workspace_bytes() */
+} EodCenterNetLossDesc;
+size_t eod_centernet_loss_workspace_bytes(void);
+int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t stream);
+
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
   const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */

@@ -1,0 +1,67 @@
+"""CPU restatement of the proposal generator's training losses  --  TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline).
+
+CenterNet `losses()` for the recurrent configuration (ONLY_PROPOSAL + WITH_AGN_HM: class-agnostic heatmap focal loss + GIoU
+regression loss; `Detic/third_party/CenterNet2/centernet/modeling/dense_heads/centernet.py:241-318`), with the two functions it calls:
+`binary_heatmap_focal_loss` (`.../layers/heatmap_focal_loss.py:52-84`) and `IOULoss.forward` (`.../layers/iou_loss.py:10-64`).
+Plain differentiable torch on CPU tensors; pinned by `tests/golden/centernet_loss.npz` (the reference's own functions run on seeded
+inputs, `tests/golden/gen_golden_losses.py`).  Single process: `num_pos_avg` / `reg_norm` are what `reduce_sum(...) / num_gpus`
+gives on one rank (centernet.py:259-265, 290-293).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+
+def binary_heatmap_focal_loss(logits: torch.Tensor, targets: torch.Tensor, pos_inds: torch.Tensor, alpha: float = -1.0,
+                              beta: float = 4.0, gamma: float = 2.0, sigmoid_clamp: float = 1e-4, ignore_high_fp: float = -1.0):
+    """heatmap_focal_loss.py:52-84 (without the in-place sigmoid): logits, targets [M]; pos_inds [N] -> (pos_loss, neg_loss)."""
+    pred = torch.clamp(torch.sigmoid(logits), min=sigmoid_clamp, max=1 - sigmoid_clamp)
+    neg_weights = torch.pow(1 - targets, beta)
+    pos_pred = pred[pos_inds]
+    pos_loss = torch.log(pos_pred) * torch.pow(1 - pos_pred, gamma)
+    neg_loss = torch.log(1 - pred) * torch.pow(pred, gamma) * neg_weights
+    if ignore_high_fp > 0:
+        neg_loss = (pred < ignore_high_fp).float() * neg_loss
+    pos_loss = -pos_loss.sum()
+    neg_loss = -neg_loss.sum()
+    if alpha >= 0:
+        pos_loss = alpha * pos_loss
+        neg_loss = (1 - alpha) * neg_loss
+    return pos_loss, neg_loss
+
+
+def giou_ltrb_loss(pred: torch.Tensor, target: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """iou_loss.py:10-64 with loc_loss_type 'giou', reduction 'sum': pred / target [K,4] distances (left, top, right, bottom)."""
+    pl, pt, pr, pb = pred.unbind(1)
+    tl, tt, tr, tb = target.unbind(1)
+    t_area = (tl + tr) * (tt + tb)
+    p_area = (pl + pr) * (pt + pb)
+    w_i = torch.min(pl, tl) + torch.min(pr, tr)
+    h_i = torch.min(pb, tb) + torch.min(pt, tt)
+    g_w = torch.max(pl, tl) + torch.max(pr, tr)
+    g_h = torch.max(pb, tb) + torch.max(pt, tt)
+    ac = g_w * g_h
+    a_i = w_i * h_i
+    a_u = t_area + p_area - a_i
+    ious = (a_i + 1.0) / (a_u + 1.0)
+    gious = ious - (ac - a_u) / ac
+    return ((1 - gious) * weight).sum()
+
+
+def centernet_proposal_losses(agn_logits: torch.Tensor, reg_pred: torch.Tensor, agn_heatmap: torch.Tensor, reg_targets: torch.Tensor,
+                              pos_inds: torch.Tensor, *, alpha: float = 0.25, beta: float = 4.0, gamma: float = 2.0,
+                              sigmoid_clamp: float = 1e-4, ignore_high_fp: float = 0.85, pos_weight: float = 0.5,
+                              neg_weight: float = 0.5, reg_weight: float = 1.0) -> Dict[str, torch.Tensor]:
+    """centernet.py:241-318 for only_proposal + with_agn_hm + not_norm_reg on one rank.  agn_logits [M], reg_pred [M,4] (after
+    scale + ReLU), agn_heatmap [M] (= flattened_hms.max(dim=1)), reg_targets [M,4] (-INF rows where no object), pos_inds [N]."""
+    num_pos_avg = max(float(pos_inds.numel()), 1.0)
+    reg_inds = torch.nonzero(reg_targets.max(dim=1)[0] >= 0).squeeze(1)
+    weight = torch.ones((reg_inds.numel(),), dtype=torch.float32)                 # not_norm_reg (centernet.py:288-289)
+    reg_norm = max(float(weight.sum()), 1.0)
+    loc = reg_weight * giou_ltrb_loss(reg_pred[reg_inds], reg_targets[reg_inds], weight) / reg_norm
+    pos, neg = binary_heatmap_focal_loss(agn_logits.float(), agn_heatmap.float(), pos_inds, alpha, beta, gamma, sigmoid_clamp,
+                                         ignore_high_fp)
+    return {"loss_centernet_loc": loc, "loss_centernet_agn_pos": pos_weight * pos / num_pos_avg,
+            "loss_centernet_agn_neg": neg_weight * neg / num_pos_avg}

@@ -453,3 +453,85 @@ def test_roi_align_backward_matches_autograd():
     ops.roi_align_backward(d2[0], d2[1], d2[2], shapes[0][0], shapes[0][1], Cc, boxes.to(dev), torch.zeros_like(count), R, 7,
                            Gs[7].permute(0, 2, 3, 1).contiguous().to(dev))
     assert all(float(t.abs().max()) == 0.0 for t in d2)
+
+
+def _raw_from_reg(reg_pred, scales, off, g):
+    """Head rows whose relu(scale_l * raw) is `reg_pred`: positives divided by the level's scale, zeros from negative raw values."""
+    raw = torch.empty_like(reg_pred)
+    for l, sc in enumerate(scales):
+        r = reg_pred[off[l]:off[l + 1]]
+        neg = -(torch.rand(r.shape, generator=g) + 0.1)
+        raw[off[l]:off[l + 1]] = torch.where(r > 0, r / sc, neg)
+    return raw
+
+
+def test_centernet_loss_matches_the_reference_functions():
+    """`eod_centernet_loss` (CenterNet.losses of the recurrent configuration, centernet.py:241-318) against the fixture made by the
+    reference's OWN binary_heatmap_focal_loss_jit / IOULoss (tests/golden/gen_golden_losses.py): the three losses and the gradient with
+    respect to the head's raw output rows (agnostic logit; bbox_pred before the level's Scale and the ReLU).  Then a second, larger
+    case against the oracle's restatement with autograd through relu(scale * raw)."""
+    import numpy as np
+    from embodied_object_detection_amd import ops
+    from oracle import losses as OL
+    from test_losses_golden import load_fixture
+    dev = torch.device("cuda:0")
+    z, t, cfg = load_fixture()
+    shapes = [tuple(x) for x in z["shapes"].tolist()]
+    off = [0]
+    for h, w in shapes:
+        off.append(off[-1] + h * w)
+    scales = [1.0, 0.8, 1.3, 2.0, 0.5]
+    g = torch.Generator().manual_seed(5)
+
+    def run(logits, reg_pred, heat, reg_targets, pos, off, scales):
+        M = logits.numel()
+        raw = _raw_from_reg(reg_pred, scales, off, g)
+        # what relu(scale * raw) really is in fp32 (the division above is not exactly undone): the reference values are taken on it
+        reg_eff = torch.cat([torch.relu(raw[off[l]:off[l + 1]] * scales[l]) for l in range(len(scales))])
+        head = torch.zeros((M, 8))
+        head[:, 0] = logits
+        head[:, 1:5] = raw
+        head[:, 5:] = torch.randn((M, 3), generator=g)
+        n_reg = int((reg_targets.max(dim=1)[0] >= 0).sum())
+        loss_fn = ops.CenterNetLoss(off, scales, dev, head_stride=8, **{k: cfg[k] for k in ("alpha", "beta", "gamma", "sigmoid_clamp",
+                                                                                             "ignore_high_fp", "pos_weight", "neg_weight",
+                                                                                             "reg_weight")})
+        losses, dh = loss_fn(head.to(dev), heat.to(dev), reg_targets.contiguous().to(dev), pos.int().to(dev), max(float(pos.numel()), 1.0),
+                             max(float(n_reg), 1.0))
+        return losses.cpu(), dh.cpu(), raw, reg_eff
+
+    # ---- the reference's numbers
+    losses, dh, raw, reg_eff = run(t("logits"), t("reg_pred"), t("heat"), t("reg_targets"), t("pos_inds"), off, scales)
+    for i, k in enumerate(("loss_loc", "loss_agn_pos", "loss_agn_neg")):
+        assert abs(float(losses[i]) - float(z[k])) <= 2e-5 * abs(float(z[k])), (k, float(losses[i]), float(z[k]))
+    gl = t("grad_logits")
+    assert float((dh[:, 0] - gl).abs().max()) <= 2e-5 * float(gl.abs().max())
+    sc_rows = torch.cat([torch.full((off[l + 1] - off[l], 1), scales[l]) for l in range(5)])
+    ref_raw_grad = t("grad_reg") * sc_rows * (raw > 0)
+    assert float((dh[:, 1:5] - ref_raw_grad).abs().max()) <= 1e-4 * float(ref_raw_grad.abs().max())
+    assert float(dh[:, 5:].abs().max()) == 0.0
+    # ---- a pyramid of the full-size frame (640x640: 8 525 positions) against the oracle with autograd through scale + ReLU
+    shapes2 = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    off2 = [0]
+    for h, w in shapes2:
+        off2.append(off2[-1] + h * w)
+    M = off2[-1]
+    logits = torch.randn((M,), generator=g) * 3
+    heat = torch.rand((M,), generator=g) ** 8
+    pos = torch.randperm(M, generator=g)[:150]
+    heat[pos] = 1.0
+    reg_pred = torch.rand((M, 4), generator=g) * 60
+    reg_pred[torch.rand((M, 4), generator=g) < 0.05] = 0.0
+    reg_targets = torch.full((M, 4), -1e8)
+    rows = torch.randperm(M, generator=g)[:900]
+    reg_targets[rows] = torch.rand((900, 4), generator=g) * 70 + 0.5
+    losses, dh, raw, _ = run(logits, reg_pred, heat, reg_targets, pos, off2, scales)
+    zl = logits.clone().requires_grad_()
+    rw = raw.clone().requires_grad_()
+    reg = torch.cat([torch.relu(rw[off2[l]:off2[l + 1]] * scales[l]) for l in range(5)])
+    ref = OL.centernet_proposal_losses(zl, reg, heat, reg_targets, pos, **cfg)
+    sum(ref.values()).backward()
+    for i, k in enumerate(("loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg")):
+        assert abs(float(losses[i]) - ref[k].item()) <= 2e-5 * abs(ref[k].item()), k
+    assert float((dh[:, 0] - zl.grad).abs().max()) <= 2e-5 * float(zl.grad.abs().max())
+    assert float((dh[:, 1:5] - rw.grad).abs().max()) <= 1e-4 * float(rw.grad.abs().max())

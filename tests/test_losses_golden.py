@@ -1,0 +1,33 @@
+"""The oracle's restatement of the proposal generator's training losses against the reference's own functions
+(`tests/golden/centernet_loss.npz`, made by `tests/golden/gen_golden_losses.py` from heatmap_focal_loss.py / iou_loss.py as
+`CenterNet.losses` calls them, centernet.py:241-318).  CPU."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import losses as OL
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "centernet_loss.npz")
+
+
+def load_fixture():
+    z = np.load(GOLD)
+    t = lambda k: torch.from_numpy(z[k])
+    cfg = {k[4:]: float(z[k]) for k in z.files if k.startswith("cfg_")}
+    return z, t, cfg
+
+
+def test_oracle_losses_match_the_reference_functions():
+    z, t, cfg = load_fixture()
+    logits = t("logits").clone().requires_grad_()
+    reg = t("reg_pred").clone().requires_grad_()
+    out = OL.centernet_proposal_losses(logits, reg, t("heat"), t("reg_targets"), t("pos_inds"), **cfg)
+    for k, name in (("loss_loc", "loss_centernet_loc"), ("loss_agn_pos", "loss_centernet_agn_pos"), ("loss_agn_neg", "loss_centernet_agn_neg")):
+        assert abs(out[name].item() - float(z[k])) <= 1e-6 * abs(float(z[k])), k
+    sum(out.values()).backward()
+    assert float((logits.grad - t("grad_logits")).abs().max()) <= 1e-7
+    assert float((reg.grad - t("grad_reg")).abs().max()) <= 1e-7
+    # the fixture exercises what it claims to: clamped logits (zero gradient), a duplicated positive, ReLU zeros, ignored positions
+    assert int((t("grad_logits") == 0).sum()) > 10 and len(set(z["pos_inds"].tolist())) < len(z["pos_inds"])
+    assert int((t("reg_targets").max(dim=1)[0] >= 0).sum()) == 60

@@ -119,6 +119,10 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_void_p]),
     "eod_centernet_loss_workspace_bytes": (C.c_size_t, []),
     "eod_centernet_loss": (C.c_int, [C.POINTER(EodCenterNetLossDesc), C.c_void_p]),
+    "eod_fast_rcnn_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "eod_fast_rcnn_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),

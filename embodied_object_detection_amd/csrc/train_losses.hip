@@ -137,7 +137,104 @@ __global__ __launch_bounds__(256) void centernet_loss_pos_kernel(CnLossArgs a, i
 
 constexpr int kDenseBlocksMax = 512;
 
+// DeticFastRCNNOutputLayers.losses for USE_SIGMOID_CE + class-agnostic regression (detic_fast_rcnn.py:157-197): one workgroup per
+// ROI row -- sigmoid cross entropy over the C foreground columns against the one-hot of gt_classes (the background column takes no
+// part, :205-207), optional per-class weight (:213-225), and for foreground rows the smooth-L1 distance between the predicted deltas
+// and Box2BoxTransform.get_deltas(proposal, gt) (:282-291); both normalised by the number of rows B (:232, :303).  Row sums in
+// double, added in row order by the second launch.
+struct BoxLossArgs {
+  const float* scores; int ld;     // [B, ld], columns 0..C
+  const float* deltas;             // [B,4]
+  const float* prop; const float* gtb;   // [B,4]
+  const int* gt;                   // [B]
+  const float* cw;                 // [C] or null
+  int B, C;
+  float wx, wy, ww, wh, beta;
+  float* d_scores; float* d_deltas;
+  double* partial;                 // [B][2]
+  float* losses;                   // [2]: loss_cls, loss_box_reg
+};
+
+__global__ __launch_bounds__(256) void fast_rcnn_loss_rows_kernel(BoxLossArgs a) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const int g = a.gt[b];
+  const float inv_b = 1.f / (float)a.B;
+  const float* z = a.scores + (size_t)b * a.ld;
+  float* dz = a.d_scores + (size_t)b * a.ld;
+  double sum = 0.0;
+  for (int c = threadIdx.x; c < a.ld; c += blockDim.x) {
+    if (c >= a.C) { dz[c] = 0.f; continue; }
+    const float w = a.cw ? a.cw[c] : 1.f;
+    const float y = c == g ? 1.f : 0.f;
+    const float v = z[c];
+    // binary_cross_entropy_with_logits: (1 - y) v + log1p(exp(-|v|)) + max(-v, 0)
+    sum += (double)(w * ((1.f - y) * v + log1pf(expf(-fabsf(v))) + fmaxf(-v, 0.f)));
+    dz[c] = w * (eod_sigmoid_precise(v) - y) * inv_b;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) red[wv] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.partial[b * 2] = red[0] + red[1] + red[2] + red[3];
+    double reg = 0.0;
+    float gd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g >= 0 && g < a.C) {
+      const float* s = a.prop + b * 4;
+      const float* t = a.gtb + b * 4;
+      const float sw = s[2] - s[0], sh = s[3] - s[1], sx = s[0] + 0.5f * sw, sy = s[1] + 0.5f * sh;
+      const float tw = t[2] - t[0], th = t[3] - t[1], tx = t[0] + 0.5f * tw, ty = t[1] + 0.5f * th;
+      const float tgt[4] = {a.wx * (tx - sx) / sw, a.wy * (ty - sy) / sh, a.ww * logf(tw / sw), a.wh * logf(th / sh)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = a.deltas[b * 4 + k] - tgt[k], ae = fabsf(e);
+        const float sgn = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+        if (a.beta < 1e-5f) {
+          reg += (double)ae;
+          gd[k] = sgn * inv_b;
+        } else if (ae < a.beta) {
+          reg += (double)(0.5f * e * e / a.beta);
+          gd[k] = e / a.beta * inv_b;
+        } else {
+          reg += (double)(ae - 0.5f * a.beta);
+          gd[k] = sgn * inv_b;
+        }
+      }
+    }
+    a.partial[b * 2 + 1] = reg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.d_deltas[b * 4 + k] = gd[k];
+  }
+}
+
+__global__ __launch_bounds__(64) void fast_rcnn_loss_sum_kernel(BoxLossArgs a) {
+  if (threadIdx.x != 0) return;
+  double cls = 0.0, reg = 0.0;
+  for (int b = 0; b < a.B; ++b) { cls += a.partial[b * 2]; reg += a.partial[b * 2 + 1]; }
+  a.losses[0] = (float)(cls / (double)a.B);
+  a.losses[1] = (float)(reg / (double)a.B);
+}
+
 }  // namespace
+
+extern "C" size_t eod_fast_rcnn_loss_workspace_bytes(int B) { return B > 0 ? (size_t)B * 2 * sizeof(double) : 0; }
+
+extern "C" int eod_fast_rcnn_loss(const float* scores, int ld, const float* deltas, const float* proposal_boxes, const float* gt_boxes,
+                                  const int32_t* gt_classes, const float* class_weight, int B, int num_classes, float wx, float wy,
+                                  float ww, float wh, float smooth_l1_beta, float* d_scores, float* d_deltas, float* losses,
+                                  void* workspace, size_t workspace_bytes, eod_stream_t stream) {
+  if (!scores || !deltas || !proposal_boxes || !gt_boxes || !gt_classes || !d_scores || !d_deltas || !losses || !workspace) return EOD_ERR_NULL;
+  if (B <= 0 || num_classes <= 0 || ld < num_classes + 1 || !(smooth_l1_beta >= 0.f)) return EOD_ERR_BAD_DIMS;
+  if (workspace_bytes < eod_fast_rcnn_loss_workspace_bytes(B)) return EOD_ERR_CAPACITY;
+  BoxLossArgs a{};
+  a.scores = scores; a.ld = ld; a.deltas = deltas; a.prop = proposal_boxes; a.gtb = gt_boxes; a.gt = gt_classes; a.cw = class_weight;
+  a.B = B; a.C = num_classes; a.wx = wx; a.wy = wy; a.ww = ww; a.wh = wh; a.beta = smooth_l1_beta;
+  a.d_scores = d_scores; a.d_deltas = d_deltas; a.partial = static_cast<double*>(workspace); a.losses = losses;
+  hipLaunchKernelGGL(fast_rcnn_loss_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(fast_rcnn_loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
 
 extern "C" size_t eod_centernet_loss_workspace_bytes(void) { return (size_t)kDenseBlocksMax * 2 * sizeof(double); }
 

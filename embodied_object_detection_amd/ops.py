@@ -665,6 +665,26 @@ class CenterNetLoss:
         return self.losses, out
 
 
+def fast_rcnn_loss(scores: torch.Tensor, deltas: torch.Tensor, proposal_boxes: torch.Tensor, gt_boxes: torch.Tensor,
+                   gt_classes: torch.Tensor, num_classes: int, box_weights: Sequence[float], class_weight: Optional[torch.Tensor] = None,
+                   smooth_l1_beta: float = 0.0):
+    """One cascade stage's `DeticFastRCNNOutputLayers.losses` (sigmoid CE + class-agnostic smooth-L1, detic_fast_rcnn.py:157-303) on the
+    device -> (losses [2] = loss_cls, loss_box_reg; dL/d(scores) [B, ld]; dL/d(deltas) [B,4]).  gt_classes int32, background = C."""
+    _need_cuda(scores, deltas, proposal_boxes, gt_boxes, gt_classes, class_weight)
+    B, ld = scores.shape
+    assert scores.is_contiguous() and tuple(deltas.shape) == (B, 4) and deltas.is_contiguous() and gt_classes.dtype == torch.int32
+    lib = _lib.load()
+    nbytes = lib.eod_fast_rcnn_loss_workspace_bytes(B)
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=scores.device)
+    losses = torch.empty((2,), dtype=torch.float32, device=scores.device)
+    ds, dd = torch.empty_like(scores), torch.empty_like(deltas)
+    wx, wy, ww, wh = box_weights
+    check(lib.eod_fast_rcnn_loss(scores.data_ptr(), ld, deltas.data_ptr(), proposal_boxes.data_ptr(), gt_boxes.data_ptr(),
+                                 gt_classes.data_ptr(), _ptr(class_weight), B, num_classes, wx, wy, ww, wh, smooth_l1_beta, ds.data_ptr(),
+                                 dd.data_ptr(), losses.data_ptr(), ws.data_ptr(), nbytes, _stream()), "eod_fast_rcnn_loss")
+    return losses, ds, dd
+
+
 class AdamW:
     """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
     tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).

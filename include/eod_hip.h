@@ -219,6 +219,17 @@ typedef struct EodCenterNetLossDesc {
 size_t eod_centernet_loss_workspace_bytes(void);
 int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t stream);
 
+/* Training losses of one cascade stage's box head with their gradients: DeticFastRCNNOutputLayers.losses for USE_SIGMOID_CE +
+ * CLS_AGNOSTIC_BBOX_REG (detic_fast_rcnn.py:157-197): sigmoid_cross_entropy_loss (:200-233; class_weight [C] = federated-loss mask x
+ * zero-frequency mask, or NULL) and box_reg_loss (:270-303, smooth_l1; beta 0 = L1) against Box2BoxTransform.get_deltas(proposal, gt)
+ * with the stage's weights.  scores [B, ld] logits (columns 0..C, C = background), gt_classes [B] in [0, C]; every column of d_scores
+ * is written (background and padding: 0).  losses [2] = loss_cls, loss_box_reg.  The sampled / matched proposals are inputs. */
+size_t eod_fast_rcnn_loss_workspace_bytes(int B);
+int eod_fast_rcnn_loss(const float* scores, int ld, const float* deltas /*[B,4]*/, const float* proposal_boxes, const float* gt_boxes,
+                       const int32_t* gt_classes, const float* class_weight, int B, int num_classes, float wx, float wy, float ww,
+                       float wh, float smooth_l1_beta, float* d_scores, float* d_deltas, float* losses, void* workspace,
+                       size_t workspace_bytes, eod_stream_t stream);
+
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
   const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */

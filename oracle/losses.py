@@ -65,3 +65,46 @@ def centernet_proposal_losses(agn_logits: torch.Tensor, reg_pred: torch.Tensor, 
                                          ignore_high_fp)
     return {"loss_centernet_loc": loc, "loss_centernet_agn_pos": pos_weight * pos / num_pos_avg,
             "loss_centernet_agn_neg": neg_weight * neg / num_pos_avg}
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# DeticFastRCNNOutputLayers.losses (`Detic/detic/modeling/roi_heads/detic_fast_rcnn.py:157-197`) for USE_SIGMOID_CE + class-agnostic
+# box regression: sigmoid_cross_entropy_loss (:200-233) and box_reg_loss (:270-303, smooth_l1 branch).  The three upstream pieces it
+# calls are not in the reference tree and are restated from their published definitions (parity "unpinned" for them, as SURVEY
+# Appendix A says of detectron2 / fvcore): Box2BoxTransform.get_deltas, fvcore smooth_l1_loss, nonzero_tuple.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def get_deltas(src: torch.Tensor, dst: torch.Tensor, weights) -> torch.Tensor:
+    """detectron2 Box2BoxTransform.get_deltas: (dx, dy, dw, dh) that take `src` boxes to `dst`."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = dst[:, 2] - dst[:, 0], dst[:, 3] - dst[:, 1]
+    tx, ty = dst[:, 0] + 0.5 * tw, dst[:, 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
+
+
+def smooth_l1_sum(x: torch.Tensor, y: torch.Tensor, beta: float) -> torch.Tensor:
+    """fvcore.nn.smooth_l1_loss(reduction='sum'): plain L1 below beta 1e-5."""
+    d = torch.abs(x - y)
+    if beta < 1e-5:
+        return d.sum()
+    return torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta).sum()
+
+
+def sigmoid_cross_entropy_loss(logits: torch.Tensor, gt_classes: torch.Tensor, class_weight=None) -> torch.Tensor:
+    """detic_fast_rcnn.py:200-233: logits [B, C+1] (last column: background, unused), gt_classes [B] in [0, C] (C = background);
+    `class_weight` [C]: the product of the federated-loss mask (:213-222) and the zero-frequency mask (:223-225), or None."""
+    B, C = logits.shape[0], logits.shape[1] - 1
+    target = logits.new_zeros(B, C + 1)
+    target[torch.arange(B), gt_classes] = 1
+    cls_loss = torch.nn.functional.binary_cross_entropy_with_logits(logits[:, :-1], target[:, :C], reduction="none")
+    if class_weight is not None:
+        cls_loss = cls_loss * class_weight.view(1, C)
+    return cls_loss.sum() / B
+
+
+def box_reg_loss(proposal_boxes, gt_boxes, pred_deltas, gt_classes, num_classes: int, weights, beta: float = 0.0) -> torch.Tensor:
+    """detic_fast_rcnn.py:270-303, class-agnostic deltas, smooth_l1: foreground rows only, normalised by ALL rows."""
+    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_classes)).squeeze(1)
+    tgt = get_deltas(proposal_boxes[fg], gt_boxes[fg], weights)
+    return smooth_l1_sum(pred_deltas[fg], tgt, beta) / max(gt_classes.numel(), 1.0)

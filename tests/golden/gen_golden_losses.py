@@ -5,7 +5,8 @@ Loads the reference's OWN loss modules from where they lie (`Detic/third_party/C
 heatmap_focal_loss.py`, `iou_loss.py`: plain torch, no detectron2) and evaluates `binary_heatmap_focal_loss_jit` and
 `IOULoss('giou')` exactly as `CenterNet.losses` calls them (`.../dense_heads/centernet.py:283-313`) on seeded inputs of a five-level
 pyramid, with autograd's gradients with respect to the agnostic logits and the regression predictions.  Stores inputs, the three
-losses and the gradients in `tests/golden/centernet_loss.npz`.  No reference source or bytecode is copied.
+losses and the gradients in `tests/golden/centernet_loss.npz`; `main_box` does the same for the cascade's box-head losses
+(`tests/golden/fast_rcnn_loss.npz`).  No reference source or bytecode is copied.
 
     python tests/golden/gen_golden_losses.py
 """
@@ -81,5 +82,60 @@ def main():
     print("wrote", path, {k: float(out[k]) for k in ("loss_loc", "loss_agn_pos", "loss_agn_neg")})
 
 
+def make_box_inputs(seed: int = 1, B: int = 96, C: int = 20):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn((B, C + 1), generator=g) * 3
+    gt = torch.randint(0, C + 1, (B,), generator=g)
+    gt[::3] = C                                                   # background rows
+    xy = torch.rand((B, 2), generator=g) * 300
+    wh = torch.rand((B, 2), generator=g) * 200 + 4
+    prop = torch.cat([xy, xy + wh], dim=1)
+    jit = (torch.rand((B, 4), generator=g) - 0.5) * 30
+    gtb = prop + jit
+    gtb[:, 2:] = torch.maximum(gtb[:, 2:], gtb[:, :2] + 2)
+    deltas = torch.randn((B, 4), generator=g) * 0.5
+    cw = (torch.rand((C,), generator=g) < 0.7).float()            # a federated-loss mask
+    return logits, gt, prop, gtb, deltas, cw
+
+
+def main_box():
+    """`DeticFastRCNNOutputLayers.sigmoid_cross_entropy_loss` / `box_reg_loss` (detic_fast_rcnn.py:200-233, 270-303) run as unbound
+    methods of the reference class on a stand-in `self` (the attributes `__init__` would set for USE_SIGMOID_CE, class-agnostic
+    regression, smooth_l1 beta 0, one cascade stage's weights).  detectron2 / fvcore are absent: `nonzero_tuple`, `smooth_l1_loss` and
+    `Box2BoxTransform.get_deltas` are injected from their restatements in `oracle/losses.py`; what the fixture pins is the
+    reference's own part -- target construction, the class-weight mask, foreground selection, the normalisations."""
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, HERE)
+    import gen_golden as G
+    from oracle import losses as OL
+    G.install_shim()
+    mods = G.load_reference_modules()
+    fr = mods["fast_rcnn"]
+    fr.nonzero_tuple = lambda x: torch.nonzero(x, as_tuple=True)
+    fr.smooth_l1_loss = lambda a, b, beta, reduction="sum": OL.smooth_l1_sum(a, b, beta)
+    weights = (20.0, 20.0, 10.0, 10.0)                             # second cascade stage (ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS)
+    C = 20
+    logits, gt, prop, gtb, deltas, cw = make_box_inputs()
+    out = {}
+    for tag, fw in (("plain", None), ("fed", cw)):
+        self_ = types.SimpleNamespace(num_classes=C, use_fed_loss=False, ignore_zero_cats=fw is not None,
+                                      freq_weight=None if fw is None else fw * 1.0, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0,
+                                      box2box_transform=types.SimpleNamespace(get_deltas=lambda a, b: OL.get_deltas(a, b, weights)))
+        z = logits.clone().requires_grad_()
+        d = deltas.clone().requires_grad_()
+        lc = fr.DeticFastRCNNOutputLayers.sigmoid_cross_entropy_loss(self_, z, gt)
+        lb = fr.DeticFastRCNNOutputLayers.box_reg_loss(self_, prop, gtb, d, gt, num_classes=C)
+        (lc + lb).backward()
+        out.update({f"{tag}_loss_cls": np.float64(lc.item()), f"{tag}_loss_box_reg": np.float64(lb.item()),
+                    f"{tag}_grad_logits": z.grad.numpy(), f"{tag}_grad_deltas": d.grad.numpy()})
+    out.update(logits=logits.numpy(), gt_classes=gt.numpy().astype(np.int64), proposal_boxes=prop.numpy(), gt_boxes=gtb.numpy(),
+               deltas=deltas.numpy(), class_weight=cw.numpy(), box_weights=np.array(weights, np.float64), num_classes=np.int64(C))
+    path = os.path.join(HERE, "fast_rcnn_loss.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: float(v) for k, v in out.items() if "loss" in k})
+
+
 if __name__ == "__main__":
     main()
+    main_box()

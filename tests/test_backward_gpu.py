@@ -535,3 +535,46 @@ def test_centernet_loss_matches_the_reference_functions():
         assert abs(float(losses[i]) - ref[k].item()) <= 2e-5 * abs(ref[k].item()), k
     assert float((dh[:, 0] - zl.grad).abs().max()) <= 2e-5 * float(zl.grad.abs().max())
     assert float((dh[:, 1:5] - rw.grad).abs().max()) <= 1e-4 * float(rw.grad.abs().max())
+
+
+def test_fast_rcnn_loss_matches_the_reference_methods():
+    """`eod_fast_rcnn_loss` (one cascade stage's sigmoid CE + class-agnostic L1 / smooth-L1 box loss, detic_fast_rcnn.py:157-303) against
+    the fixture made by the reference's OWN `sigmoid_cross_entropy_loss` / `box_reg_loss` methods (gen_golden_losses.py::main_box), with
+    and without a class-weight mask; then beta > 0 and LVIS width (1 203 classes, zero-shot logits padded to a 1 216-column row)
+    against the oracle with autograd."""
+    from embodied_object_detection_amd import ops
+    from oracle import losses as OL
+    from test_losses_golden import load_box_fixture
+    dev = torch.device("cuda:0")
+    z, t = load_box_fixture()
+    C = int(z["num_classes"])
+    weights = tuple(float(v) for v in z["box_weights"])
+    for tag, cw in (("plain", None), ("fed", t("class_weight"))):
+        losses, ds, dd = ops.fast_rcnn_loss(t("logits").to(dev), t("deltas").to(dev), t("proposal_boxes").to(dev), t("gt_boxes").to(dev),
+                                            t("gt_classes").int().to(dev), C, weights, None if cw is None else cw.to(dev))
+        assert abs(float(losses[0]) - float(z[f"{tag}_loss_cls"])) <= 1e-5 * float(z[f"{tag}_loss_cls"]), tag
+        assert abs(float(losses[1]) - float(z[f"{tag}_loss_box_reg"])) <= 1e-5 * float(z[f"{tag}_loss_box_reg"]), tag
+        assert float((ds.cpu() - t(f"{tag}_grad_logits")).abs().max()) <= 1e-7, tag
+        assert float((dd.cpu() - t(f"{tag}_grad_deltas")).abs().max()) <= 1e-7, tag
+    # LVIS width, padded rows, smooth-L1 with beta > 0
+    g = torch.Generator().manual_seed(81)
+    B, C, ld = 512, 1203, 1216
+    logits = torch.randn((B, ld), generator=g) * 4
+    gt = torch.randint(0, C + 1, (B,), generator=g)
+    gt[::4] = C
+    xy = torch.rand((B, 2), generator=g) * 500
+    prop = torch.cat([xy, xy + torch.rand((B, 2), generator=g) * 200 + 4], dim=1)
+    gtb = prop + (torch.rand((B, 4), generator=g) - 0.5) * 20
+    gtb[:, 2:] = torch.maximum(gtb[:, 2:], gtb[:, :2] + 2)
+    deltas = torch.randn((B, 4), generator=g) * 0.4
+    cw = (torch.rand((C,), generator=g) < 0.05).float()
+    zl = logits[:, :C + 1].clone().requires_grad_()
+    dl = deltas.clone().requires_grad_()
+    lc = OL.sigmoid_cross_entropy_loss(zl, gt, cw)
+    lb = OL.box_reg_loss(prop, gtb, dl, gt, C, (30.0, 30.0, 15.0, 15.0), 0.3)
+    (lc + lb).backward()
+    losses, ds, dd = ops.fast_rcnn_loss(logits.to(dev), deltas.to(dev), prop.to(dev), gtb.to(dev), gt.int().to(dev), C,
+                                        (30.0, 30.0, 15.0, 15.0), cw.to(dev), 0.3)
+    assert abs(float(losses[0]) - lc.item()) <= 1e-5 * lc.item() and abs(float(losses[1]) - lb.item()) <= 1e-5 * lb.item()
+    assert float((ds.cpu()[:, :C + 1] - zl.grad).abs().max()) <= 1e-7 and float(ds.cpu()[:, C:].abs().max()) == 0.0
+    assert float((dd.cpu() - dl.grad).abs().max()) <= 1e-6

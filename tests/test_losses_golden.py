@@ -31,3 +31,30 @@ def test_oracle_losses_match_the_reference_functions():
     # the fixture exercises what it claims to: clamped logits (zero gradient), a duplicated positive, ReLU zeros, ignored positions
     assert int((t("grad_logits") == 0).sum()) > 10 and len(set(z["pos_inds"].tolist())) < len(z["pos_inds"])
     assert int((t("reg_targets").max(dim=1)[0] >= 0).sum()) == 60
+
+
+GOLD_BOX = os.path.join(os.path.dirname(__file__), "golden", "fast_rcnn_loss.npz")
+
+
+def load_box_fixture():
+    z = np.load(GOLD_BOX)
+    return z, (lambda k: torch.from_numpy(z[k]))
+
+
+def test_oracle_box_head_losses_match_the_reference_methods():
+    """`oracle.losses.sigmoid_cross_entropy_loss` / `box_reg_loss` against the reference's own methods
+    (detic_fast_rcnn.py:200-233, 270-303; gen_golden_losses.py::main_box), with and without a class-weight mask."""
+    z, t = load_box_fixture()
+    C = int(z["num_classes"])
+    weights = tuple(float(v) for v in z["box_weights"])
+    for tag, cw in (("plain", None), ("fed", t("class_weight"))):
+        logits = t("logits").clone().requires_grad_()
+        deltas = t("deltas").clone().requires_grad_()
+        lc = OL.sigmoid_cross_entropy_loss(logits, t("gt_classes"), cw)
+        lb = OL.box_reg_loss(t("proposal_boxes"), t("gt_boxes"), deltas, t("gt_classes"), C, weights, 0.0)
+        assert abs(lc.item() - float(z[f"{tag}_loss_cls"])) <= 1e-6 * float(z[f"{tag}_loss_cls"])
+        assert abs(lb.item() - float(z[f"{tag}_loss_box_reg"])) <= 1e-6 * float(z[f"{tag}_loss_box_reg"])
+        (lc + lb).backward()
+        assert float((logits.grad - t(f"{tag}_grad_logits")).abs().max()) <= 1e-8
+        assert float((deltas.grad - t(f"{tag}_grad_deltas")).abs().max()) <= 1e-8
+    assert int((t("gt_classes") == C).sum()) >= 32 and float(t("fed_grad_logits")[:, C].abs().max()) == 0.0

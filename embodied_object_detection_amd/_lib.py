@@ -59,6 +59,15 @@ class EodCenterNetLossDesc(C.Structure):
     ]
 
 
+class EodCenterNetTargetDesc(C.Structure):
+    _fields_ = [
+        ("gt_boxes", C.c_void_p), ("n_boxes", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 9), ("level_w", C.c_int32 * 8),
+        ("level_stride", C.c_int32 * 8), ("soi_lo", C.c_float * 8), ("soi_hi", C.c_float * 8), ("hm_min_overlap", C.c_double),
+        ("min_radius", C.c_double), ("agn_heatmap", C.c_void_p), ("reg_targets", C.c_void_p), ("pos_inds", C.c_void_p),
+        ("counts", C.c_void_p),
+    ]
+
+
 class EodProposalDesc(C.Structure):
     _fields_ = [
         ("head_out", C.c_void_p), ("head_stride", C.c_int32), ("levels", C.c_int32), ("level_off", C.c_int32 * 6),
@@ -123,6 +132,7 @@ SIGNATURES = {
     "eod_fast_rcnn_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "eod_centernet_targets": (C.c_int, [C.POINTER(EodCenterNetTargetDesc), C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),

@@ -110,6 +110,11 @@ def get_cfg() -> CfgNode:
                 "PRE_NMS_TOPK_TRAIN": 1000, "POST_NMS_TOPK_TRAIN": 100, "PRE_NMS_TOPK_TEST": 1000, "POST_NMS_TOPK_TEST": 100,
                 "NORM": "GN", "USE_DEFORMABLE": False, "NUM_CLS_CONVS": 4, "NUM_BOX_CONVS": 4, "NUM_SHARE_CONVS": 0,
                 "WITH_AGN_HM": False, "ONLY_PROPOSAL": False, "AS_PROPOSAL": False, "NOT_NMS": False, "NOT_NORM_REG": True,
+                # training keys (centernet/config.py:24-44): target assignment and losses of `modeling/training.py`
+                "LOC_LOSS_TYPE": "giou", "SIGMOID_CLAMP": 1e-4, "HM_MIN_OVERLAP": 0.8, "MIN_RADIUS": 4,
+                "SOI": [[0, 80], [64, 160], [128, 320], [256, 640], [512, 10000000]], "POS_WEIGHT": 1.0, "NEG_WEIGHT": 1.0,
+                "REG_WEIGHT": 2.0, "HM_FOCAL_BETA": 4, "HM_FOCAL_ALPHA": 0.25, "LOSS_GAMMA": 2.0, "IGNORE_HIGH_FP": -1.0,
+                "MORE_POS": False, "NO_REDUCE": False,
             },
             "ROI_HEADS": {
                 "NAME": "Res5ROIHeads", "NUM_CLASSES": 80, "IN_FEATURES": ["res4"], "SCORE_THRESH_TEST": 0.05, "NMS_THRESH_TEST": 0.5,

@@ -216,7 +216,143 @@ __global__ __launch_bounds__(64) void fast_rcnn_loss_sum_kernel(BoxLossArgs a) {
   a.losses[1] = (float)(reg / (double)a.B);
 }
 
+// CenterNet target assignment for ONLY_PROPOSAL, one image (centernet.py:342-479).  Every comparison below decides a target, so the
+// arithmetic follows the reference's fp32 operations one by one (no fused multiply-add: `fp contract(off)`).
+struct CnTargetArgs {
+  const float* boxes;   // [N,4]
+  int N, P, levels;
+  int lv_off[9], lv_w[8], lv_stride[8];
+  float soi_lo[8], soi_hi[8];
+  float radius_scale;   // (float)(delta^2 * 2)
+  float min_radius2;
+  float* heat;          // [P]
+  float* reg;           // [P,4]
+  int* pos;             // [N * levels]
+  int* counts;          // [2]: positives, regression rows
+};
+
+// positive locations (`_get_label_inds`, :441-479): box-major, level-minor list of the cells that hold a box's centre on the levels
+// whose size range contains the box (`assign_fpn_level`, :482-498).  One wave; also resets the regression-row counter.
+__global__ __launch_bounds__(64) void centernet_pos_inds_kernel(CnTargetArgs a) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x;
+  int base = 0;
+  const int total = a.N * a.levels;
+  for (int i0 = 0; i0 < total; i0 += 64) {
+    const int i = i0 + lane;
+    bool cared = false;
+    int idx = 0;
+    if (i < total) {
+      const int n = i / a.levels, l = i - n * a.levels;
+      const float x1 = a.boxes[n * 4], y1 = a.boxes[n * 4 + 1], x2 = a.boxes[n * 4 + 2], y2 = a.boxes[n * 4 + 3];
+      const float w = x2 - x1, h = y2 - y1;
+      const float crit = sqrtf(w * w + h * h) / 2.f;
+      cared = crit >= a.soi_lo[l] && crit <= a.soi_hi[l];
+      const float s = (float)a.lv_stride[l];
+      const int cxi = (int)(((x1 + x2) / 2.f) / s), cyi = (int)(((y1 + y2) / 2.f) / s);
+      idx = a.lv_off[l] + cyi * a.lv_w[l] + cxi;
+    }
+    const unsigned long long bal = __ballot(cared);
+    if (cared) a.pos[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    base += __popcll(bal);
+  }
+  if (lane == 0) { a.counts[0] = base; a.counts[1] = 0; }
+}
+
+// per grid position (`_get_ground_truth`, :342-438): the regression target of the nearest (radius-weighted) object among those whose
+// 3x3 centre region contains the position on this level, and the class-agnostic Gaussian heatmap over all objects.
+__global__ __launch_bounds__(256) void centernet_targets_kernel(CnTargetArgs a) {
+#pragma clang fp contract(off)
+  __shared__ float sb[256][8];   // x1, y1, x2, y2, cx, cy, radius2
+  const float INF = 100000000.f;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = m < a.P;
+  int l = 0;
+  if (live)
+    while (l + 1 < a.levels && m >= a.lv_off[l + 1]) ++l;
+  const int si = a.lv_stride[l];
+  const float s = (float)si;
+  const int rel = live ? m - a.lv_off[l] : 0;
+  const int iy = rel / a.lv_w[l], ix = rel - iy * a.lv_w[l];
+  const float gx = (float)(ix * si + si / 2), gy = (float)(iy * si + si / 2);     // compute_grids (:321-339)
+  float best = INF, hmin = INF * 10.f;
+  float r0 = -INF, r1 = -INF, r2 = -INF, r3 = -INF;
+  for (int n0 = 0; n0 < a.N; n0 += 256) {
+    __syncthreads();
+    const int nb = n0 + threadIdx.x;
+    if (nb < a.N) {
+      const float x1 = a.boxes[nb * 4], y1 = a.boxes[nb * 4 + 1], x2 = a.boxes[nb * 4 + 2], y2 = a.boxes[nb * 4 + 3];
+      sb[threadIdx.x][0] = x1; sb[threadIdx.x][1] = y1; sb[threadIdx.x][2] = x2; sb[threadIdx.x][3] = y2;
+      sb[threadIdx.x][4] = (x1 + x2) / 2.f;
+      sb[threadIdx.x][5] = (y1 + y2) / 2.f;
+      const float area = (x2 - x1) * (y2 - y1);
+      sb[threadIdx.x][6] = fmaxf(area * a.radius_scale, a.min_radius2);
+    }
+    __syncthreads();
+    const int cnt = min(256, a.N - n0);
+    if (!live) continue;
+    for (int j = 0; j < cnt; ++j) {
+      const float x1 = sb[j][0], y1 = sb[j][1], x2 = sb[j][2], y2 = sb[j][3], cx = sb[j][4], cy = sb[j][5];
+      const float lt = gx - x1, tt = gy - y1, rt = x2 - gx, bt = y2 - gy;
+      const float cdx = (float)(int)(cx / s) * s + s / 2.f, cdy = (float)(int)(cy / s) * s + s / 2.f;
+      const float ex = gx - cdx, ey = gy - cdy;
+      const bool is_peak = (ex * ex + ey * ey) == 0.f;
+      const bool in_box = fminf(fminf(lt, tt), fminf(rt, bt)) > 0.f;
+      const bool c3 = fabsf(ex) <= s && fabsf(ey) <= s && in_box;
+      const float sw = lt + rt, sh = tt + bt;
+      const float crit = sqrtf(sw * sw + sh * sh) / 2.f;
+      const bool mask = c3 && crit >= a.soi_lo[l] && crit <= a.soi_hi[l];
+      const float dx = gx - cx, dy = gy - cy;
+      const float dist2 = is_peak ? 0.f : dx * dx + dy * dy;
+      const float wd = dist2 / sb[j][6];
+      hmin = fminf(hmin, wd);
+      if (mask && wd < best) {          // strict: the first of equal distances wins, as torch.min(dim) returns it
+        best = wd;
+        r0 = lt; r1 = tt; r2 = rt; r3 = bt;
+      }
+    }
+  }
+  bool has = false;
+  if (live) {
+    has = best < INF;
+    if (!has) { r0 = r1 = r2 = r3 = -INF; }
+    f32x4 o = {r0 / s, r1 / s, r2 / s, r3 / s};
+    *reinterpret_cast<f32x4*>(a.reg + (size_t)m * 4) = o;
+    float hm = a.N > 0 ? expf(-hmin) : 0.f;
+    if (hm < 1e-4f) hm = 0.f;
+    a.heat[m] = hm;
+  }
+  const unsigned long long bal = __ballot(has);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(a.counts + 1, __popcll(bal));
+}
+
 }  // namespace
+
+extern "C" int eod_centernet_targets(const EodCenterNetTargetDesc* d, eod_stream_t stream) {
+  if (!d || !d->agn_heatmap || !d->reg_targets || !d->pos_inds || !d->counts) return EOD_ERR_NULL;
+  if (d->n_boxes > 0 && !d->gt_boxes) return EOD_ERR_NULL;
+  if (d->n_boxes < 0 || d->n_boxes > 4096 || d->levels < 1 || d->levels > 8 || d->level_off[0] != 0) return EOD_ERR_BAD_DIMS;
+  for (int l = 0; l < d->levels; ++l)
+    if (d->level_w[l] <= 0 || d->level_stride[l] <= 0 || d->level_off[l + 1] <= d->level_off[l] ||
+        (d->level_off[l + 1] - d->level_off[l]) % d->level_w[l] != 0)
+      return EOD_ERR_BAD_DIMS;
+  if (!(d->hm_min_overlap > 0.0 && d->hm_min_overlap < 1.0) || !(d->min_radius >= 0.0)) return EOD_ERR_BAD_DIMS;
+  if (!eod_aligned16(d->reg_targets)) return EOD_ERR_ALIGN;
+  CnTargetArgs a{};
+  a.boxes = d->gt_boxes; a.N = d->n_boxes; a.levels = d->levels; a.P = d->level_off[d->levels];
+  for (int l = 0; l <= d->levels; ++l) a.lv_off[l] = d->level_off[l];
+  for (int l = 0; l < d->levels; ++l) {
+    a.lv_w[l] = d->level_w[l]; a.lv_stride[l] = d->level_stride[l];
+    a.soi_lo[l] = d->soi_lo[l]; a.soi_hi[l] = d->soi_hi[l];
+  }
+  const double delta = (1.0 - d->hm_min_overlap) / (1.0 + d->hm_min_overlap);          // centernet.py:117
+  a.radius_scale = (float)(delta * delta * 2.0);                                       // :414
+  a.min_radius2 = (float)(d->min_radius * d->min_radius);
+  a.heat = d->agn_heatmap; a.reg = d->reg_targets; a.pos = d->pos_inds; a.counts = d->counts;
+  hipLaunchKernelGGL(centernet_pos_inds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(centernet_targets_kernel, dim3((a.P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
 
 extern "C" size_t eod_fast_rcnn_loss_workspace_bytes(int B) { return B > 0 ? (size_t)B * 2 * sizeof(double) : 0; }
 

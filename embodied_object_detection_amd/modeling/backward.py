@@ -20,12 +20,16 @@ from .backbone import CustomRecurrentFPN
 
 
 class BackboneBackward:
-    def __init__(self, backbone: CustomRecurrentFPN):
+    def __init__(self, backbone: CustomRecurrentFPN, merge_weights: Optional[List[torch.Tensor]] = None):
+        """`merge_weights`: the three `backbone.map_merge_projection{1,2,3}.weight` tensors ([256,512,1,1] fp32 masters), needed
+        only when the forward runs with a memory."""
         if backbone.feat_fusion not in ("sum", "image_only"):
             raise ValueError("the backbone's backward covers MAP_FEAT_FUSION sum / image_only (mem_only has no image gradient)")
         self.bb = backbone
         self.lib = _lib.load()
         self._bw: Dict[int, ops.ConvBackward] = {}
+        self.merge_weights = merge_weights
+        self._merge_bw = None
 
     def _b(self, conv: ops.Conv) -> ops.ConvBackward:
         if id(conv) not in self._bw:
@@ -33,9 +37,9 @@ class BackboneBackward:
         return self._bw[id(conv)]
 
     # ---- forward that keeps its activations -------------------------------------------------------------------------------
-    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, memory_term: Optional[List[torch.Tensor]] = None):
-        """-> ([P3..P7] as [N,h,w,256] tensors, saved).  `memory_term`: what the memory fusion adds to P3..P5 (weight x
-        projection of the pooled memory, already computed by `eod_memory_project_fuse`'s training form); None = image only."""
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, memory=None):
+        """-> ([P3..P7] as [N,h,w,256] tensors, saved).  `memory = (memory_f16, proj)`: the memory read + sum fusion into P3..P5 as
+        the hot path runs it (`eod_memory_gather_pool` + `eod_memory_project_fuse`; N == 1); None = image only."""
         bb = self.bb
         keep: dict = {}
         c = bb.bottom_up.forward(x4, H, W, N, keep=keep)
@@ -47,14 +51,23 @@ class BackboneBackward:
         lat3 = bb.lateral[3](c3, N, h3, w3, res=lat4, res_mode=2)
         p3 = bb.output[3](lat3, N, h3, w3)
         P = [p3, p4, p5]
-        if memory_term is not None:
-            P = [p + m.view_as(p) for p, m in zip(P, memory_term)]
+        keep["pooled"] = None
+        if memory is not None and bb.feat_fusion == "sum":
+            if N != 1:
+                raise ValueError("the memory fusion is per scene: N == 1")
+            rows = torch.cat([p.reshape(-1, 256) for p in P])
+            pooled = ops.memory_gather_pool(memory[0], memory[1], H, W, torch_order=bb.pool_in_torch_order)
+            bb.merge(pooled, rows, H, W, bb.map_feature_weight, bb.feat_fusion)
+            o = 0
+            for i, p in enumerate(P):
+                P[i] = rows[o:o + p.shape[1] * p.shape[2]].view(p.shape)
+                o += p.shape[1] * p.shape[2]
+            keep["pooled"] = pooled
         p6 = bb.p6(P[2], N, h5, w5)
         h6, w6 = bb.p6.out_hw(h5, w5)
         p7 = bb.p7(p6, N, h6, w6, in_relu=True)
         keep["fpn"] = dict(c=(c3, c4, c5), lat=(lat3, lat4, lat5), P=P, p6=p6, hw=((h3, w3), (h4, w4), (h5, w5), (h6, w6)))
-        keep["N"] = N
-        keep["x4"] = x4
+        keep["N"], keep["x4"], keep["HW"] = N, x4, (H, W)
         return P + [p6, p7], keep
 
     # ---- backward ------------------------------------------------------------------------------------------------------------
@@ -89,6 +102,16 @@ class BackboneBackward:
         r = self._b(bb.p6)(P[2].contiguous(), None, g6.contiguous())
         put(bb.p6, r)
         g_out = [dP[0].contiguous(), dP[1].contiguous(), (dP[2] + r["dx"]).contiguous()]      # sum fusion: identity to the image branch
+        if saved["pooled"] is not None:
+            # the memory branch of the fusion: dW / db of the map_merge projections (timm.py:170-178)
+            if self._merge_bw is None:
+                if self.merge_weights is None:
+                    raise ValueError("pass the map_merge_projection weights (merge_weights=) to back-propagate into the memory branch")
+                self._merge_bw = ops.MemoryProjectorBackward(self.merge_weights, self.bb.device)
+            H, W = saved["HW"]
+            mb = self._merge_bw([t.view(-1, 256) for t in g_out], saved["pooled"], H, W, bb.map_feature_weight)
+            for i in range(3):
+                grads[f"map_merge_projection{i + 1}"] = (mb["dW"][i], mb["db"][i])
         # output convs -> gradients of the merged laterals; top-down add: the coarser level also collects the 2x2 block sums
         r5 = self._b(bb.output[5])(lat5, None, g_out[2])
         put(bb.output[5], r5)

@@ -623,6 +623,38 @@ class ConvBackward:
         return dict(dx=dx, dw=dw, db=db)
 
 
+CENTERNET_SOI = ((0, 80), (64, 160), (128, 320), (256, 640), (512, 10000000))      # MODEL.CENTERNET.SOI
+
+
+def centernet_targets(gt_boxes: torch.Tensor, level_hw: Sequence[Tuple[int, int]], strides: Sequence[int] = (8, 16, 32, 64, 128),
+                      sizes_of_interest=CENTERNET_SOI, hm_min_overlap: float = 0.8, min_radius: float = 4.0):
+    """CenterNet's target assignment for one image on the device (`eod_centernet_targets`; centernet.py:342-479) ->
+    (agn_heatmap [P], reg_targets [P,4], pos_inds int32 [N * levels] of which counts[0] are valid, counts int32 [2] = positives,
+    regression rows).  gt_boxes [N,4] float32 on the device."""
+    _need_cuda(gt_boxes)
+    dev = gt_boxes.device
+    d = _lib.EodCenterNetTargetDesc()
+    N, L = gt_boxes.shape[0], len(level_hw)
+    off = [0]
+    for (h, w) in level_hw:
+        off.append(off[-1] + h * w)
+    P = off[-1]
+    d.gt_boxes, d.n_boxes, d.levels = (gt_boxes.data_ptr() if N else None), N, L
+    for i, v in enumerate(off):
+        d.level_off[i] = v
+    for l in range(L):
+        d.level_w[l], d.level_stride[l] = level_hw[l][1], strides[l]
+        d.soi_lo[l], d.soi_hi[l] = float(sizes_of_interest[l][0]), float(sizes_of_interest[l][1])
+    d.hm_min_overlap, d.min_radius = hm_min_overlap, min_radius
+    heat = torch.empty((P,), dtype=torch.float32, device=dev)
+    reg = torch.empty((P, 4), dtype=torch.float32, device=dev)
+    pos = torch.zeros((max(N * L, 1),), dtype=torch.int32, device=dev)
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    d.agn_heatmap, d.reg_targets, d.pos_inds, d.counts = heat.data_ptr(), reg.data_ptr(), pos.data_ptr(), counts.data_ptr()
+    check(_lib.load().eod_centernet_targets(C.byref(d), _stream()), "eod_centernet_targets")
+    return heat, reg, pos, counts
+
+
 class CenterNetLoss:
     """`CenterNet.losses` of the recurrent configuration on the device with its gradient (`eod_centernet_loss`; centernet.py:241-318:
     agnostic heatmap focal loss + GIoU regression loss).  `__call__(head_out [P, stride], agn_heatmap [P], reg_targets [P,4],

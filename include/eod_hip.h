@@ -219,6 +219,26 @@ typedef struct EodCenterNetLossDesc {
 size_t eod_centernet_loss_workspace_bytes(void);
 int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t stream);
 
+/* CenterNet target assignment for ONLY_PROPOSAL, one image (centernet.py:342-479: _get_ground_truth, _get_label_inds and their
+ * helpers): from the ground-truth boxes to what eod_centernet_loss consumes.  Bit-exact with the reference's fp32 arithmetic except
+ * the heatmap's expf (<= 2 ulp). */
+typedef struct EodCenterNetTargetDesc {
+  const float* gt_boxes;      /* [n_boxes,4] x1,y1,x2,y2 on the device */
+  int32_t n_boxes;            /* 0 .. 4096 */
+  int32_t levels;             /* <= 8 */
+  int32_t level_off[9];       /* rows of the pyramid's row list */
+  int32_t level_w[8];
+  int32_t level_stride[8];    /* MODEL.CENTERNET.FPN_STRIDES */
+  float soi_lo[8], soi_hi[8]; /* MODEL.CENTERNET.SOI */
+  double hm_min_overlap;      /* 0.8 */
+  double min_radius;          /* 4 */
+  float* agn_heatmap;         /* [P] */
+  float* reg_targets;         /* [P,4] in units of the level's stride; -1e8 / stride where no object claims the position */
+  int32_t* pos_inds;          /* [n_boxes * levels] positive rows, box-major / level-minor */
+  int32_t* counts;            /* [2]: number of positives, number of positions with a regression target */
+} EodCenterNetTargetDesc;
+int eod_centernet_targets(const EodCenterNetTargetDesc* d, eod_stream_t stream);
+
 /* Training losses of one cascade stage's box head with their gradients: DeticFastRCNNOutputLayers.losses for USE_SIGMOID_CE +
  * CLS_AGNOSTIC_BBOX_REG (detic_fast_rcnn.py:157-197): sigmoid_cross_entropy_loss (:200-233; class_weight [C] = federated-loss mask x
  * zero-frequency mask, or NULL) and box_reg_loss (:270-303, smooth_l1; beta 0 = L1) against Box2BoxTransform.get_deltas(proposal, gt)

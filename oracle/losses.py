@@ -108,3 +108,74 @@ def box_reg_loss(proposal_boxes, gt_boxes, pred_deltas, gt_classes, num_classes:
     fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_classes)).squeeze(1)
     tgt = get_deltas(proposal_boxes[fg], gt_boxes[fg], weights)
     return smooth_l1_sum(pred_deltas[fg], tgt, beta) / max(gt_classes.numel(), 1.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# CenterNet target assignment for ONLY_PROPOSAL, one image (centernet.py:342-479): `_get_ground_truth` with `compute_grids` (:321-339),
+# `_get_label_inds` (:441-479), `assign_fpn_level` (:482-498), `assign_reg_fpn` (:501-513), `_get_reg_targets` (:516-528),
+# `_create_agn_heatmaps_from_dist` (:549-560), `get_center3x3` (:577-594).  Pinned by tests/golden/centernet_targets.npz.
+# ----------------------------------------------------------------------------------------------------------------------------------
+CENTERNET_INF = 100000000          # centernet.py:28
+CENTERNET_SOI = ((0, 80), (64, 160), (128, 320), (256, 640), (512, 10000000))
+
+
+def centernet_targets(gt_boxes: torch.Tensor, level_hw, strides=(8, 16, 32, 64, 128), sizes_of_interest=CENTERNET_SOI,
+                      hm_min_overlap: float = 0.8, min_radius: float = 4.0):
+    """gt_boxes [N,4] (x1,y1,x2,y2), level_hw [(h, w)] per level -> (pos_inds [N'] int64, reg_targets [M,4] in units of the level's
+    stride with -INF / stride rows where no object claims the position, agn_heatmap [M]), M = sum h*w in level order."""
+    delta = (1 - hm_min_overlap) / (1 + hm_min_overlap)
+    M = sum(h * w for h, w in level_hw)
+    N = gt_boxes.shape[0]
+    regs, heats, pos = [], [], []
+    boxes = gt_boxes.float()
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    centers = (boxes[:, :2] + boxes[:, 2:]) / 2                                     # [N,2]
+    radius2 = torch.clamp(delta ** 2 * 2 * area, min=min_radius ** 2)               # [N]
+    # positive locations: box-major, level-minor (centernet.py:463-473)
+    crit_box = ((boxes[:, 2:] - boxes[:, :2]) ** 2).sum(dim=1) ** 0.5 / 2
+    base = 0
+    bases = []
+    for (h, w) in level_hw:
+        bases.append(base)
+        base += h * w
+    for n in range(N):
+        for l, s in enumerate(strides):
+            lo, hi = sizes_of_interest[l]
+            if float(crit_box[n]) >= lo and float(crit_box[n]) <= hi:
+                ci = (centers[n] / float(s)).long()
+                pos.append(bases[l] + int(ci[1]) * level_hw[l][1] + int(ci[0]))
+    for l, ((h, w), s) in enumerate(zip(level_hw, strides)):
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) * s + s // 2, torch.arange(w, dtype=torch.float32) * s + s // 2,
+                                indexing="ij")
+        gx, gy = xs.reshape(-1, 1), ys.reshape(-1, 1)                               # [m,1]
+        m = gx.shape[0]
+        if N == 0:
+            regs.append(torch.full((m, 4), -float(CENTERNET_INF)) / float(s))
+            heats.append(torch.zeros((m,)))
+            continue
+        lt = gx - boxes[:, 0].view(1, N)
+        tt = gy - boxes[:, 1].view(1, N)
+        rt = boxes[:, 2].view(1, N) - gx
+        bt = boxes[:, 3].view(1, N) - gy
+        ltrb = torch.stack([lt, tt, rt, bt], dim=2)                                 # [m,N,4]
+        cdx = (centers[:, 0].view(1, N) / s).int().float() * s + s / 2
+        cdy = (centers[:, 1].view(1, N) / s).int().float() * s + s / 2
+        is_peak = ((gx - cdx) ** 2 + (gy - cdy) ** 2) == 0
+        in_box = ltrb.min(dim=2)[0] > 0
+        c3 = ((gx - cdx).abs() <= s) & ((gy - cdy).abs() <= s) & in_box
+        crit = ((lt + rt) ** 2 + (tt + bt) ** 2) ** 0.5 / 2
+        lo, hi = sizes_of_interest[l]
+        mask = c3 & (crit >= lo) & (crit <= hi)
+        dist2 = (gx - centers[:, 0].view(1, N)) ** 2 + (gy - centers[:, 1].view(1, N)) ** 2
+        dist2[is_peak] = 0
+        wd = dist2 / radius2.view(1, N)
+        d = wd.clone()
+        d[~mask] = CENTERNET_INF * 1.0
+        md, mi = d.min(dim=1)
+        r = ltrb[torch.arange(m), mi].clone()
+        r[md == CENTERNET_INF] = -float(CENTERNET_INF)
+        regs.append(r / float(s))
+        hm = torch.exp(-wd.min(dim=1)[0])
+        hm[hm < 1e-4] = 0
+        heats.append(hm)
+    return torch.tensor(pos, dtype=torch.int64), torch.cat(regs), torch.cat(heats)

@@ -136,6 +136,71 @@ def main_box():
     print("wrote", path, {k: float(v) for k, v in out.items() if "loss" in k})
 
 
+class _GtBoxes:
+    def __init__(self, t):
+        self.tensor = t
+
+    def area(self):
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def make_gt_boxes(seed: int = 2):
+    """Ground-truth boxes of a 256x320 image: small / medium / large (all five size ranges of MODEL.CENTERNET.SOI are hit), two boxes
+    with one centre, a centre exactly on a grid point, a box reaching outside the image."""
+    g = torch.Generator().manual_seed(seed)
+    boxes = [[20.0, 30.0, 52.0, 70.0], [100.5, 40.25, 180.0, 150.0], [4.0, 4.0, 316.0, 252.0], [60.0, 60.0, 68.0, 66.0],
+             [200.0, 100.0, 310.0, 240.0], [210.0, 110.0, 300.0, 230.0], [92.0, 92.0, 100.0, 100.0], [-10.0, 180.0, 90.0, 270.0],
+             [120.0, 8.0, 250.0, 120.0], [30.0, 140.0, 190.0, 250.0]]
+    extra = torch.rand((6, 2), generator=g) * torch.tensor([250.0, 200.0])
+    wh = torch.rand((6, 2), generator=g) * 90 + 6
+    boxes = torch.cat([torch.tensor(boxes), torch.cat([extra, extra + wh], dim=1)])
+    classes = torch.randint(0, 20, (boxes.shape[0],), generator=g)
+    return boxes, classes
+
+
+def main_targets():
+    """`CenterNet._get_ground_truth` + `_get_label_inds` (centernet.py:342-479) and every helper they call (`compute_grids`,
+    `assign_fpn_level`, `assign_reg_fpn`, `_get_reg_targets`, `_create_agn_heatmaps_from_dist`, `get_center3x3`, `_transpose`) run as
+    the reference's own code on a stand-in `self` carrying the configuration's attributes (ONLY_PROPOSAL, default SOI / strides /
+    HM_MIN_OVERLAP / MIN_RADIUS); detectron2's `cat` is torch.cat.  One image with 16 boxes and one image without objects."""
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, HERE)
+    import gen_golden as G
+    if "centernet.modeling.dense_heads.centernet" not in sys.modules:
+        G.install_shim()
+        G.load_reference_modules()
+    cn = sys.modules["centernet.modeling.dense_heads.centernet"]
+    cn.cat = torch.cat
+    CN = cn.CenterNet
+    self_ = types.SimpleNamespace(strides=[8, 16, 32, 64, 128], num_classes=20, only_proposal=True, more_pos=False, not_clamp_box=False,
+                                  sizes_of_interest=[[0, 80], [64, 160], [128, 320], [256, 640], [512, 10000000]], min_radius=4,
+                                  delta=(1 - 0.8) / (1 + 0.8))
+    for name in ("compute_grids", "_get_label_inds", "assign_fpn_level", "assign_reg_fpn", "_get_reg_targets",
+                 "_create_agn_heatmaps_from_dist", "get_center3x3", "_get_ground_truth"):
+        setattr(self_, name, types.MethodType(getattr(CN, name), self_))
+    H, W = 256, 320
+    shapes = [(H // s + (1 if H % s else 0), W // s + (1 if W % s else 0)) for s in self_.strides]
+    feats = [torch.zeros((1, 1, h, w)) for h, w in shapes]
+    grids = self_.compute_grids(feats)
+    shapes_per_level = grids[0].new_tensor(shapes)
+    boxes, classes = make_gt_boxes()
+    out = dict(image_hw=np.array([H, W], np.int32), shapes=np.array(shapes, np.int32), gt_boxes=boxes.numpy(),
+               gt_classes=classes.numpy().astype(np.int64), grids=torch.cat(grids).numpy())
+    for tag, b, c in (("full", boxes, classes), ("empty", boxes[:0], classes[:0])):
+        inst = [types.SimpleNamespace(gt_boxes=_GtBoxes(b.clone()), gt_classes=c.clone())]
+        pos_inds, labels, reg_targets, hms = self_._get_ground_truth([x.clone() for x in grids], shapes_per_level, inst)
+        out.update({f"{tag}_pos_inds": pos_inds.numpy().astype(np.int64), f"{tag}_labels": labels.numpy().astype(np.int64),
+                    f"{tag}_reg_targets": reg_targets.numpy(), f"{tag}_heatmap": hms.numpy()})
+    path = os.path.join(HERE, "centernet_targets.npz")
+    np.savez_compressed(path, **out)
+    rt = out["full_reg_targets"]
+    print("wrote", path, "positions", rt.shape[0], "positives", len(out["full_pos_inds"]), "regression rows",
+          int((rt.max(axis=1) >= 0).sum()), "heatmap > 0", int((out["full_heatmap"] > 0).sum()))
+
+
 if __name__ == "__main__":
     main()
     main_box()
+    main_targets()

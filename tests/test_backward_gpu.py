@@ -1,6 +1,8 @@
 """Training forward, first slice: backward of the memory READ (timm.py:142-192) on HIP against torch autograd
 on the oracle's own forward (`oracle/model.py::memory_read_pooled` / `fuse_memory`, run on the CPU in fp32 with the reference's
 fp16 casts): dW / db of the three `map_merge_projection` 1x1 convolutions and the gradients of the cascaded pools."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -578,3 +580,197 @@ def test_fast_rcnn_loss_matches_the_reference_methods():
     assert abs(float(losses[0]) - lc.item()) <= 1e-5 * lc.item() and abs(float(losses[1]) - lb.item()) <= 1e-5 * lb.item()
     assert float((ds.cpu()[:, :C + 1] - zl.grad).abs().max()) <= 1e-7 and float(ds.cpu()[:, C:].abs().max()) == 0.0
     assert float((dd.cpu() - dl.grad).abs().max()) <= 1e-6
+
+
+def test_centernet_targets_match_the_reference():
+    """`eod_centernet_targets` against the reference's own `_get_ground_truth` / `_get_label_inds` (centernet.py:342-479; fixture by
+    gen_golden_losses.py::main_targets): positive locations and regression targets bit for bit, the heatmap within 2 ulp (expf), the
+    image without objects; then a 640x640 pyramid with 300 boxes (two LDS chunks) against the oracle; and the targets feed
+    `eod_centernet_loss` directly."""
+    import numpy as np
+    from embodied_object_detection_amd import ops
+    from oracle import losses as OL
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "centernet_targets.npz"))
+    shapes = [tuple(x) for x in z["shapes"].tolist()]
+
+    def compare(boxes, ref_pos, ref_reg, ref_heat, level_hw):
+        heat, reg, pos, counts = ops.centernet_targets(boxes.to(dev), level_hw)
+        n_pos, n_reg = counts.cpu().tolist()
+        assert pos.cpu()[:n_pos].tolist() == list(ref_pos)
+        assert torch.equal(reg.cpu(), ref_reg)
+        assert n_reg == int((ref_reg.max(dim=1)[0] >= 0).sum())
+        h = heat.cpu()
+        assert torch.equal(h == 0, ref_heat == 0)
+        assert float(((h - ref_heat).abs() / ref_heat.clamp(min=1e-4)).max()) <= 3e-7
+        return heat, reg, pos, counts
+
+    compare(torch.from_numpy(z["gt_boxes"]), z["full_pos_inds"].tolist(), torch.from_numpy(z["full_reg_targets"]),
+            torch.from_numpy(z["full_heatmap"][:, 0]), shapes)
+    compare(torch.zeros((0, 4)), [], torch.from_numpy(z["empty_reg_targets"]), torch.from_numpy(z["empty_heatmap"][:, 0]), shapes)
+    # full-size pyramid, 300 boxes
+    g = torch.Generator().manual_seed(91)
+    shapes2 = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    xy = torch.rand((300, 2), generator=g) * 560
+    wh = torch.cat([torch.rand((200, 2), generator=g) * 60 + 4, torch.rand((100, 2), generator=g) * 500 + 40])
+    boxes = torch.cat([xy, (xy + wh).clamp(max=639.0)], dim=1)          # inside the image: a centre beyond it has no grid cell
+    rp, rr, rh = OL.centernet_targets(boxes, shapes2)
+    heat, reg, pos, counts = compare(boxes, rp.tolist(), rr, rh, shapes2)
+    # the targets drive the loss kernel as they are
+    n_pos, n_reg = counts.cpu().tolist()
+    off = [0]
+    for h, w in shapes2:
+        off.append(off[-1] + h * w)
+    head = torch.randn((off[-1], 8), generator=g)
+    scales = [1.0, 0.9, 1.1, 1.2, 0.8]
+    losses, dh = ops.CenterNetLoss(off, scales, dev)(head.to(dev), heat, reg, pos[:n_pos], max(float(n_pos), 1.0), max(float(n_reg), 1.0))
+    hz = head.clone().requires_grad_()
+    regp = torch.cat([torch.relu(hz[off[l]:off[l + 1], 1:5] * scales[l]) for l in range(5)])
+    ref = OL.centernet_proposal_losses(hz[:, 0], regp, rh, rr, rp)
+    sum(ref.values()).backward()
+    for i, k in enumerate(("loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg")):
+        assert abs(float(losses[i]) - ref[k].item()) <= 3e-5 * abs(ref[k].item()), k
+    assert float((dh.cpu() - hz.grad).abs().max()) <= 1e-4 * float(hz.grad.abs().max())
+
+
+def test_proposal_training_step_matches_autograd(synthetic_sd):
+    """The proposal half of the reference's training forward (custom_rcnn.py:584-679 up to `proposal_losses`) on the HIP kernels
+    (`modeling/training.py`): image -> ResNet-50 / FPN with the memory read fused in -> CenterNet head -> target assignment ->
+    CenterNet.losses -> the gradient of EVERY parameter upstream (level scales, agn_hm / bbox_pred, 4 x tower conv + GroupNorm, P6 / P7,
+    FPN, map_merge projections, 53 trunk convs), against torch autograd on the oracle's forward + the oracle's targets / losses.
+
+    A ReLU whose pre-activation is within fp32 rounding of zero can be open in one implementation and closed in the other; that is a
+    discrete difference of the gradient (first seen at seed 101: one element of tower layer 1 on P4, 2e-3 of the affected tensors).
+    The test counts such flips over all ReLUs of trunk and head and asserts the tight tolerance on an input without any."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import ProposalTraining
+    from oracle import losses as OL
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5])
+    model = build_model(cfg, synthetic_sd)
+    step = ProposalTraining(model, synthetic_sd)
+    H, W, n_cells = 128, 160, 500
+    gt = torch.tensor([[10.0, 12.0, 60.0, 70.0], [40.0, 30.0, 150.0, 120.0], [90.0, 8.0, 118.0, 40.0], [5.0, 80.0, 44.0, 124.0],
+                       [100.0, 60.0, 156.0, 126.0], [64.0, 64.0, 72.0, 72.0], [2.0, 2.0, 158.0, 126.0]])
+    ocfg = M.OracleCfg(map_feature_weight=5.0)
+    h = "proposal_generator.centernet_head"
+    base = "backbone.bottom_up.base"
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+
+    def run(seed):
+        g = torch.Generator().manual_seed(seed)
+        img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+        mem16 = (torch.randn((n_cells, 512), generator=g) * 2).half()
+        proj = torch.randint(0, n_cells, (H, W), generator=g)
+        # ---- torch autograd on the oracle (the head restated with its pre-activations kept: centernet_head.py:141-161)
+        trainable = lambda k, v: v.is_floating_point() and "running_" not in k and (k.startswith("backbone.") or "centernet_head" in k)
+        sd = {k: (v.clone().float().requires_grad_() if trainable(k, v) else v) for k, v in synthetic_sd.items()}
+        # the trunk restated with every post-ReLU activation kept (timm.py:277-299), then FPN + memory fusion + P6 / P7 of the oracle
+        x = M.preprocess_image(img, ocfg)
+        t = F.relu(M.frozen_bn(F.conv2d(x, sd[f"{base}.conv1.weight"], stride=2, padding=3), sd, f"{base}.bn1"))
+        trunk_acts = [t.detach()]
+        t = F.max_pool2d(t, kernel_size=3, stride=2, padding=1)
+        cfeats = {}
+        for li, nblk in enumerate((3, 4, 6, 3), start=1):
+            for b in range(nblk):
+                p = f"{base}.layer{li}.{b}"
+                st = 2 if (b == 0 and li > 1) else 1
+                o1 = F.relu(M.frozen_bn(F.conv2d(t, sd[f"{p}.conv1.weight"]), sd, f"{p}.bn1"))
+                o2 = F.relu(M.frozen_bn(F.conv2d(o1, sd[f"{p}.conv2.weight"], stride=st, padding=1), sd, f"{p}.bn2"))
+                o3 = M.frozen_bn(F.conv2d(o2, sd[f"{p}.conv3.weight"]), sd, f"{p}.bn3")
+                sc = t
+                if f"{p}.downsample.0.weight" in sd:
+                    sc = M.frozen_bn(F.conv2d(t, sd[f"{p}.downsample.0.weight"], stride=st), sd, f"{p}.downsample.1")
+                t = F.relu(o3 + sc)
+                trunk_acts += [o1.detach(), o2.detach(), t.detach()]
+            cfeats[f"layer{li + 1}"] = t
+        feats = M.fuse_memory(M.fpn_top_down(cfeats, sd), M.memory_read_pooled(mem16, proj), sd, ocfg)
+        feats = feats + M.top_block(feats[2], sd)
+        shapes = [(f.shape[2], f.shape[3]) for f in feats]
+        pre = [[] for _ in range(4)]
+        agn, reg = [], []
+        for l, f in enumerate(feats):
+            t = f
+            for i in range(4):
+                t = F.group_norm(F.conv2d(t, sd[f"{h}.bbox_tower.{3 * i}.weight"], sd[f"{h}.bbox_tower.{3 * i}.bias"], padding=1), 32,
+                                 sd[f"{h}.bbox_tower.{3 * i + 1}.weight"], sd[f"{h}.bbox_tower.{3 * i + 1}.bias"], eps=1e-5)
+                pre[i].append(t.detach()[0].permute(1, 2, 0).reshape(-1, 256))
+                t = F.relu(t)
+            agn.append(F.conv2d(t, sd[f"{h}.agn_hm.weight"], sd[f"{h}.agn_hm.bias"], padding=1))
+            reg.append(F.relu(F.conv2d(t, sd[f"{h}.bbox_pred.weight"], sd[f"{h}.bbox_pred.bias"], padding=1) * sd[f"{h}.scales.{l}.scale"]))
+        logits = torch.cat([a.permute(0, 2, 3, 1).reshape(-1) for a in agn])
+        reg_pred = torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg])
+        pos, reg_t, heat = OL.centernet_targets(gt, shapes)
+        assert pos.numel() >= 7 and int((reg_t.max(dim=1)[0] >= 0).sum()) >= 20
+        ref = OL.centernet_proposal_losses(logits, reg_pred, heat, reg_t, pos)
+        sum(ref.values()).backward()
+        # ---- the HIP step
+        losses, grads = step.forward_backward(img.to(dev), gt.to(dev), memory=(mem16.to(dev), proj.int().to(dev)))
+        torch.cuda.synchronize()
+        flips = 0
+        for i in range(4):
+            p = torch.cat(pre[i])
+            mism = (step.last["keep"][i][3].cpu() > 0) != (p > 0)
+            flips += int(mism.sum())
+            assert float(p[mism].abs().max()) < 1e-4 if mism.any() else True          # only knife-edge elements may differ
+        saved = step.last["saved"]
+        prod_acts = [saved["stem"][0]] + [a for blk in saved["blocks"] for a in (blk[1], blk[2], blk[3])]
+        assert len(prod_acts) == len(trunk_acts)
+        for pa, ra in zip(prod_acts, trunk_acts):
+            flips += int(((pa.cpu() > 0) != (ra[0].permute(1, 2, 0).unsqueeze(0) > 0)).sum())
+        for k in ref:
+            assert abs(float(losses[k]) - ref[k].item()) <= 1e-4 * abs(ref[k].item()), (k, float(losses[k]), ref[k].item())
+        err = {}
+        packed = lambda w: w.grad.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+        def check(name, got, want):
+            err[name] = rel(got.cpu(), want)
+
+        check("scales", grads["scales"], torch.stack([sd[f"{h}.scales.{l}.scale"].grad.reshape(()) for l in range(5)]))
+        for name in ("agn_hm", "bbox_pred"):
+            check(name + ".w", grads[name][0], packed(sd[f"{h}.{name}.weight"]))
+            check(name + ".b", grads[name][1], sd[f"{h}.{name}.bias"].grad)
+        for i in range(4):
+            dw, db = grads[f"bbox_tower.{3 * i}"]
+            dga, dbe = grads[f"bbox_tower.{3 * i}.norm"]
+            check(f"tower{i}.w", dw, packed(sd[f"{h}.bbox_tower.{3 * i}.weight"]))
+            check(f"tower{i}.b", db, sd[f"{h}.bbox_tower.{3 * i}.bias"].grad)
+            check(f"tower{i}.gamma", dga, sd[f"{h}.bbox_tower.{3 * i + 1}.weight"].grad)
+            check(f"tower{i}.beta", dbe, sd[f"{h}.bbox_tower.{3 * i + 1}.bias"].grad)
+        for l in (3, 4, 5):
+            for kind in ("lateral", "output"):
+                check(f"fpn_{kind}{l}.w", grads[f"fpn_{kind}{l}"][0], packed(sd[f"backbone.fpn_{kind}{l}.weight"]))
+                check(f"fpn_{kind}{l}.b", grads[f"fpn_{kind}{l}"][1], sd[f"backbone.fpn_{kind}{l}.bias"].grad)
+        for name in ("p6", "p7"):
+            check(name + ".w", grads[name][0], packed(sd[f"backbone.top_block.{name}.weight"]))
+        for i in (1, 2, 3):
+            dW, db = grads[f"map_merge_projection{i}"]
+            check(f"map_merge{i}.w", dW, sd[f"backbone.map_merge_projection{i}.weight"].grad.reshape(256, 512))
+            check(f"map_merge{i}.b", db, sd[f"backbone.map_merge_projection{i}.bias"].grad)
+        n = 0
+        for li, nblk in enumerate((3, 4, 6, 3), start=1):
+            for b in range(nblk):
+                p = f"{base}.layer{li}.{b}"
+                pairs = [(f"{p}.conv{i}", f"{p}.conv{i}.weight", f"{p}.bn{i}") for i in (1, 2, 3)]
+                if f"{p}.downsample.0.weight" in sd:
+                    pairs.append((f"{p}.downsample", f"{p}.downsample.0.weight", f"{p}.downsample.1"))
+                for name, wk, bnp in pairs:
+                    scale = (sd[f"{bnp}.weight"] / torch.sqrt(sd[f"{bnp}.running_var"] + 1e-5)).detach()
+                    check(name + ".w", grads[name][0].cpu() * scale[:, None], packed(sd[wk]))
+                    check(name + ".b", grads[name][1], sd[f"{bnp}.bias"].grad)
+                    n += 1
+        assert n == 52
+        return losses, err, flips
+
+    seen = []
+    for seed in (105, 106, 107, 108, 109, 110):           # measured: seeds 102 / 103 / 104 have 1 / 3 / 2 flips (errors 2e-3 .. 2e-2), 105 none
+        losses, err, flips = run(seed)
+        seen.append((seed, flips, "%.1e" % max(err.values())))
+        if flips == 0:
+            break
+    print("seeds (seed, ReLU flips in trunk + head, worst error):", seen)
+    assert flips == 0, seen
+    bad = {k: "%.1e" % v for k, v in err.items() if v > 1e-4}
+    assert not bad, bad
+    print("proposal training step (seed %d): losses %s; worst relative gradient error %.2e (%s) over %d tensors"
+          % (seed, {k: round(float(v), 5) for k, v in losses.items()}, max(err.values()), max(err, key=err.get), len(err)))

@@ -58,3 +58,20 @@ def test_oracle_box_head_losses_match_the_reference_methods():
         assert float((logits.grad - t(f"{tag}_grad_logits")).abs().max()) <= 1e-8
         assert float((deltas.grad - t(f"{tag}_grad_deltas")).abs().max()) <= 1e-8
     assert int((t("gt_classes") == C).sum()) >= 32 and float(t("fed_grad_logits")[:, C].abs().max()) == 0.0
+
+
+GOLD_TGT = os.path.join(os.path.dirname(__file__), "golden", "centernet_targets.npz")
+
+
+def test_oracle_target_assignment_matches_the_reference():
+    """`oracle.losses.centernet_targets` against the reference's own `_get_ground_truth` / `_get_label_inds` (centernet.py:342-479;
+    gen_golden_losses.py::main_targets): positive locations, regression targets and the agnostic heatmap, bit for bit; and the
+    image without objects."""
+    z = np.load(GOLD_TGT)
+    shapes = [tuple(x) for x in z["shapes"].tolist()]
+    for tag, boxes in (("full", torch.from_numpy(z["gt_boxes"])), ("empty", torch.zeros((0, 4)))):
+        pos, reg, heat = OL.centernet_targets(boxes, shapes)
+        assert pos.tolist() == z[f"{tag}_pos_inds"].tolist(), tag
+        assert np.array_equal(reg.numpy(), z[f"{tag}_reg_targets"]), tag
+        assert np.array_equal(heat.numpy(), z[f"{tag}_heatmap"][:, 0]), tag
+    assert len(z["full_pos_inds"]) > len(z["gt_boxes"]) and int((z["full_reg_targets"].max(axis=1) >= 0).sum()) > 100

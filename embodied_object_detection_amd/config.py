@@ -152,7 +152,15 @@ def get_cfg() -> CfgNode:
         "DATASETS": {"TRAIN": (), "TEST": ()},
         "DATALOADER": {"NUM_WORKERS": 4, "SAMPLER_TRAIN": "TrainingSampler"},
         "TEST": {"DETECTIONS_PER_IMAGE": 100, "EVAL_PERIOD": 0},
-        "SOLVER": {},
+        # detectron2's SOLVER defaults + Detic's additions (detic/config.py:153-157): read by solver.py / modeling/training.py
+        "SOLVER": {
+            "LR_SCHEDULER_NAME": "WarmupMultiStepLR", "MAX_ITER": 40000, "BASE_LR": 0.001, "MOMENTUM": 0.9, "NESTEROV": False,
+            "WEIGHT_DECAY": 0.0001, "WARMUP_FACTOR": 0.001, "WARMUP_ITERS": 1000, "WARMUP_METHOD": "linear", "IMS_PER_BATCH": 16,
+            "CHECKPOINT_PERIOD": 5000,
+            "CLIP_GRADIENTS": {"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0, "NORM_TYPE": 2.0},
+            "USE_CUSTOM_SOLVER": False, "OPTIMIZER": "SGD", "BACKBONE_MULTIPLIER": 1.0, "CUSTOM_MULTIPLIER": 1.0,
+            "CUSTOM_MULTIPLIER_NAME": [],
+        },
         "DEBUG": False,
         "VIS_THRESH": 0.3,
         "EVAL_PROPOSAL_AR": False,

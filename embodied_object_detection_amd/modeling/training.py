@@ -110,3 +110,125 @@ class ProposalTraining:
         bgrads, _ = self.bb.backward(saved, dP)
         grads.update(bgrads)
         return losses, grads
+
+
+class ProposalTrainer:
+    """`ProposalTraining` closed into optimizer steps: the reference's AdamW set-up (`build_custom_optimizer`, custom_solver.py:19-79, as
+    `solver.param_groups_from_cfg` restates it: BACKBONE_MULTIPLIER, `map_merge` at CUSTOM_MULTIPLIER, clip by value) over every
+    parameter upstream of the proposal losses, updated IN the layers the inference path runs: FPN / tower / P6 / P7 convs step their
+    packed weights in place; the trunk's convs step a raw master and are re-folded with their FrozenBatchNorm (whose weight / bias are
+    buffers, not parameters: timm.py:277-299); the map_merge projections are re-prepared; the level scales go back to the decoder."""
+
+    def __init__(self, model, sd: Dict[str, torch.Tensor]):
+        from .. import solver
+        self.model, self.dev = model, model.device
+        self.step_fn = ProposalTraining(model, sd)
+        cfg = model.cfg
+        dev = self.dev
+        bbm, pg = model.backbone, model.proposal_generator
+        self.entries = []          # (reference parameter name, tensor stepped by AdamW, gradient getter)
+        self.after = []            # callables run after every optimizer step
+        base = "backbone.bottom_up.base"
+
+        def add(name, tensor, getter):
+            self.entries.append((name, tensor, getter))
+
+        def trunk_conv(conv, wname, bnp, cin_pad=None):
+            # raw master in the packed layout; gradient of the raw weight = gradient of the folded one x gamma / sqrt(var + eps)
+            master, _ = ops.pack_conv_weight(sd[wname].float(), cin_pad)
+            K = conv.KH * conv.KW * conv.Cin
+            master = master[:, :K].contiguous().to(dev)
+            scale = (sd[f"{bnp}.weight"].float() / torch.sqrt(sd[f"{bnp}.running_var"].float() + 1e-5)).to(dev).view(-1, 1)
+            add(wname, master, lambda g, n=conv.name, s=scale: (g[n][0] * s).contiguous())
+            self.after.append(lambda c=conv, m=master, s=scale, K=K: c.w[:, :K].copy_(m * s))
+
+        trunk_conv(bbm.bottom_up.stem, f"{base}.conv1.weight", f"{base}.bn1", cin_pad=4)
+        for (li, c1, c2, c3, ds) in bbm.bottom_up.blocks:
+            for conv in (c1, c2, c3):
+                p = conv.name                                    # '<base>.layerL.B.convI'
+                trunk_conv(conv, p + ".weight", p.rsplit(".conv", 1)[0] + ".bn" + p[-1])
+            if ds is not None:
+                trunk_conv(ds, ds.name + ".0.weight", ds.name + ".1")
+
+        def plain_conv(conv, prefix, rows=None):
+            assert conv.Kpad == conv.KH * conv.KW * conv.Cin
+            w = conv.w if rows is None else conv.w[rows[0]:rows[1]]
+            b = conv.bias if rows is None else conv.bias[rows[0]:rows[1]]
+            return w, b
+
+        for l in (3, 4, 5):
+            for kind, conv in (("lateral", bbm.lateral[l]), ("output", bbm.output[l])):
+                w, b = plain_conv(conv, None)
+                add(f"backbone.fpn_{kind}{l}.weight", w, lambda g, n=conv.name: g[n][0])
+                add(f"backbone.fpn_{kind}{l}.bias", b, lambda g, n=conv.name: g[n][1])
+        for name, conv in (("p6", bbm.p6), ("p7", bbm.p7)):
+            w, b = plain_conv(conv, None)
+            add(f"backbone.top_block.{name}.weight", w, lambda g, n=conv.name: g[n][0])
+            add(f"backbone.top_block.{name}.bias", b, lambda g, n=conv.name: g[n][1])
+        self.merge_w = [sd[f"backbone.map_merge_projection{i}.weight"].float().reshape(256, 512).contiguous().to(dev) for i in (1, 2, 3)]
+        self.merge_b = [sd[f"backbone.map_merge_projection{i}.bias"].float().contiguous().to(dev) for i in (1, 2, 3)]
+        for i in range(3):
+            add(f"backbone.map_merge_projection{i + 1}.weight", self.merge_w[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][0])
+            add(f"backbone.map_merge_projection{i + 1}.bias", self.merge_b[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][1])
+
+        def remerge():
+            bbm.merge = ops.MemoryProjector(self.merge_w, self.merge_b, dev)
+            self.step_fn.bb.merge_weights = self.merge_w
+            self.step_fn.bb._merge_bw = None
+        self.after.append(remerge)
+        h = "proposal_generator.centernet_head"
+        for i, (conv, gamma, beta) in enumerate(pg.tower):
+            w, b = plain_conv(conv, None)
+            add(f"{h}.bbox_tower.{3 * i}.weight", w, lambda g, n=conv.name: g[n][0])
+            add(f"{h}.bbox_tower.{3 * i}.bias", b, lambda g, n=conv.name: g[n][1])
+            add(f"{h}.bbox_tower.{3 * i + 1}.weight", gamma, lambda g, n=conv.name: g[n + ".norm"][0])
+            add(f"{h}.bbox_tower.{3 * i + 1}.bias", beta, lambda g, n=conv.name: g[n + ".norm"][1])
+        out32 = self.step_fn.out32
+        for name, rows in (("agn_hm", (0, 1)), ("bbox_pred", (1, 5))):
+            w, b = plain_conv(out32, None, rows)
+            add(f"{h}.{name}.weight", w, lambda g, n=name: g[n][0].contiguous())
+            add(f"{h}.{name}.bias", b, lambda g, n=name: g[n][1].contiguous())
+
+        def sync_out_conv():                                      # the inference path's 5-channel layer is its own object
+            pg.out_conv.w.copy_(out32.w[:5])
+            pg.out_conv.bias.copy_(out32.bias[:5])
+        self.after.append(sync_out_conv)
+        self.scales = torch.tensor(pg.scales, dtype=torch.float32, device=dev)
+        add(f"{h}.scales", self.scales, lambda g: g["scales"])    # five scalar parameters `scales.{l}.scale`, stepped as one tensor
+
+        def sync_scales():
+            pg.scales = [float(v) for v in self.scales.cpu().tolist()]
+            pg._plans.clear()                                    # the decoders carry the scales in their descriptors
+            self.step_fn._loss.clear()
+        self.after.append(sync_scales)
+
+        def stale_caches():
+            for bw in list(self.step_fn._bw.values()) + list(self.step_fn.bb._bw.values()):
+                bw._flipped_of = None                            # rotated weights of the dgrad convs
+                bw.conv.w_split = None                           # bf16x3 pieces, if that arithmetic was in use
+        self.after.append(stale_caches)
+        s = cfg.SOLVER
+        if str(s.OPTIMIZER) != "ADAMW":
+            raise NotImplementedError("the device optimizer is AdamW (SOLVER.OPTIMIZER ADAMW, Base-...recurrent.yaml)")
+        frozen = []
+        if bool(cfg.MODEL.FREEZE_BACKBONE):
+            # train_mp3d.py:704-710: a parameter stays trainable iff one of UNFROZEN_LAYERS is a substring of its name
+            keys = list(cfg.MODEL.UNFROZEN_LAYERS)
+            frozen = [n for n, _, _ in self.entries if not any(k in n for k in keys)]
+        self.groups = solver.param_groups_from_cfg(cfg, [(n, t) for n, t, _ in self.entries])
+        self.groups = [g for g in self.groups if g["name"] not in frozen]
+        self.getters = {n: f for n, _, f in self.entries}
+        clip = s.CLIP_GRADIENTS
+        if bool(clip.ENABLED) and str(clip.CLIP_TYPE) != "value":
+            raise NotImplementedError("gradient clipping: CLIP_TYPE value (detectron2's default)")
+        self.opt = ops.AdamW(self.groups, weight_decay=float(s.WEIGHT_DECAY), clip_value=float(clip.CLIP_VALUE) if bool(clip.ENABLED) else 0.0)
+        self.iteration = 0
+
+    def step(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, lr_factor: float = 1.0):
+        """One training iteration on one frame -> the three proposal losses (device scalars, of the weights BEFORE the update)."""
+        losses, grads = self.step_fn.forward_backward(image_u8, gt_boxes, memory=memory)
+        self.opt.step([self.getters[g["name"]](grads) for g in self.groups], lr_factor=lr_factor)
+        for f in self.after:
+            f()
+        self.iteration += 1
+        return losses

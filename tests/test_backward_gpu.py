@@ -774,3 +774,87 @@ def test_proposal_training_step_matches_autograd(synthetic_sd):
     assert not bad, bad
     print("proposal training step (seed %d): losses %s; worst relative gradient error %.2e (%s) over %d tensors"
           % (seed, {k: round(float(v), 5) for k, v in losses.items()}, max(err.values()), max(err, key=err.get), len(err)))
+
+
+def test_proposal_trainer_steps_like_torch_and_reduces_the_loss(synthetic_sd):
+    """`ProposalTrainer` (modeling/training.py): the reference's AdamW set-up over every parameter upstream of the proposal losses,
+    applied to the layers the inference path runs.  (1) after ONE step the parameters equal those of torch.optim.AdamW (+ detectron2's
+    clip by value) stepping the oracle's raw parameters on autograd's gradients, with the learning rates `build_custom_optimizer`
+    assigns (custom_solver.py:19-79: backbone multiplier, map_merge x 10); (2) further steps on the same frame reduce the loss, and
+    the inference path -- which shares the updated layers -- still runs."""
+    from embodied_object_detection_amd import build_model, setup_cfg, solver
+    from embodied_object_detection_amd.modeling.training import ProposalTrainer
+    from oracle import losses as OL
+    dev = torch.device("cuda:0")
+    lr = 2e-5
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "SOLVER.BASE_LR", lr])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = ProposalTrainer(model, sd0)
+    H, W, n_cells = 128, 160, 500
+    g = torch.Generator().manual_seed(105)                      # the flip-free input of the test above
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 2).half()
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    gt = torch.tensor([[10.0, 12.0, 60.0, 70.0], [40.0, 30.0, 150.0, 120.0], [90.0, 8.0, 118.0, 40.0], [5.0, 80.0, 44.0, 124.0],
+                       [100.0, 60.0, 156.0, 126.0], [64.0, 64.0, 72.0, 72.0], [2.0, 2.0, 158.0, 126.0]])
+    # ---- torch: autograd on the oracle, AdamW with the reference's groups
+    ocfg = M.OracleCfg(map_feature_weight=5.0)
+    trainable = lambda k, v: v.is_floating_point() and "running_" not in k and ".bn" not in k and ".downsample.1." not in k and \
+        (k.startswith("backbone.") or "centernet_head" in k)
+    sd = {k: (v.clone().float().requires_grad_() if trainable(k, v) else v) for k, v in synthetic_sd.items()}
+    feats = M.backbone_forward(M.preprocess_image(img, ocfg), sd, ocfg, mem16, proj)
+    agn, reg = M.centernet_head(feats, sd)
+    shapes = [(f.shape[2], f.shape[3]) for f in feats]
+    pos, reg_t, heat = OL.centernet_targets(gt, shapes)
+    ref = OL.centernet_proposal_losses(torch.cat([a.permute(0, 2, 3, 1).reshape(-1) for a in agn]),
+                                       torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg]), heat, reg_t, pos)
+    sum(ref.values()).backward()
+    named = [(k, v) for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None]
+    groups = solver.param_groups_from_cfg(cfg, named)
+    assert {g_["lr"] for g_ in groups if "map_merge" in g_["name"]} == {lr * 10.0}
+    opt = torch.optim.AdamW([{"params": [g_["param"]], "lr": g_["lr"]} for g_ in groups], lr=lr, weight_decay=float(cfg.SOLVER.WEIGHT_DECAY))
+    for _, v in named:
+        v.grad.clamp_(-float(cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE), float(cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE))
+    opt.step()
+    # ---- the HIP trainer, one step
+    mem = (mem16.to(dev), proj.int().to(dev))
+    l0 = trainer.step(img.to(dev), gt.to(dev), memory=mem)
+    first = sum(float(v) for v in l0.values())
+    assert abs(first - sum(v.item() for v in ref.values())) <= 1e-4 * first
+    packed = lambda w: w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    stepped = {n: t for n, t, _ in trainer.entries}
+    h = "proposal_generator.centernet_head"
+    checked = 0
+    for name, tensor in stepped.items():
+        if name == f"{h}.scales":
+            want = torch.stack([sd[f"{h}.scales.{l}.scale"].detach().reshape(()) for l in range(5)])
+        elif name.endswith("conv1.weight") and "layer" not in name:
+            want = F.pad(sd[name].detach().permute(0, 2, 3, 1), (0, 1)).reshape(64, -1)               # the stem's 4-channel tap layout
+        elif sd[name].dim() == 4 and "map_merge" not in name:
+            want = packed(sd[name])
+        else:
+            want = sd[name].detach().reshape(tensor.shape)
+        group_lr = next(g_["lr"] for g_ in trainer.groups if g_["name"] == name)
+        diff = (tensor.cpu().reshape(want.shape) - want).abs()
+        # the first AdamW step moves every weight by lr * g / (|g| + eps): equal gradients give equal steps; an element whose gradient
+        # is within rounding of zero may step the other way (2 lr)
+        assert float(diff.max()) <= 2.01 * group_lr, (name, float(diff.max()), group_lr)
+        assert float(diff.mean()) <= 2e-3 * group_lr, (name, float(diff.mean()), group_lr)
+        checked += 1
+    assert checked == len(trainer.entries) == 53 + 12 + 4 + 6 + 16 + 4 + 1
+    # the trunk's re-folded layer really carries the stepped master
+    c = model.backbone.bottom_up.blocks[5][2]
+    bnp = c.name.rsplit(".conv", 1)[0] + ".bn" + c.name[-1]
+    scale = (synthetic_sd[f"{bnp}.weight"] / torch.sqrt(synthetic_sd[f"{bnp}.running_var"] + 1e-5)).view(-1, 1)
+    assert float((c.w.cpu() - stepped[c.name + ".weight"].cpu() * scale).abs().max()) <= 1e-6
+    # ---- more steps on the same frame: the loss goes down; the inference path runs on the updated layers
+    last = first
+    for _ in range(7):
+        last = sum(float(v) for v in trainer.step(img.to(dev), gt.to(dev), memory=mem).values())
+    assert last < first, (first, last)
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    out = model([[SyntheticSequence(0, H=H, W=W, n_frames=1).frame(0)]])
+    assert len(out) == 1 and "instances" in out[0]
+    print("proposal trainer: total loss %.4f -> %.4f after 8 steps at lr %.0e" % (first, last, lr))

@@ -170,6 +170,12 @@ struct ConvBwdArgs {
   float* db;        // [Cout] or null
   int N, H, W, Cin, Cout, KH, KW, pad, stride, OH, OW;
   FastDiv div_w, div_h;     // by OW, OH
+  // splits > 1 (blockIdx.z): the positions are cut into `splits` contiguous ranges, each writing its own partial dW / db into
+  // part [splits][Cout * Ktot] / bpart [splits][Cout]; wgrad_reduce_kernel adds them in range order.  Layers with few channel tiles
+  // and many positions (the trunk's first stages: 4 .. 64 workgroups otherwise) fill the chip this way.
+  int splits;
+  float* part;
+  float* bpart;
 };
 
 __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs a) {
@@ -182,10 +188,13 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
   const int col = lane & 31, kh = lane >> 5;
   const int P = a.N * a.OH * a.OW;            // positions of the OUTPUT grid
   const int steps = (P + 7) / 8;
-  const int spw = (steps + 3) / 4;
-  const int s_begin = wave * spw;
+  const int sps = (steps + a.splits - 1) / a.splits;           // steps of this split
+  const int z_begin = blockIdx.z * sps;
+  const int z_end = min(z_begin + sps, steps);
+  const int spw = (sps + 3) / 4;
+  const int s_begin = z_begin + wave * spw;
   int s_end = s_begin + spw;
-  if (s_end > steps) s_end = steps;
+  if (s_end > z_end) s_end = z_end;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -230,16 +239,34 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
     for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
   // C/D layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int Ktot = a.KH * a.KW * a.Cin;
+  float* dw = a.splits > 1 ? a.part + (size_t)blockIdx.z * a.Cout * Ktot : a.dw;
+  float* db = a.splits > 1 ? a.bpart + (size_t)blockIdx.z * a.Cout : a.db;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    a.dw[(size_t)co * Ktot + (size_t)tap * a.Cin + ci0 + col] = acc[r];
+    dw[(size_t)co * Ktot + (size_t)tap * a.Cin + ci0 + col] = acc[r];
   }
   if (a.db && tap == 0 && (tile % ci_tiles) == 0 && lane < 32) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += bred[w * 64 + lane] + bred[w * 64 + 32 + lane];    // even + odd positions, wave order
-    a.db[co0 + lane] = v;
+    db[co0 + lane] = v;
+  }
+}
+
+// dW / db = the partial results of the position ranges added in range order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dw,
+                                                           float* __restrict__ db, size_t n, int Cout, int splits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + (db ? Cout : 0); i += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < n) {
+      for (int z = 0; z < splits; ++z) v += part[(size_t)z * n + i];
+      dw[i] = v;
+    } else {
+      const size_t c = i - n;
+      for (int z = 0; z < splits; ++z) v += bpart[(size_t)z * Cout + c];
+      db[c] = v;
+    }
   }
 }
 
@@ -253,9 +280,11 @@ __global__ __launch_bounds__(1024) void conv_backward_weights_tap4_kernel(ConvBw
   const int ky = tap / a.KW, kx = tap - ky * a.KW;
   const int t = threadIdx.x, ci = t & 3, col = (t >> 2) & 15, lane_p = t >> 6;
   const int P = a.N * a.OH * a.OW;
+  const int pps = (P + a.splits - 1) / a.splits;
+  const int p_begin = blockIdx.z * pps, p_end = min(p_begin + pps, P);
   float acc = 0.f, accb = 0.f;
 #pragma unroll 4
-  for (int p = lane_p; p < P; p += 16) {
+  for (int p = p_begin + lane_p; p < p_end; p += 16) {
     const int ox = p % a.OW, r = p / a.OW;
     const int oy = r % a.OH, n = r / a.OH;
     const float gv = a.g[(size_t)p * a.Cout + co0 + col];
@@ -269,11 +298,14 @@ __global__ __launch_bounds__(1024) void conv_backward_weights_tap4_kernel(ConvBw
   if (t < 64) {
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += part[i][t];
-    a.dw[(size_t)(co0 + col) * (a.KH * a.KW * 4) + tap * 4 + ci] = s;
+    const int Ktot = a.KH * a.KW * 4;
+    float* dw = a.splits > 1 ? a.part + (size_t)blockIdx.z * a.Cout * Ktot : a.dw;
+    float* db = a.splits > 1 ? a.bpart + (size_t)blockIdx.z * a.Cout : a.db;
+    dw[(size_t)(co0 + col) * Ktot + tap * 4 + ci] = s;
     if (tap == 0 && ci == 0 && a.db) {
       float sb = 0.f;
       for (int i = 0; i < 16; ++i) sb += partb[i][col];
-      a.db[co0 + col] = sb;
+      db[co0 + col] = sb;
     }
   }
 }
@@ -408,19 +440,65 @@ static int conv_bwd_args(ConvBwdArgs& a, int N, int H, int W, int Cin, int Cout,
   return EOD_OK;
 }
 
-extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
-                                           int stride, float* dw, float* db, eod_stream_t stream) {
+// position ranges of a weight-gradient launch: enough workgroups for the chip, ranges of at least 16 steps (128 positions)
+static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const long P = (long)N * OH * OW;
+  const long wgs = Cin == 4 ? (long)KH * KW * (Cout >> 4) : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
+  long s = Cin == 4 ? 16 : (768 + wgs - 1) / wgs;                // the stem's kernel is latency-bound per thread: more, shorter ranges
+  const long cap = Cin == 4 ? P / 2048 : (P + 7) / 8 / 16;
+  if (s > cap) s = cap;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" size_t eod_conv2d_backward_weights_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || pad < 0 || stride < 1) return 0;
+  const int s = wgrad_splits(N, H, W, Cin, Cout, KH, KW, pad, stride);
+  return s > 1 ? (size_t)s * ((size_t)Cout * KH * KW * Cin + Cout) * sizeof(float) : 0;
+}
+
+static int conv2d_backward_weights_impl(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                        int stride, float* dw, float* db, void* workspace, size_t workspace_bytes, eod_stream_t stream) {
   if (!x || !g || !dw) return EOD_ERR_NULL;
   ConvBwdArgs a{};
   const int st = conv_bwd_args(a, N, H, W, Cin == 4 ? 32 : Cin, Cout, KH, KW, pad, stride);     // Cin == 4: the stem's tap layout
   if (st != EOD_OK) return st;
   a.Cin = Cin;
   a.x = x; a.g = g; a.dw = dw; a.db = db;
+  a.splits = 1;
+  const size_t n = (size_t)Cout * KH * KW * Cin;
+  if (workspace) {
+    const size_t need = eod_conv2d_backward_weights_workspace_bytes(N, H, W, Cin, Cout, KH, KW, pad, stride);
+    if (need > workspace_bytes) return EOD_ERR_CAPACITY;
+    if (need) {
+      a.splits = wgrad_splits(N, H, W, Cin, Cout, KH, KW, pad, stride);
+      a.part = static_cast<float*>(workspace);
+      a.bpart = a.part + (size_t)a.splits * n;
+    }
+  }
   if (Cin == 4)
-    hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4), dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4, a.splits), dim3(1024), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW, a.splits), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.splits > 1) {
+    size_t blocks = (n + Cout + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a.part, a.bpart, dw, db, n, Cout, a.splits);
+  }
   return eod_launch_status();
+}
+
+extern "C" int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                           int stride, float* dw, float* db, eod_stream_t stream) {
+  return conv2d_backward_weights_impl(x, g, N, H, W, Cin, Cout, KH, KW, pad, stride, dw, db, nullptr, 0, stream);
+}
+
+extern "C" int eod_conv2d_backward_weights_ws(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                              int pad, int stride, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                                              eod_stream_t stream) {
+  if (workspace_bytes && !workspace) return EOD_ERR_NULL;
+  return conv2d_backward_weights_impl(x, g, N, H, W, Cin, Cout, KH, KW, pad, stride, dw, db, workspace, workspace_bytes, stream);
 }
 
 extern "C" int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW,

@@ -171,11 +171,9 @@ class ProposalTrainer:
             add(f"backbone.map_merge_projection{i + 1}.weight", self.merge_w[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][0])
             add(f"backbone.map_merge_projection{i + 1}.bias", self.merge_b[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][1])
 
-        def remerge():
-            bbm.merge = ops.MemoryProjector(self.merge_w, self.merge_b, dev)
-            self.step_fn.bb.merge_weights = self.merge_w
-            self.step_fn.bb._merge_bw = None
-        self.after.append(remerge)
+        self.step_fn.bb.merge_weights = self.merge_w
+        # (the gradient of the pooled memory, for which MemoryProjectorBackward keeps W^T convs, is not read by this step)
+        self.after.append(lambda: bbm.merge.refresh(self.merge_w, self.merge_b))
         h = "proposal_generator.centernet_head"
         for i, (conv, gamma, beta) in enumerate(pg.tower):
             w, b = plain_conv(conv, None)
@@ -199,7 +197,9 @@ class ProposalTrainer:
         def sync_scales():
             pg.scales = [float(v) for v in self.scales.cpu().tolist()]
             pg._plans.clear()                                    # the decoders carry the scales in their descriptors
-            self.step_fn._loss.clear()
+            for loss in self.step_fn._loss.values():
+                for l, v in enumerate(pg.scales):
+                    loss.desc.level_scale[l] = v
         self.after.append(sync_scales)
 
         def stale_caches():

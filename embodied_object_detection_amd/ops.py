@@ -6,7 +6,7 @@ buffers the kernels write.  No arithmetic is done with torch ops here.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -525,6 +525,15 @@ class MemoryProjector:
                                                   bs[2].data_ptr(), self.prepared.data_ptr(), _stream()), "eod_memory_project_prepare")
         torch.cuda.current_stream().synchronize()       # ws / bs die with this frame; the prepare kernels must have read them
 
+    def refresh(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+        """Re-prepare from stepped fp32 masters that live on the device ([256,512] / [256], contiguous, kept alive by the caller)."""
+        _need_cuda(*weights, *biases)
+        for w, b in zip(weights, biases):
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == 256 * 512 and b.is_contiguous() and b.numel() == 256
+        check(self.lib.eod_memory_project_prepare(weights[0].data_ptr(), biases[0].data_ptr(), weights[1].data_ptr(), biases[1].data_ptr(),
+                                                  weights[2].data_ptr(), biases[2].data_ptr(), self.prepared.data_ptr(), _stream()),
+              "eod_memory_project_prepare")
+
     def __call__(self, pooled_f16: torch.Tensor, feats: torch.Tensor, H: int, W: int, weight: float, mode: str, batch: int = 1):
         """`batch` > 1: `feats` is level major over the scenes (include/eod_hip.h)."""
         _need_cuda(pooled_f16, feats)
@@ -574,11 +583,17 @@ class ConvBackward:
     layout of `Conv.w`, db).  dx = `eod_conv2d` of the pre-activation gradient with the 180-degree rotated, in/out-transposed
     weights; dw / db = `eod_conv2d_backward_weights`."""
 
+    _workspace: Dict = {}      # per device: partial sums of the position-split weight gradient (stream-ordered reuse)
+
     def __init__(self, conv: "Conv"):
         if conv.out_mode != 0:
             raise ValueError("ConvBackward covers plain convolutions (no deconv)")
         # stride-1 'same' layers: dX on the matrix cores (eod_conv2d with rotated weights); anything else: the gather kernel
         self.same = conv.stride == 1 and conv.KH == conv.KW and conv.pad * 2 == conv.KH - 1
+        # strided 'same'-padded layers (3x3 s2 p1: P6 / P7 and the trunk's conv2; 1x1 s2: its downsample convs): the gradient is
+        # spread onto the input grid with zeros in between and goes through the same rotated-weights conv on the matrix cores
+        # (3/4 of the products are zeros, still ~20x faster than the gather kernel: 0.87 ms -> tens of us per layer at 640x640)
+        self.zero_insert = conv.stride > 1 and conv.KH == conv.KW and conv.pad * 2 == conv.KH - 1
         self.conv = conv
         self.lib = _lib.load()
         self._flipped = None
@@ -591,8 +606,14 @@ class ConvBackward:
             c = self.conv
             K = c.KH * c.KW * c.Cin
             w = c.w[:, :K].reshape(c.Cout, c.KH, c.KW, c.Cin)                       # [co, ky, kx, ci]
-            wt = w.flip(1, 2).permute(3, 0, 1, 2).contiguous()                     # [ci, co, ky', kx'] = OIHW of the transposed conv
-            self._flipped = Conv(wt.cpu(), None, stride=1, pad=c.pad, device=c.w.device, name=c.name + "^T")
+            if self._flipped is None:
+                wt = w.flip(1, 2).permute(3, 0, 1, 2).contiguous()                 # [ci, co, ky', kx'] = OIHW of the transposed conv
+                self._flipped = Conv(wt.cpu(), None, stride=1, pad=c.pad, device=c.w.device, name=c.name + "^T")
+            else:
+                # the weights were stepped: refresh the packed rows [ci][(ky', kx', co)] on the device (no host round trip)
+                K2 = c.KH * c.KW * c.Cout
+                self._flipped.w[:, :K2].copy_(w.flip(1, 2).permute(3, 1, 2, 0).reshape(c.Cin, K2))
+                self._flipped.w_split = None
             self._flipped_of = key
         return self._flipped
 
@@ -611,11 +632,20 @@ class ConvBackward:
         K = c.KH * c.KW * c.Cin
         dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
         db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
-        check(self.lib.eod_conv2d_backward_weights(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
-                                                   dw.data_ptr(), db.data_ptr(), _stream()), "eod_conv2d_backward_weights")
+        need = self.lib.eod_conv2d_backward_weights_workspace_bytes(N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride)
+        ws = ConvBackward._workspace.get(x.device)
+        if need and (ws is None or ws.numel() * 4 < need):
+            ws = ConvBackward._workspace[x.device] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=x.device)
+        check(self.lib.eod_conv2d_backward_weights_ws(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
+                                                      dw.data_ptr(), db.data_ptr(), ws.data_ptr() if need else None, ws.numel() * 4 if need else 0,
+                                                      _stream()), "eod_conv2d_backward_weights_ws")
         dx = None
         if need_dx and self.same:
             dx = self._dgrad_conv()(g, N, H, W)
+        elif need_dx and self.zero_insert:
+            up = torch.zeros((N, H, W, c.Cout), dtype=torch.float32, device=x.device)
+            up[:, ::c.stride, ::c.stride] = g
+            dx = self._dgrad_conv()(up, N, H, W)
         elif need_dx:
             dx = torch.empty_like(x)
             check(self.lib.eod_conv2d_backward_input(g.data_ptr(), c.w.data_ptr(), c.Kpad, N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,

@@ -412,6 +412,12 @@ int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* 
  * deterministic summation order).  The gradient with respect to x is eod_conv2d of g with the rotated / transposed weights. */
 int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                                 int stride, float* dw, float* db, eod_stream_t stream);
+/* The same with a workspace (>= eod_conv2d_backward_weights_workspace_bytes(...) for the same arguments; 0 bytes: not needed): layers
+ * with few 32 x 32 channel tiles and many positions (the trunk's first stages) cut the positions into up to 64 ranges, one grid slice
+ * each, whose partial results are added in range order by a second launch. */
+size_t eod_conv2d_backward_weights_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride);
+int eod_conv2d_backward_weights_ws(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                   int stride, float* dw, float* db, void* workspace, size_t workspace_bytes, eod_stream_t stream);
 /* Input gradient of a strided convolution (stride >= 2: P6 / P7, timm.py:359-364; g is [N,OH,OW,Cout]), gather form, w = the
  * forward's packed weights [Cout][Kpad]; dx [N,H,W,Cin].  Stride-1 'same' layers use eod_conv2d with the rotated weights instead. */
 int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,

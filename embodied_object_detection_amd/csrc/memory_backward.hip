@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// Weight gradient of the 4-channel stem (tap layout: packed k = (ky, kx, ci), ci < 4; timm.py:279): Cin is too narrow for the
-// matrix-core tiles above.  Workgroup = one tap x 16 output channels; its 16 waves take every 16th output position, lane =
+// Weight gradient of a 4-channel layer whose kernel rows are wider than 8 taps (fallback; the stem, timm.py:279, takes the MFMA
+// kernel below): tap layout, packed k = (ky, kx, ci), ci < 4.  Workgroup = one tap x 16 output channels; its 16 waves take every 16th output position, lane =
 // (co, ci); the 16 partial sums are added in wave order through LDS (deterministic).  Tap 0's workgroups also write db.
 __global__ __launch_bounds__(1024) void conv_backward_weights_tap4_kernel(ConvBwdArgs a) {
   __shared__ float part[16][64];
@@ -307,6 +307,85 @@ __global__ __launch_bounds__(1024) void conv_backward_weights_tap4_kernel(ConvBw
       for (int i = 0; i < 16; ++i) sb += partb[i][col];
       db[co0 + col] = sb;
     }
+  }
+}
+
+// The stem's weight gradient on the matrix cores (KW * 4 <= 32): for one kernel row ky the packed columns (kx, ci) of an output
+// position are KW * 4 CONSECUTIVE floats of the 4-channel image row, so a workgroup owns a 32 (co) x 32 (kx, ci) tile of one ky and
+// contracts over the positions exactly like conv_backward_weights_kernel (columns >= KW * 4 are computed and dropped).
+__global__ __launch_bounds__(256) void conv_backward_weights_tap4_mfma_kernel(ConvBwdArgs a) {
+  const int tile = blockIdx.x;                       // (co tile, ky)
+  const int co0 = (tile / a.KH) * 32, ky = tile % a.KH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int kx = col >> 2;
+  const bool col_live = kx < a.KW;
+  const int P = a.N * a.OH * a.OW;
+  const int steps = (P + 7) / 8;
+  const int sps = (steps + a.splits - 1) / a.splits;
+  const int z_begin = blockIdx.z * sps;
+  const int z_end = min(z_begin + sps, steps);
+  const int spw = (sps + 3) / 4;
+  const int s_begin = z_begin + wave * spw;
+  int s_end = s_begin + spw;
+  if (s_end > z_end) s_end = z_end;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = s * 8 + 2 * t + kh;
+      float gv = 0.f, xv = 0.f;
+      if (pos < P) {
+        gv = a.g[(size_t)pos * a.Cout + co0 + col];
+        const int row = (int)fdiv((unsigned)pos, a.div_w);
+        const int ox = pos - row * a.OW;
+        const int n = (int)fdiv((unsigned)row, a.div_h);
+        const int oy = row - n * a.OH;
+        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+        if (col_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          xv = a.x[((size_t)(n * a.H + iy) * a.W + ix) * 4 + (col & 3)];
+      }
+      av[t] = gv;
+      bv[t] = xv;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      bsum += av[t];
+    }
+  }
+  __shared__ float red[3 * 16 * 64];
+  __shared__ float bred[4 * 64];
+  bred[wave * 64 + lane] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
+  const int Ktot = a.KH * a.KW * 4;
+  float* dw = a.splits > 1 ? a.part + (size_t)blockIdx.z * a.Cout * Ktot : a.dw;
+  float* db = a.splits > 1 ? a.bpart + (size_t)blockIdx.z * a.Cout : a.db;
+  if (col_live) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      dw[(size_t)co * Ktot + ky * a.KW * 4 + col] = acc[r];
+    }
+  }
+  if (a.db && ky == 0 && lane < 32) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += bred[w * 64 + lane] + bred[w * 64 + 32 + lane];
+    db[co0 + lane] = v;
   }
 }
 
@@ -444,9 +523,10 @@ static int conv_bwd_args(ConvBwdArgs& a, int N, int H, int W, int Cin, int Cout,
 static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   const long P = (long)N * OH * OW;
-  const long wgs = Cin == 4 ? (long)KH * KW * (Cout >> 4) : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
-  long s = Cin == 4 ? 16 : (768 + wgs - 1) / wgs;                // the stem's kernel is latency-bound per thread: more, shorter ranges
-  const long cap = Cin == 4 ? P / 2048 : (P + 7) / 8 / 16;
+  const bool tap4_scalar = Cin == 4 && KW > 8;                    // wider kernel rows than a 32-column tile: the scalar kernel
+  const long wgs = Cin == 4 ? (tap4_scalar ? (long)KH * KW * (Cout >> 4) : (long)(Cout >> 5) * KH) : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
+  long s = tap4_scalar ? 16 : (768 + wgs - 1) / wgs;
+  const long cap = tap4_scalar ? P / 2048 : (P + 7) / 8 / 16;
   if (s > cap) s = cap;
   if (s > 64) s = 64;
   return s < 1 ? 1 : (int)s;
@@ -477,7 +557,9 @@ static int conv2d_backward_weights_impl(const float* x, const float* g, int N, i
       a.bpart = a.part + (size_t)a.splits * n;
     }
   }
-  if (Cin == 4)
+  if (Cin == 4 && KW <= 8)
+    hipLaunchKernelGGL(conv_backward_weights_tap4_mfma_kernel, dim3((Cout >> 5) * KH, 1, a.splits), dim3(256), 0, (hipStream_t)stream, a);
+  else if (Cin == 4)
     hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4, a.splits), dim3(1024), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW, a.splits), dim3(256), 0, (hipStream_t)stream, a);

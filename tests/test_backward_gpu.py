@@ -858,3 +858,34 @@ def test_proposal_trainer_steps_like_torch_and_reduces_the_loss(synthetic_sd):
     out = model([[SyntheticSequence(0, H=H, W=W, n_frames=1).frame(0)]])
     assert len(out) == 1 and "instances" in out[0]
     print("proposal trainer: total loss %.4f -> %.4f after 8 steps at lr %.0e" % (first, last, lr))
+
+
+def test_four_channel_weight_gradient_kernels_match_autograd():
+    """Weight gradient of 4-channel (tap layout) layers against autograd: the stem's 7x7 stride-2 form on the matrix cores (odd image
+    sizes, two images, position ranges through the workspace and the single-range form of the plain entry point) and the scalar
+    fallback for kernel rows wider than 8 taps."""
+    import ctypes as C
+    from embodied_object_detection_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(111)
+    for (kh, k, stride, pad, H, W) in ((7, 7, 2, 3, 37, 45), (7, 7, 2, 3, 128, 160), (3, 9, 1, 1, 20, 24)):
+        w = (torch.randn((64, 3, kh, k), generator=g) * 0.1).requires_grad_()
+        b = torch.zeros(64, requires_grad=True)
+        x = torch.randn((2, 3, H, W), generator=g)
+        y = F.conv2d(x, w, b, stride=stride, padding=pad)
+        go = torch.randn(y.shape, generator=g)
+        (y * go).sum().backward()
+        ref = F.pad(w.grad.permute(0, 2, 3, 1), (0, 1)).reshape(64, -1)
+        conv = ops.Conv(w.detach(), b.detach(), stride=stride, pad=pad, device=dev, cin_pad=4)
+        x4 = F.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+        gd = go.permute(0, 2, 3, 1).contiguous().to(dev)
+        o = ops.ConvBackward(conv)(x4, None, gd, need_dx=False)
+        assert float((o["dw"].cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, H, W)
+        assert float((o["db"].cpu() - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()), (k, H, W)
+        # the entry point without a workspace: one position range
+        dw = torch.empty_like(o["dw"])
+        db = torch.empty_like(o["db"])
+        _lib.check(lib.eod_conv2d_backward_weights(x4.data_ptr(), gd.data_ptr(), 2, H, W, 4, 64, kh, k, pad, stride, dw.data_ptr(), db.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), "wgrad")
+        assert float((dw.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, H, W)

@@ -119,6 +119,8 @@ def get_cfg() -> CfgNode:
             "ROI_HEADS": {
                 "NAME": "Res5ROIHeads", "NUM_CLASSES": 80, "IN_FEATURES": ["res4"], "SCORE_THRESH_TEST": 0.05, "NMS_THRESH_TEST": 0.5,
                 "IOU_THRESHOLDS": [0.5], "MASK_WEIGHT": 1.0, "ONE_CLASS_PER_PROPOSAL": False,
+                # detectron2 defaults read by the training forward (label_and_sample_proposals)
+                "BATCH_SIZE_PER_IMAGE": 512, "POSITIVE_FRACTION": 0.25, "PROPOSAL_APPEND_GT": True,
             },
             "ROI_BOX_HEAD": {
                 "NAME": "", "NUM_FC": 0, "FC_DIM": 1024, "NUM_CONV": 0, "CONV_DIM": 256, "POOLER_RESOLUTION": 14,
@@ -128,6 +130,7 @@ def get_cfg() -> CfgNode:
                 "ZEROSHOT_WEIGHT_DIM": 512, "NORM_WEIGHT": True, "NORM_TEMP": 50.0, "IGNORE_ZERO_CATS": False, "USE_BIAS": 0.0,
                 "MULT_PROPOSAL_SCORE": False, "USE_SIGMOID_CE": False, "PRIOR_PROB": 0.01, "ADD_FEATURE_TO_PROP": False,
                 "ADD_IMAGE_BOX": False, "IMAGE_BOX_SIZE": 1.0, "WS_NUM_PROPS": 128,
+                "SMOOTH_L1_BETA": 0.0, "BBOX_REG_LOSS_TYPE": "smooth_l1", "BBOX_REG_LOSS_WEIGHT": 1.0, "USE_FED_LOSS": False,
             },
             "ROI_BOX_CASCADE_HEAD": {
                 "BBOX_REG_WEIGHTS": ((10.0, 10.0, 5.0, 5.0), (20.0, 20.0, 10.0, 10.0), (30.0, 30.0, 15.0, 15.0)),

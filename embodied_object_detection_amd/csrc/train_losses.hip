@@ -398,3 +398,200 @@ extern "C" int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t st
   hipLaunchKernelGGL(centernet_loss_pos_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, blocks);
   return eod_launch_status();
 }
+
+// ==================================================================================================================================
+// The ROI heads' half of the training forward (custom_rcnn.py:642-650 -> detic_roi_heads.py:226-240,88-147): what stands between the
+// proposals and `eod_fast_rcnn_loss`.
+//  * match_label_kernel: detectron2's `pairwise_iou` + `Matcher([thr], [0, 1], allow_low_quality_matches=False)` + the labelling of
+//    `ROIHeads._sample_proposals` / `CascadeROIHeads._match_and_label_boxes` (called at detic_roi_heads.py:232,115): every proposal
+//    takes the FIRST ground-truth box of maximal IoU (torch.max(dim=0)), is foreground iff that IoU >= the stage's threshold, and
+//    carries the matched box and its class (background = num_classes).  One thread per proposal, the ground-truth boxes staged
+//    through LDS 256 at a time; no fused multiply-adds, so that every IoU is the reference's fp32 value and the >= decides alike.
+//  * sample_proposals_kernel: `subsample_labels` (called through `label_and_sample_proposals`, detic_roi_heads.py:232) as a
+//    selection by random KEYS: of the foreground rows the min(int(batch * fraction), #fg) with the smallest (key, row), of the
+//    background rows the min(batch - that, #bg) smallest; foreground rows first, each class in ascending row order.  With
+//    independent uniform keys this is the uniform random subset the reference draws with torch.randperm (its RNG stream itself is
+//    not reproducible across devices); one workgroup, keys and kinds in LDS, rank by counting.
+//  * zs_logits_kernel: DeticFastRCNNOutputLayers.forward's `scores` (detic_fast_rcnn.py:437-466 -> zero_shot_classifier.py:71-111,
+//    NORM_WEIGHT, USE_BIAS 0): logits = temp * normalize(feat) . zs_weight, the value `zs_classify_kernel` (heads.hip) feeds its
+//    sigmoid, with that kernel's lane ownership and summation order -- but written out, for any number of classes.
+// Integer / index work + a [B,512] x [512,C1] product: launch-latency bound at these sizes (R <= 8192, B <= 512).
+// ==================================================================================================================================
+namespace {
+
+struct MatchArgs {
+  const float* boxes; int R;
+  const float* gtb; const int* gtc; int G;
+  float thr; int C;
+  int* matched; float* iou; int* cls; float* out_gtb;
+};
+
+__global__ __launch_bounds__(256) void match_label_kernel(MatchArgs a) {
+#pragma clang fp contract(off)
+  __shared__ float g[256 * 5];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f, barea = 0.f;
+  if (i < a.R) {
+    bx0 = a.boxes[i * 4]; by0 = a.boxes[i * 4 + 1]; bx1 = a.boxes[i * 4 + 2]; by1 = a.boxes[i * 4 + 3];
+    barea = (bx1 - bx0) * (by1 - by0);                                   // Boxes.area
+  }
+  float best = -1.f;
+  int bi = 0;
+  for (int base = 0; base < a.G; base += 256) {
+    const int n = a.G - base < 256 ? a.G - base : 256;
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      const float* p = a.gtb + (size_t)(base + threadIdx.x) * 4;
+      const float x0 = p[0], y0 = p[1], x1 = p[2], y1 = p[3];
+      float* q = g + threadIdx.x * 5;
+      q[0] = x0; q[1] = y0; q[2] = x1; q[3] = y1; q[4] = (x1 - x0) * (y1 - y0);
+    }
+    __syncthreads();
+    if (i < a.R) {
+      for (int j = 0; j < n; ++j) {
+        const float* q = g + j * 5;
+        float w = fminf(q[2], bx1) - fmaxf(q[0], bx0);                     // pairwise_intersection: min of the maxima - max of the minima
+        float h = fminf(q[3], by1) - fmaxf(q[1], by0);
+        w = fmaxf(w, 0.f); h = fmaxf(h, 0.f);                              // clamp_(min=0)
+        const float inter = w * h;
+        float v = 0.f;
+        if (inter > 0.f) {                                                 // torch.where(inter > 0, inter / (area1 + area2 - inter), 0)
+          const float s = q[4] + barea;
+          v = inter / (s - inter);
+        }
+        if (v > best) { best = v; bi = base + j; }                         // first maximum
+      }
+    }
+  }
+  if (i >= a.R) return;
+  if (a.G == 0) {                                                          // Matcher on an empty matrix: match 0, label 0
+    a.matched[i] = 0; a.iou[i] = 0.f; a.cls[i] = a.C;
+    a.out_gtb[i * 4] = 0.f; a.out_gtb[i * 4 + 1] = 0.f; a.out_gtb[i * 4 + 2] = 0.f; a.out_gtb[i * 4 + 3] = 0.f;
+    return;
+  }
+  a.matched[i] = bi;
+  a.iou[i] = best;
+  a.cls[i] = best >= a.thr ? a.gtc[bi] : a.C;
+  const float* p = a.gtb + (size_t)bi * 4;
+  a.out_gtb[i * 4] = p[0]; a.out_gtb[i * 4 + 1] = p[1]; a.out_gtb[i * 4 + 2] = p[2]; a.out_gtb[i * 4 + 3] = p[3];
+}
+
+#define SAMPLE_MAX_R 8192
+struct SampleArgs {
+  const int* cls; const float* keys;
+  int R, C, batch, max_pos;
+  int* sampled; int* counts;
+};
+
+__global__ __launch_bounds__(1024) void sample_proposals_kernel(SampleArgs a) {
+  __shared__ float key[SAMPLE_MAX_R];
+  __shared__ unsigned char kind[SAMPLE_MAX_R];      // 0: ignored (-1), 1: foreground, 2: background; bit 2: sampled
+  __shared__ int tot[2];
+  const int tid = threadIdx.x;
+  if (tid < 2) tot[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < a.R; i += 1024) {
+    const int c = a.cls[i];
+    const unsigned char k = c == a.C ? 2 : (c != -1 ? 1 : 0);            // subsample_labels: (labels != -1) & (labels != bg) / labels == bg
+    key[i] = a.keys[i];
+    kind[i] = k;
+    if (k) atomicAdd(&tot[k - 1], 1);
+  }
+  __syncthreads();
+  const int n_pos = tot[0] < a.max_pos ? tot[0] : a.max_pos;
+  const int n_neg = tot[1] < a.batch - n_pos ? tot[1] : a.batch - n_pos;
+  unsigned keep = 0;                                                      // bit q: row tid + 1024 q is sampled
+  for (int i = tid, q = 0; i < a.R; i += 1024, ++q) {
+    const unsigned char k = kind[i];
+    if (!k) continue;
+    const float ki = key[i];
+    int rank = 0;
+    for (int j = 0; j < a.R; ++j) {
+      const float kj = key[j];
+      rank += (kind[j] == k && (kj < ki || (kj == ki && j < i))) ? 1 : 0;
+    }
+    if (rank < (k == 1 ? n_pos : n_neg)) keep |= 1u << q;
+  }
+  __syncthreads();
+  for (int i = tid, q = 0; i < a.R; i += 1024, ++q)
+    if (keep >> q & 1u) kind[i] |= 4;
+  __syncthreads();
+  for (int i = tid, q = 0; i < a.R; i += 1024, ++q) {
+    if (!(keep >> q & 1u)) continue;
+    const unsigned char k = kind[i];
+    int slot = 0;
+    for (int j = 0; j < i; ++j) slot += kind[j] == k ? 1 : 0;
+    a.sampled[((k & 3) == 1 ? 0 : n_pos) + slot] = i;
+  }
+  if (tid == 0) { a.counts[0] = n_pos; a.counts[1] = n_pos + n_neg; }
+}
+
+// one wave per row; lane owns channels [8 lane, 8 lane + 8) as in zs_classify_kernel (D = 512)
+__global__ __launch_bounds__(256) void zs_logits_kernel(const float* __restrict__ feat, const float* __restrict__ zs, int B, int C1,
+                                                         float temp, float* __restrict__ logits, int ld, float* __restrict__ featn_out) {
+  const int D = 512;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = feat[(size_t)row * D + lane * 8 + q];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ss += x[q] * x[q];
+  ss = wave_reduce_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);                            // F.normalize eps
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = temp * (x[q] / denom);
+  if (featn_out) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) featn_out[(size_t)row * D + lane * 8 + q] = x[q];
+  }
+  for (int c0 = 0; c0 < C1; c0 += 64) {
+    const int n = C1 - c0 < 64 ? C1 - c0 : 64;
+    float mine = 0.f;
+    for (int c = 0; c < n; ++c) {
+      const float* w = zs + (size_t)(lane * 8) * C1 + c0 + c;            // zs_weight [D, C1]
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += x[q] * w[(size_t)q * C1];
+      s = wave_reduce_sum(s);
+      if (lane == c) mine = s;
+    }
+    if (lane < n) logits[(size_t)row * ld + c0 + lane] = mine;
+  }
+}
+
+}  // namespace
+
+extern "C" int eod_match_label(const float* boxes, int R, const float* gt_boxes, const int32_t* gt_classes, int G, float iou_thresh,
+                               int num_classes, int32_t* matched_idx, float* matched_iou, int32_t* out_classes, float* out_gt_boxes,
+                               eod_stream_t stream) {
+  if (!boxes || !matched_idx || !matched_iou || !out_classes || !out_gt_boxes) return EOD_ERR_NULL;
+  if (G > 0 && (!gt_boxes || !gt_classes)) return EOD_ERR_NULL;
+  if (R <= 0 || G < 0 || num_classes <= 0 || !(iou_thresh >= 0.f && iou_thresh <= 1.f)) return EOD_ERR_BAD_DIMS;
+  MatchArgs a{boxes, R, gt_boxes, gt_classes, G, iou_thresh, num_classes, matched_idx, matched_iou, out_classes, out_gt_boxes};
+  hipLaunchKernelGGL(match_label_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_sample_proposals(const int32_t* classes, const float* keys, int R, int num_classes, int batch_size_per_image,
+                                    float positive_fraction, int32_t* sampled_idx, int32_t* counts, eod_stream_t stream) {
+  if (!classes || !keys || !sampled_idx || !counts) return EOD_ERR_NULL;
+  if (R <= 0 || num_classes <= 0 || batch_size_per_image <= 0 || !(positive_fraction >= 0.f && positive_fraction <= 1.f))
+    return EOD_ERR_BAD_DIMS;
+  if (R > SAMPLE_MAX_R) return EOD_ERR_CAPACITY;
+  SampleArgs a{classes, keys, R, num_classes, batch_size_per_image, (int)((double)batch_size_per_image * (double)positive_fraction),
+               sampled_idx, counts};
+  hipLaunchKernelGGL(sample_proposals_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_zs_logits(const float* feat, const float* zs_weight, int B, int D, int C1, float temp, float* logits, int ld,
+                             float* featn_out, eod_stream_t stream) {
+  if (!feat || !zs_weight || !logits) return EOD_ERR_NULL;
+  if (B <= 0 || D != 512 || C1 < 1 || ld < C1) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(zs_logits_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs_weight, B, C1, temp, logits, ld,
+                     featn_out);
+  return eod_launch_status();
+}

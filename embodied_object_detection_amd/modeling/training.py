@@ -232,3 +232,92 @@ class ProposalTrainer:
             f()
         self.iteration += 1
         return losses
+
+
+class DetectorTraining:
+    """The ROI heads' half of `forward_model`, forward (custom_rcnn.py:642-650 -> `DeticCascadeROIHeads.forward` in training mode,
+    detic_roi_heads.py:226-249 with ann_type 'box'): `label_and_sample_proposals` (ground truth appended, IoU matching, 512 rows at
+    1/4 foreground), then per cascade stage ROIAlign(7) -> box head -> predictor -> `DeticFastRCNNOutputLayers.losses`, the next
+    stage's proposals = the refined boxes, clipped, empty ones dropped, re-matched at the stage's IoU (`_match_and_label_boxes`,
+    :115).  The MP3D loader carries no `gt_masks`, so the mask branch is `_get_empty_mask_loss` (:246-249): loss_mask = 0.
+
+    Runs on the layers of the inference path (`roi_heads.stages`): matching / sampling / logits / losses are the kernels of
+    `csrc/train_losses.hip`, the rest the hot path's ROIAlign and GEMMs at N = the sampled row count.  Also returns each stage's
+    loss gradients w.r.t. the predictor outputs (d scores, d deltas) and keeps the activations a backward pass needs.  The
+    proposals are an input: the reference draws them with PRE/POST_NMS_TOPK_TRAIN 4000 / 2000, beyond the capacity of the
+    inference-sized selection kernels (8192 candidate slots, 512 kept)."""
+
+    def __init__(self, model):
+        cfg = model.cfg
+        self.model, self.dev, self.rh = model, model.device, model.roi_heads
+        rhc, rb = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+        self.ious = tuple(float(v) for v in cfg.MODEL.ROI_BOX_CASCADE_HEAD.IOUS)
+        if len(self.ious) != self.rh.num_stages or self.ious[0] != float(rhc.IOU_THRESHOLDS[0]):
+            raise ValueError("ROI_BOX_CASCADE_HEAD.IOUS: one IoU per stage, the first equal to ROI_HEADS.IOU_THRESHOLDS[0] "
+                             "(detectron2 CascadeROIHeads.from_config)")
+        if bool(rb.USE_FED_LOSS) or bool(rb.IGNORE_ZERO_CATS):
+            raise NotImplementedError("federated loss / zero-frequency categories need the LVIS frequency file (not on the MP3D path)")
+        if str(rb.BBOX_REG_LOSS_TYPE) != "smooth_l1":
+            raise NotImplementedError("ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE: smooth_l1 (the recurrent yaml)")
+        self.batch, self.frac = int(rhc.BATCH_SIZE_PER_IMAGE), float(rhc.POSITIVE_FRACTION)
+        self.append_gt = bool(rhc.PROPOSAL_APPEND_GT)
+        self.beta, self.box_w = float(rb.SMOOTH_L1_BETA), float(rb.BBOX_REG_LOSS_WEIGHT)
+        self.C = self.rh.num_classes
+        self.last = None
+
+    def label_and_sample(self, prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, keys: Optional[torch.Tensor] = None,
+                         generator: Optional[torch.Generator] = None):
+        """detic_roi_heads.py:232 -> (boxes [B,4], classes int32 [B], matched gt boxes [B,4], sampled rows int64 [B])."""
+        boxes = torch.cat([prop_boxes, gt_boxes]).contiguous() if self.append_gt else prop_boxes.contiguous()
+        _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[0], self.C)
+        if keys is None:
+            keys = torch.rand((boxes.shape[0],), device=self.dev, generator=generator)
+        idx, counts = ops.sample_proposals(cls, keys, self.C, self.batch, self.frac)
+        n = int(counts.cpu()[1])                                   # the reference's nonzero() / randperm sizes
+        rows = idx[:n].long()
+        return boxes.index_select(0, rows), cls.index_select(0, rows), gtb.index_select(0, rows), rows
+
+    def run_stage(self, P, boxes: torch.Tensor, k: int):
+        """`_run_stage` (:328-349) on B rows -> dict of the stage's activations; logits [B, C+1], deltas [B,4]."""
+        st, B = self.rh.stages[k], int(boxes.shape[0])
+        h3, w3 = int(P[0].shape[1]), int(P[0].shape[2])
+        pool = ops.roi_align(P[0], P[1], P[2], h3, w3, 256, boxes, None, B, 7)
+        h1 = st["fc1"](pool, B, 1, 1, relu=True)
+        h2 = st["fc2"](h1, B, 1, 1, relu=True)
+        feat = st["cls"](h2, B, 1, 1)
+        hb = st["bb0"](h2, B, 1, 1, relu=True)
+        deltas = st["bb2"](hb, B, 1, 1).view(B, 4)
+        featn = torch.empty((B, 512), dtype=torch.float32, device=self.dev)
+        logits = ops.zs_logits(feat, st["zs"], self.rh.norm_temp, featn_out=featn)
+        return dict(boxes=boxes, pool=pool, h1=h1, h2=h2, feat=feat, featn=featn, hb=hb, deltas=deltas, logits=logits)
+
+    def losses(self, P: Sequence[torch.Tensor], prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor,
+               image_hw: Tuple[int, int], keys: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
+        """P: the pyramid's P3..P5 as [1,h,w,256] device tensors; prop_boxes [R,4]; gt_boxes [G,4] fp32, gt_classes int32 [G] ->
+        {loss_cls_stage{k}, loss_box_reg_stage{k}, loss_mask} (device scalars) and the per-stage records (`self.last`)."""
+        H, W = image_hw
+        gt_boxes, gt_classes = gt_boxes.contiguous(), gt_classes.to(torch.int32).contiguous()
+        boxes, cls, gtb, _ = self.label_and_sample(prop_boxes, gt_boxes, gt_classes, keys, generator)
+        out: Dict[str, torch.Tensor] = {}
+        stages = []
+        for k in range(self.rh.num_stages):
+            if k > 0:
+                prev = stages[-1]
+                B0 = int(prev["boxes"].shape[0])
+                nxt = torch.empty((B0, 4), dtype=torch.float32, device=self.dev)
+                ops.apply_deltas(prev["deltas"], 4, prev["boxes"], nxt, None, B0, self.rh.cascade_weights[k - 1], True, float(W), float(H))
+                keep = (nxt[:, 2] - nxt[:, 0] > 0) & (nxt[:, 3] - nxt[:, 1] > 0)          # Boxes.nonempty (:317-319)
+                boxes = nxt if bool(keep.all()) else nxt[keep].contiguous()
+                if boxes.shape[0] == 0:
+                    raise RuntimeError(f"cascade stage {k}: every refined box is empty")
+                _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[k], self.C)
+            rec = self.run_stage(P, boxes, k)
+            l, ds, dd = ops.fast_rcnn_loss(rec["logits"], rec["deltas"], boxes, gtb, cls, self.C, self.rh.cascade_weights[k], None, self.beta)
+            rec.update(classes=cls, gt_boxes=gtb, d_logits=ds, d_deltas=dd)
+            stages.append(rec)
+            out[f"loss_cls_stage{k}"] = l[0]
+            out[f"loss_box_reg_stage{k}"] = l[1] * self.box_w
+        if bool(self.model.cfg.MODEL.MASK_ON):
+            out["loss_mask"] = torch.zeros((), dtype=torch.float32, device=self.dev)
+        self.last = stages
+        return out

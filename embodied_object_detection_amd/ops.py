@@ -747,6 +747,54 @@ def fast_rcnn_loss(scores: torch.Tensor, deltas: torch.Tensor, proposal_boxes: t
     return losses, ds, dd
 
 
+def match_label(boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, iou_thresh: float, num_classes: int):
+    """detectron2's pairwise_iou + Matcher([iou_thresh], [0, 1]) + the labelling of `_sample_proposals` / `_match_and_label_boxes`
+    (called at detic_roi_heads.py:232,115) -> (matched_idx int32 [R], matched_iou [R], classes int32 [R] with background =
+    num_classes, matched gt boxes [R,4]).  gt_boxes [G,4] / gt_classes int32 [G]; G may be 0."""
+    _need_cuda(boxes, gt_boxes, gt_classes)
+    R, G = int(boxes.shape[0]), int(gt_boxes.shape[0])
+    assert boxes.is_contiguous() and boxes.dtype == torch.float32 and tuple(boxes.shape) == (R, 4)
+    assert gt_boxes.is_contiguous() and gt_boxes.dtype == torch.float32 and gt_classes.dtype == torch.int32 and gt_classes.numel() == G
+    dev = boxes.device
+    midx = torch.empty((R,), dtype=torch.int32, device=dev)
+    miou = torch.empty((R,), dtype=torch.float32, device=dev)
+    cls = torch.empty((R,), dtype=torch.int32, device=dev)
+    gtb = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    check(_lib.load().eod_match_label(boxes.data_ptr(), R, gt_boxes.data_ptr() if G else None, gt_classes.data_ptr() if G else None, G,
+                                      float(iou_thresh), num_classes, midx.data_ptr(), miou.data_ptr(), cls.data_ptr(), gtb.data_ptr(),
+                                      _stream()), "eod_match_label")
+    return midx, miou, cls, gtb
+
+
+def sample_proposals(classes: torch.Tensor, keys: torch.Tensor, num_classes: int, batch_size_per_image: int, positive_fraction: float):
+    """detectron2's `subsample_labels` as a selection by random keys (include/eod_hip.h) -> (sampled_idx int32 [batch], counts int32
+    [2] = foreground rows, rows), both on the device."""
+    _need_cuda(classes, keys)
+    R = int(classes.numel())
+    assert classes.dtype == torch.int32 and keys.dtype == torch.float32 and keys.numel() == R
+    idx = torch.zeros((batch_size_per_image,), dtype=torch.int32, device=classes.device)
+    counts = torch.zeros((2,), dtype=torch.int32, device=classes.device)
+    st = _lib.load().eod_sample_proposals(classes.data_ptr(), keys.data_ptr(), R, num_classes, batch_size_per_image,
+                                          float(positive_fraction), idx.data_ptr(), counts.data_ptr(), _stream())
+    if st == -5:
+        raise _lib.EodError(f"eod_sample_proposals: {R} proposals exceed the sampling kernel's capacity of 8192 rows")
+    check(st, "eod_sample_proposals")
+    return idx, counts
+
+
+def zs_logits(feat: torch.Tensor, zs: torch.Tensor, temp: float = 50.0, ld: Optional[int] = None, featn_out: Optional[torch.Tensor] = None):
+    """The training-mode scores of DeticFastRCNNOutputLayers.forward: temp * normalize(feat [B,512]) @ zs [512,C1] -> logits [B, ld]."""
+    _need_cuda(feat, zs, featn_out)
+    B, C1 = int(feat.shape[0]), int(zs.shape[1])
+    feat = feat.view(B, 512)
+    assert feat.is_contiguous() and zs.is_contiguous() and int(zs.shape[0]) == 512
+    ld = C1 if ld is None else ld
+    out = torch.zeros((B, ld), dtype=torch.float32, device=feat.device)
+    check(_lib.load().eod_zs_logits(feat.data_ptr(), zs.data_ptr(), B, 512, C1, float(temp), out.data_ptr(), ld, _ptr(featn_out),
+                                    _stream()), "eod_zs_logits")
+    return out
+
+
 class AdamW:
     """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
     tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).

@@ -250,6 +250,27 @@ int eod_fast_rcnn_loss(const float* scores, int ld, const float* deltas /*[B,4]*
                        float wh, float smooth_l1_beta, float* d_scores, float* d_deltas, float* losses, void* workspace,
                        size_t workspace_bytes, eod_stream_t stream);
 
+/* The ROI heads' half of the training forward (custom_rcnn.py:642-650 -> detic_roi_heads.py:226-240, 88-147): proposal matching,
+ * labelling and sampling, and the classifier's logits -- what stands between the proposals and eod_fast_rcnn_loss.
+ * eod_match_label: detectron2's pairwise_iou + Matcher([iou_thresh], [0, 1]) + the labelling of ROIHeads._sample_proposals /
+ * CascadeROIHeads._match_and_label_boxes (called at detic_roi_heads.py:232 and :115): proposal i takes the first ground-truth box of
+ * maximal IoU; out_classes[i] = its class if that IoU >= iou_thresh, else num_classes (background); out_gt_boxes[i] = the matched box.
+ * G = 0: every proposal is background with a zero box.  Bit-exact with torch's fp32 arithmetic. */
+int eod_match_label(const float* boxes /*[R,4]*/, int R, const float* gt_boxes /*[G,4]*/, const int32_t* gt_classes /*[G]*/, int G,
+                    float iou_thresh, int num_classes, int32_t* matched_idx /*[R]*/, float* matched_iou /*[R]*/,
+                    int32_t* out_classes /*[R]*/, float* out_gt_boxes /*[R,4]*/, eod_stream_t stream);
+/* eod_sample_proposals: detectron2's subsample_labels (through label_and_sample_proposals, detic_roi_heads.py:232) as a selection by
+ * random keys: the min(int(batch * positive_fraction), #foreground) foreground rows and the min(batch - that, #background) background
+ * rows with the smallest (key, row); classes [R] as eod_match_label writes them (-1 = ignored).  sampled_idx [batch]: foreground rows
+ * first, each kind in ascending row order; counts [2] = number of foreground rows, number of rows.  R <= 8192. */
+int eod_sample_proposals(const int32_t* classes, const float* keys /*[R] uniform random*/, int R, int num_classes,
+                         int batch_size_per_image, float positive_fraction, int32_t* sampled_idx, int32_t* counts, eod_stream_t stream);
+/* eod_zs_logits: the scores DeticFastRCNNOutputLayers.forward returns in training (detic_fast_rcnn.py:437-466 with
+ * zero_shot_classifier.py:71-111, NORM_WEIGHT, no bias): logits [B, ld] (columns 0..C1-1) = temp * normalize(feat [B,512]) . zs_weight
+ * [512, C1]; featn_out [B,512] (optional) = the normalised, scaled feature.  Any C1. */
+int eod_zs_logits(const float* feat, const float* zs_weight, int B, int D /*512*/, int C1, float temp, float* logits, int ld,
+                  float* featn_out, eod_stream_t stream);
+
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
   const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */

@@ -179,3 +179,85 @@ def centernet_targets(gt_boxes: torch.Tensor, level_hw, strides=(8, 16, 32, 64, 
         hm[hm < 1e-4] = 0
         heats.append(hm)
     return torch.tensor(pos, dtype=torch.int64), torch.cat(regs), torch.cat(heats)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The ROI heads' half of the training forward: `DeticCascadeROIHeads.forward` / `_forward_box` in training mode with ann_type 'box'
+# (`Detic/detic/modeling/roi_heads/detic_roi_heads.py:226-247, 88-147, 306-326`).  The detectron2 pieces they call are not in the
+# reference tree and are restated from their published definitions ("unpinned", as SURVEY Appendix A says of detectron2):
+# `pairwise_iou` (structures/boxes.py), `Matcher` (modeling/matcher.py), `subsample_labels` (modeling/sampling.py),
+# `add_ground_truth_to_proposals` (modeling/proposal_generator/proposal_utils.py), `ROIHeads.label_and_sample_proposals` /
+# `_sample_proposals` (modeling/roi_heads/roi_heads.py), `CascadeROIHeads._match_and_label_boxes` (modeling/roi_heads/cascade_rcnn.py).
+# The random draw of `subsample_labels` (torch.randperm) is restated as a selection by given random keys: the uniform random subset
+# of the same size (the reference's RNG stream is not reproducible across devices).
+# ----------------------------------------------------------------------------------------------------------------------------------
+def pairwise_iou(boxes1: torch.Tensor, boxes2: torch.Tensor) -> torch.Tensor:
+    """detectron2 `pairwise_iou`: [N,4] x [M,4] -> [N,M]."""
+    area1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    area2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    wh = torch.min(boxes1[:, None, 2:], boxes2[:, 2:]) - torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    wh.clamp_(min=0)
+    inter = wh.prod(dim=2)
+    return torch.where(inter > 0, inter / (area1[:, None] + area2 - inter), torch.zeros(1, dtype=inter.dtype))
+
+
+def match_label(boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, iou_thresh: float, num_classes: int):
+    """Matcher([iou_thresh], [0, 1], allow_low_quality_matches=False) on pairwise_iou(gt, proposals) + the labelling of
+    `_sample_proposals` / `_match_and_label_boxes` -> (matched_idx [R], matched_iou [R], classes [R] (background = num_classes),
+    matched gt boxes [R,4]; zeros without ground truth)."""
+    R = boxes.shape[0]
+    if gt_boxes.shape[0] == 0:
+        return (torch.zeros(R, dtype=torch.int64), torch.zeros(R), torch.full((R,), num_classes, dtype=torch.int64), torch.zeros(R, 4))
+    q = pairwise_iou(gt_boxes, boxes)
+    vals, idx = q.max(dim=0)
+    labels = torch.ones(R, dtype=torch.int8)
+    for lab, low, high in ((0, -float("inf"), iou_thresh), (1, iou_thresh, float("inf"))):
+        labels[(vals >= low) & (vals < high)] = lab
+    cls = gt_classes[idx].clone()
+    cls[labels == 0] = num_classes
+    return idx, vals, cls, gt_boxes[idx]
+
+
+def sample_by_keys(classes: torch.Tensor, keys: torch.Tensor, num_classes: int, batch: int, positive_fraction: float) -> torch.Tensor:
+    """`subsample_labels(classes, batch, positive_fraction, bg_label=num_classes)` with the random subset chosen by smallest key;
+    -> sampled row indices, foreground first, each kind in ascending row order."""
+    pos = torch.nonzero((classes != -1) & (classes != num_classes)).squeeze(1)
+    neg = torch.nonzero(classes == num_classes).squeeze(1)
+    num_pos = min(pos.numel(), int(batch * positive_fraction))
+    num_neg = min(neg.numel(), batch - num_pos)
+
+    def pick(rows, n):
+        order = sorted(rows.tolist(), key=lambda r: (float(keys[r]), r))[:n]
+        return torch.tensor(sorted(order), dtype=torch.int64)
+    return torch.cat([pick(pos, num_pos), pick(neg, num_neg)])
+
+
+GT_PROPOSAL_LOGIT = 23.025850847100816        # add_ground_truth_to_proposals: log((1 - 1e-10) / (1 - (1 - 1e-10)))
+
+
+def cascade_training_losses(feats, prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, sd, cfg, image_hw,
+                            keys: torch.Tensor, ious=(0.6, 0.7, 0.8), batch: int = 512, positive_fraction: float = 0.25,
+                            smooth_l1_beta: float = 0.0, append_gt: bool = True):
+    """`DeticCascadeROIHeads.forward` in training, ann_type 'box', no gt_masks (the MP3D loader provides none:
+    `_get_empty_mask_loss`, detic_roi_heads.py:246-249,297-303) -> ({loss name: scalar}, per-stage intermediates).
+    feats: P3..P5 NCHW; prop_boxes [R,4]; keys [R + G] uniform random (one per proposal after the ground truth is appended)."""
+    from . import model as M, ops as O
+    boxes = torch.cat([prop_boxes, gt_boxes]) if append_gt else prop_boxes          # label_and_sample_proposals (:232)
+    _, _, cls, gtb = match_label(boxes, gt_boxes, gt_classes, ious[0], cfg.num_classes)
+    rows = sample_by_keys(cls, keys, cfg.num_classes, batch, positive_fraction)
+    boxes, cls, gtb = boxes[rows], cls[rows], gtb[rows]
+    losses, stages = {}, []
+    for k in range(3):
+        if k > 0:                                                                   # _create_proposals_from_boxes (:306-326)
+            boxes = O.clip_boxes(boxes, image_hw)
+            keep = (boxes[:, 2] - boxes[:, 0] > 0) & (boxes[:, 3] - boxes[:, 1] > 0)    # Boxes.nonempty
+            boxes = boxes[keep]
+            _, _, cls, gtb = match_label(boxes, gt_boxes, gt_classes, ious[k], cfg.num_classes)     # _match_and_label_boxes (:115)
+        pooled = O.roi_pool(list(feats[:3]), boxes, 7)
+        logits, deltas, _ = M.box_head_stage(pooled, sd, k, cfg)                    # _run_stage (:328-349); _ScaleGradient is the identity forward
+        losses[f"loss_cls_stage{k}"] = sigmoid_cross_entropy_loss(logits, cls)
+        losses[f"loss_box_reg_stage{k}"] = box_reg_loss(boxes, gtb, deltas, cls, cfg.num_classes, M.CASCADE_WEIGHTS[k], smooth_l1_beta)
+        stages.append(dict(boxes=boxes, classes=cls, gt_boxes=gtb, logits=logits, deltas=deltas))
+        boxes = O.apply_deltas(deltas.detach(), boxes, M.CASCADE_WEIGHTS[k])       # predict_boxes (:124)
+    losses["loss_mask"] = torch.zeros(())                                           # _get_empty_mask_loss, MASK_ON
+    return losses, stages

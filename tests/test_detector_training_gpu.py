@@ -1,0 +1,127 @@
+"""Training forward, the ROI heads' half (custom_rcnn.py:642-650 -> detic_roi_heads.py:226-249, 88-147): proposal
+matching / labelling / sampling, the classifier's logits and the cascade's six losses on the HIP kernels against the oracle
+(`oracle/losses.py`: detectron2's pairwise_iou / Matcher / subsample_labels / _match_and_label_boxes restated, Detic's
+`_forward_box` training branch and `DeticFastRCNNOutputLayers.losses`).  Index work is compared bit for bit."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as OL
+from oracle import model as M
+
+
+def _boxes(g, n_gt, n_rand, W=640.0, H=640.0):
+    xy = torch.rand((n_gt, 2), generator=g) * torch.tensor([W * 0.8, H * 0.8])
+    wh = torch.rand((n_gt, 2), generator=g) * 150 + 6
+    gt = torch.cat([xy, torch.minimum(xy + wh, torch.tensor([W, H]))], dim=1)
+    near = gt.repeat(6, 1) + torch.randn((6 * n_gt, 4), generator=g) * (gt[:, 2:] - gt[:, :2]).repeat(6, 2) * 0.06
+    rxy = torch.rand((n_rand, 2), generator=g) * torch.tensor([W * 0.9, H * 0.9])
+    rwh = torch.rand((n_rand, 2), generator=g) * 200 + 2
+    rand = torch.cat([rxy, rxy + rwh], dim=1)
+    props = torch.cat([near, rand, gt[: n_gt // 2]])                       # exact copies: IoU 1, and ties between duplicate objects
+    return gt.contiguous(), props[torch.randperm(props.shape[0], generator=g)].contiguous()
+
+
+@pytest.mark.parametrize("n_gt,n_rand,thr", [(24, 1500, 0.6), (300, 700, 0.7), (1, 63, 0.8), (0, 100, 0.6)])
+def test_match_label_bit_exact(n_gt, n_rand, thr):
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 + n_gt)
+    gt, props = _boxes(g, n_gt, n_rand)
+    if n_gt >= 24:
+        gt[5] = gt[2]                                                      # two identical objects: the FIRST maximum wins
+    gc = torch.randint(0, 20, (n_gt,), generator=g)
+    ridx, riou, rcls, rgtb = OL.match_label(props, gt, gc, thr, 20)
+    midx, miou, cls, gtb = ops.match_label(props.to(dev), gt.to(dev), gc.int().to(dev), thr, 20)
+    assert torch.equal(midx.cpu().long(), ridx)
+    assert torch.equal(miou.cpu(), riou), float((miou.cpu() - riou).abs().max())
+    assert torch.equal(cls.cpu().long(), rcls)
+    assert torch.equal(gtb.cpu(), rgtb)
+    if n_gt:
+        assert int((rcls < 20).sum()) >= n_gt // 2 and int((rcls == 20).sum()) > 0      # both kinds present
+
+
+@pytest.mark.parametrize("R,n_fg,batch,ties", [(2300, 400, 512, False), (2300, 40, 512, True), (300, 10, 512, False), (8192, 3000, 512, True),
+                                               (64, 0, 16, False)])
+def test_sample_proposals_matches_oracle(R, n_fg, batch, ties):
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(R + n_fg)
+    cls = torch.full((R,), 20, dtype=torch.int64)
+    perm = torch.randperm(R, generator=g)
+    cls[perm[:n_fg]] = torch.randint(0, 20, (n_fg,), generator=g)
+    cls[perm[n_fg:n_fg + R // 50]] = -1                                    # ignored rows (a Matcher with three labels would emit them)
+    keys = torch.rand((R,), generator=g)
+    if ties:
+        keys = (keys * 64).floor() / 64                                    # many equal keys: the row index breaks the tie
+    ref = OL.sample_by_keys(cls, keys, 20, batch, 0.25)
+    idx, counts = ops.sample_proposals(cls.int().to(dev), keys.to(dev), 20, batch, 0.25)
+    n_pos, n = counts.cpu().tolist()
+    assert n == ref.numel() and n_pos == min(n_fg, batch // 4)
+    assert torch.equal(idx.cpu()[:n].long(), ref)
+    with pytest.raises(Exception):
+        ops.sample_proposals(torch.zeros(8193, dtype=torch.int32, device=dev), torch.zeros(8193, device=dev), 20, batch, 0.25)
+
+
+@pytest.mark.parametrize("B,C1", [(77, 21), (512, 1204)])
+def test_zs_logits_match_oracle(B, C1):
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B)
+    feat = torch.randn((B, 512), generator=g) * 3
+    feat[3] = 0                                                            # F.normalize's eps row
+    zs = F.normalize(torch.randn((512, C1), generator=g), dim=0)
+    ref = torch.mm(50.0 * F.normalize(feat, p=2, dim=1), zs)
+    featn = torch.empty((B, 512), device=dev)
+    out = ops.zs_logits(feat.to(dev), zs.to(dev), 50.0, ld=C1 + 3, featn_out=featn)
+    assert float((out.cpu()[:, :C1] - ref).abs().max()) <= 2e-5 * 50
+    assert float(out.cpu()[:, C1:].abs().max()) == 0.0
+    assert float((featn.cpu() - 50.0 * F.normalize(feat, p=2, dim=1)).abs().max()) <= 1e-5
+    if C1 <= 24:                                                           # the inference kernel's sigmoid sees these logits
+        prob = torch.zeros((B, C1), device=dev)
+        ops.zs_classify(feat.to(dev).contiguous(), zs.to(dev), prob, False, None, None, B, C1, 50.0)
+        assert float((prob.cpu() - torch.sigmoid(out.cpu()[:, :C1])).abs().max()) <= 1e-6
+
+
+def test_cascade_training_losses_match_oracle(synthetic_sd):
+    """`DeticCascadeROIHeads.forward` in training (ann_type 'box', no gt_masks) on one image: the six stage losses + loss_mask, the
+    sampled rows, every stage's row count and labels, against the oracle on the same features, proposals and random keys."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import DetectorTraining
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory"])
+    model = build_model(cfg, synthetic_sd)
+    det = DetectorTraining(model)
+    assert det.ious == (0.6, 0.7, 0.8) and det.batch == 512 and det.frac == 0.25 and det.append_gt
+    H, W = 256, 320
+    g = torch.Generator().manual_seed(29)
+    gt, props = _boxes(g, 12, 900, W=float(W), H=float(H))
+    gc = torch.randint(0, 20, (12,), generator=g)
+    feats = [torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) * 0.5 for l in range(3)]
+    keys = torch.rand((props.shape[0] + gt.shape[0],), generator=g)
+    ocfg = M.OracleCfg()
+    with torch.no_grad():
+        ref, rstages = OL.cascade_training_losses(feats, props, gt, gc, synthetic_sd, ocfg, (H, W), keys)
+    P = [f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats]
+    out = det.losses(P, props.to(dev), gt.to(dev), gc.to(dev), (H, W), keys=keys.to(dev))
+    torch.cuda.synchronize()
+    assert set(out) == set(ref) and float(out["loss_mask"]) == 0.0
+    for k in range(3):
+        mine, theirs = det.last[k], rstages[k]
+        assert mine["boxes"].shape[0] == theirs["boxes"].shape[0], k
+        if k == 0:
+            assert torch.equal(mine["boxes"].cpu(), theirs["boxes"]) and torch.equal(mine["classes"].cpu().long(), theirs["classes"])
+        flips = int((mine["classes"].cpu().long() != theirs["classes"]).sum())        # a refined box within rounding of the stage's IoU
+        assert flips <= 1, (k, flips)
+        tol = 1e-4 if flips == 0 else 1e-2
+        assert float((mine["boxes"].cpu() - theirs["boxes"]).abs().max()) <= 1e-3, k
+        assert float((mine["logits"].cpu() - theirs["logits"]).abs().max()) <= 5e-3, k     # logits of scale 50
+        assert float((mine["deltas"].cpu() - theirs["deltas"]).abs().max()) <= 1e-4 * max(1.0, float(theirs["deltas"].abs().max())), k
+        for name in (f"loss_cls_stage{k}", f"loss_box_reg_stage{k}"):
+            a, b = float(out[name]), float(ref[name])
+            assert abs(a - b) <= tol * max(abs(b), 1e-3), (name, a, b)
+    # the stage-0 sample: 512 rows, a quarter foreground when there are enough (12 objects x 6 near copies + the objects themselves)
+    c0 = rstages[0]["classes"]
+    assert c0.numel() == 512 and 12 <= int((c0 < 20).sum()) <= 128

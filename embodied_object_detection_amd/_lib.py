@@ -136,6 +136,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_sample_proposals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_zs_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eod_zs_logits_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                         C.c_void_p]),
     "eod_centernet_targets": (C.c_int, [C.POINTER(EodCenterNetTargetDesc), C.c_void_p]),
     "eod_unique_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -562,6 +562,42 @@ __global__ __launch_bounds__(256) void zs_logits_kernel(const float* __restrict_
   }
 }
 
+// backward of zs_logits_kernel with respect to the feature (the class matrix is a buffer, zero_shot_classifier.py:54): with
+// n = max(|f|, eps), u = f / n and g = temp * d_logits . zs^T:  d f = (g - u (u . g)) / n  (|f| > eps; below it the clamp's gradient is 0
+// and d f = g / eps, as F.normalize's autograd gives).  Same row / lane ownership as the forward.
+__global__ __launch_bounds__(256) void zs_logits_backward_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
+                                                                  const float* __restrict__ d_logits, int ld, int B, int C1, float temp,
+                                                                  float* __restrict__ d_feat) {
+  const int D = 512;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float u[8], g[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { u[q] = feat[(size_t)row * D + lane * 8 + q]; g[q] = 0.f; }
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ss += u[q] * u[q];
+  ss = wave_reduce_sum(ss);
+  const float norm = sqrtf(ss);
+  const float denom = fmaxf(norm, 1e-12f);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) u[q] = u[q] / denom;
+  for (int c = 0; c < C1; ++c) {
+    const float dl = d_logits[(size_t)row * ld + c];
+    const float* w = zs + (size_t)(lane * 8) * C1 + c;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] += dl * w[(size_t)q * C1];
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { g[q] *= temp; dot += g[q] * u[q]; }
+  dot = wave_reduce_sum(dot);
+  const bool clamped = !(norm > 1e-12f);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) d_feat[(size_t)row * D + lane * 8 + q] = (clamped ? g[q] : g[q] - u[q] * dot) / denom;
+}
+
 }  // namespace
 
 extern "C" int eod_match_label(const float* boxes, int R, const float* gt_boxes, const int32_t* gt_classes, int G, float iou_thresh,
@@ -593,5 +629,14 @@ extern "C" int eod_zs_logits(const float* feat, const float* zs_weight, int B, i
   if (B <= 0 || D != 512 || C1 < 1 || ld < C1) return EOD_ERR_BAD_DIMS;
   hipLaunchKernelGGL(zs_logits_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs_weight, B, C1, temp, logits, ld,
                      featn_out);
+  return eod_launch_status();
+}
+
+extern "C" int eod_zs_logits_backward(const float* feat, const float* zs_weight, const float* d_logits, int ld, int B, int D, int C1,
+                                      float temp, float* d_feat, eod_stream_t stream) {
+  if (!feat || !zs_weight || !d_logits || !d_feat) return EOD_ERR_NULL;
+  if (B <= 0 || D != 512 || C1 < 1 || ld < C1) return EOD_ERR_BAD_DIMS;
+  hipLaunchKernelGGL(zs_logits_backward_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs_weight, d_logits, ld, B, C1,
+                     temp, d_feat);
   return eod_launch_status();
 }

@@ -264,6 +264,14 @@ class DetectorTraining:
         self.beta, self.box_w = float(rb.SMOOTH_L1_BETA), float(rb.BBOX_REG_LOSS_WEIGHT)
         self.C = self.rh.num_classes
         self.last = None
+        # bbox_pred.2 (1024 -> 4) in a 32-row tile, the weight-gradient kernel's tile width (as the proposal head's 5-channel output conv)
+        self.bb2_32 = []
+        for st in self.rh.stages:
+            c = st["bb2"]
+            w, b = torch.zeros((32, c.Cin)), torch.zeros((32,))
+            w[:c.Cout], b[:c.Cout] = c.w[:, :c.Cin].cpu(), c.bias.cpu()
+            self.bb2_32.append(ops.Conv(w[:, :, None, None], b, device=self.dev, name=c.name))
+        self._bw: Dict[int, ops.ConvBackward] = {}
 
     def label_and_sample(self, prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, keys: Optional[torch.Tensor] = None,
                          generator: Optional[torch.Generator] = None):
@@ -286,7 +294,7 @@ class DetectorTraining:
         h2 = st["fc2"](h1, B, 1, 1, relu=True)
         feat = st["cls"](h2, B, 1, 1)
         hb = st["bb0"](h2, B, 1, 1, relu=True)
-        deltas = st["bb2"](hb, B, 1, 1).view(B, 4)
+        deltas = self.bb2_32[k](hb, B, 1, 1).view(B, 32)[:, :4].contiguous()
         featn = torch.empty((B, 512), dtype=torch.float32, device=self.dev)
         logits = ops.zs_logits(feat, st["zs"], self.rh.norm_temp, featn_out=featn)
         return dict(boxes=boxes, pool=pool, h1=h1, h2=h2, feat=feat, featn=featn, hb=hb, deltas=deltas, logits=logits)
@@ -321,3 +329,39 @@ class DetectorTraining:
             out["loss_mask"] = torch.zeros((), dtype=torch.float32, device=self.dev)
         self.last = stages
         return out
+
+    def _conv_bw(self, conv: ops.Conv) -> ops.ConvBackward:
+        if id(conv) not in self._bw:
+            self._bw[id(conv)] = ops.ConvBackward(conv)
+        return self._bw[id(conv)]
+
+    def backward(self, P: Sequence[torch.Tensor]):
+        """Gradients of the sum of the stage losses of the last `losses()` call -> ({layer name: (dW packed [Cout, K], db)} for the
+        five linear layers of every stage, [dP3, dP4, dP5] as [h,w,256]).  Per stage: d logits -> normalize / class matrix
+        (`eod_zs_logits_backward`) -> cls_score.linear; d deltas -> bbox_pred.2 -> ReLU -> bbox_pred.0; both into fc2 -> fc1 -> the
+        pooled features x 1 / num_stages (`_ScaleGradient`, detic_roi_heads.py:334) -> ROIAlign backward, added over the stages.  The
+        stages are independent: the next stage's proposals are detached (`_create_proposals_from_boxes`, :310)."""
+        rh = self.rh
+        h3, w3 = int(P[0].shape[1]), int(P[0].shape[2])
+        dP = [torch.zeros(tuple(p.shape[1:]), dtype=torch.float32, device=self.dev) for p in P[:3]]
+        grads: Dict[str, tuple] = {}
+        for k, rec in enumerate(self.last):
+            st, B = rh.stages[k], int(rec["boxes"].shape[0])
+            d_feat = ops.zs_logits_backward(rec["feat"], st["zs"], rec["d_logits"], rh.norm_temp)
+            o = self._conv_bw(st["cls"])(rec["h2"], None, d_feat.view(B, 1, 1, 512))
+            grads[st["cls"].name] = (o["dw"], o["db"])
+            d_h2 = o["dx"]
+            g32 = torch.zeros((B, 1, 1, 32), dtype=torch.float32, device=self.dev)
+            g32[:, 0, 0, :4] = rec["d_deltas"] * self.box_w
+            o = self._conv_bw(self.bb2_32[k])(rec["hb"], None, g32)
+            grads[st["bb2"].name] = (o["dw"][:4].contiguous(), o["db"][:4].contiguous())
+            o = self._conv_bw(st["bb0"])(rec["h2"], rec["hb"], o["dx"], relu=True)
+            grads[st["bb0"].name] = (o["dw"], o["db"])
+            d_h2 = d_h2 + o["dx"]
+            o = self._conv_bw(st["fc2"])(rec["h1"], rec["h2"], d_h2, relu=True)
+            grads[st["fc2"].name] = (o["dw"], o["db"])
+            o = self._conv_bw(st["fc1"])(rec["pool"].view(B, 1, 1, -1), rec["h1"], o["dx"], relu=True)
+            grads[st["fc1"].name] = (o["dw"], o["db"])
+            d_pool = (o["dx"].view(B, 7, 7, 256) * (1.0 / rh.num_stages)).contiguous()
+            ops.roi_align_backward(dP[0], dP[1], dP[2], h3, w3, 256, rec["boxes"], None, B, 7, d_pool)
+        return grads, dP

@@ -795,6 +795,18 @@ def zs_logits(feat: torch.Tensor, zs: torch.Tensor, temp: float = 50.0, ld: Opti
     return out
 
 
+def zs_logits_backward(feat: torch.Tensor, zs: torch.Tensor, d_logits: torch.Tensor, temp: float = 50.0) -> torch.Tensor:
+    """d feat [B,512] of `zs_logits` given d_logits [B, ld] (`eod_zs_logits_backward`)."""
+    _need_cuda(feat, zs, d_logits)
+    B, C1 = int(d_logits.shape[0]), int(zs.shape[1])
+    feat = feat.view(B, 512)
+    assert feat.is_contiguous() and d_logits.is_contiguous() and d_logits.shape[1] >= C1
+    out = torch.empty((B, 512), dtype=torch.float32, device=feat.device)
+    check(_lib.load().eod_zs_logits_backward(feat.data_ptr(), zs.data_ptr(), d_logits.data_ptr(), int(d_logits.shape[1]), B, 512, C1,
+                                             float(temp), out.data_ptr(), _stream()), "eod_zs_logits_backward")
+    return out
+
+
 class AdamW:
     """`torch.optim.AdamW` (single-tensor form) + detectron2's clip-by-value on the device, one `eod_adamw_step` launch per parameter
     tensor: the optimizer of the reference's training configuration (custom_solver.py:69-72, Base-...recurrent.yaml:68-74).

@@ -271,6 +271,11 @@ int eod_sample_proposals(const int32_t* classes, const float* keys /*[R] uniform
 int eod_zs_logits(const float* feat, const float* zs_weight, int B, int D /*512*/, int C1, float temp, float* logits, int ld,
                   float* featn_out, eod_stream_t stream);
 
+/* eod_zs_logits_backward: d feat [B,512] of eod_zs_logits given d_logits [B, ld] (F.normalize's and torch.mm's autograd; the class
+ * matrix is a buffer, zero_shot_classifier.py:54). */
+int eod_zs_logits_backward(const float* feat, const float* zs_weight, const float* d_logits, int ld, int B, int D /*512*/, int C1,
+                           float temp, float* d_feat, eod_stream_t stream);
+
 /* ---- CenterNet proposal decode (centernet.py:603-745) ------------------------------------------------- */
 typedef struct EodProposalDesc {
   const float* head_out;   /* [P,8]: col 0 agn_hm logit, cols 1..4 bbox_pred (pre scale/relu) */

@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import Dict
 
 import torch
+import torch.nn.functional as F
 
 
 def binary_heatmap_focal_loss(logits: torch.Tensor, targets: torch.Tensor, pos_inds: torch.Tensor, alpha: float = -1.0,
@@ -232,6 +233,18 @@ def sample_by_keys(classes: torch.Tensor, keys: torch.Tensor, num_classes: int, 
     return torch.cat([pick(pos, num_pos), pick(neg, num_neg)])
 
 
+class _ScaleGradient(torch.autograd.Function):
+    """detectron2 `_ScaleGradient` (modeling/roi_heads/cascade_rcnn.py): identity forward, gradient x scale."""
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
 GT_PROPOSAL_LOGIT = 23.025850847100816        # add_ground_truth_to_proposals: log((1 - 1e-10) / (1 - (1 - 1e-10)))
 
 
@@ -253,11 +266,15 @@ def cascade_training_losses(feats, prop_boxes: torch.Tensor, gt_boxes: torch.Ten
             keep = (boxes[:, 2] - boxes[:, 0] > 0) & (boxes[:, 3] - boxes[:, 1] > 0)    # Boxes.nonempty
             boxes = boxes[keep]
             _, _, cls, gtb = match_label(boxes, gt_boxes, gt_classes, ious[k], cfg.num_classes)     # _match_and_label_boxes (:115)
-        pooled = O.roi_pool(list(feats[:3]), boxes, 7)
-        logits, deltas, _ = M.box_head_stage(pooled, sd, k, cfg)                    # _run_stage (:328-349); _ScaleGradient is the identity forward
+        pooled = _ScaleGradient.apply(O.roi_pool(list(feats[:3]), boxes, 7), 1.0 / 3)   # _run_stage (:328-349)
+        logits, deltas, _ = M.box_head_stage(pooled, sd, k, cfg)
+        with torch.no_grad():                                                       # the stage's ReLU patterns (tests count knife-edge flips)
+            a1 = F.relu(F.linear(pooled.flatten(1), sd[f"roi_heads.box_head.{k}.fc1.weight"], sd[f"roi_heads.box_head.{k}.fc1.bias"]))
+            a2 = F.relu(F.linear(a1, sd[f"roi_heads.box_head.{k}.fc2.weight"], sd[f"roi_heads.box_head.{k}.fc2.bias"]))
+            ab = F.relu(F.linear(a2, sd[f"roi_heads.box_predictor.{k}.bbox_pred.0.weight"], sd[f"roi_heads.box_predictor.{k}.bbox_pred.0.bias"]))
         losses[f"loss_cls_stage{k}"] = sigmoid_cross_entropy_loss(logits, cls)
         losses[f"loss_box_reg_stage{k}"] = box_reg_loss(boxes, gtb, deltas, cls, cfg.num_classes, M.CASCADE_WEIGHTS[k], smooth_l1_beta)
-        stages.append(dict(boxes=boxes, classes=cls, gt_boxes=gtb, logits=logits, deltas=deltas))
+        stages.append(dict(boxes=boxes, classes=cls, gt_boxes=gtb, logits=logits, deltas=deltas, h1=a1, h2=a2, hb=ab))
         boxes = O.apply_deltas(deltas.detach(), boxes, M.CASCADE_WEIGHTS[k])       # predict_boxes (:124)
     losses["loss_mask"] = torch.zeros(())                                           # _get_empty_mask_loss, MASK_ON
     return losses, stages

@@ -125,3 +125,85 @@ def test_cascade_training_losses_match_oracle(synthetic_sd):
     # the stage-0 sample: 512 rows, a quarter foreground when there are enough (12 objects x 6 near copies + the objects themselves)
     c0 = rstages[0]["classes"]
     assert c0.numel() == 512 and 12 <= int((c0 < 20).sum()) <= 128
+
+
+def test_cascade_training_backward_matches_autograd(synthetic_sd):
+    """Backward of the ROI heads' half: the gradients of the six stage losses with respect to the 30 tensors of the three box heads /
+    predictors (fc1, fc2, cls_score.linear, bbox_pred.0, bbox_pred.2: weights + biases) and to P3..P5 (through ROIAlign, scaled by
+    1/3 per stage as `_ScaleGradient` does), against torch autograd on the oracle.  A ReLU whose pre-activation is within fp32
+    rounding of zero may be open in one implementation and closed in the other: a discrete difference of that unit's gradient for one
+    ROI, which reaches every weight below it as a rank-1 term (first seen at seed 31: one flip, 9e-4 of fc1.weight in the L2 norm).
+    The test counts such flips over the 3 x 3 ReLU layers; inputs with flips must agree in the L2 norm, and the tight element-wise
+    bound is asserted on the first input without any."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import DetectorTraining
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 96])
+    model = build_model(cfg, synthetic_sd)
+    det = DetectorTraining(model)
+    H, W = 256, 320
+    names = [f"roi_heads.box_head.{k}.{n}" for k in range(3) for n in ("fc1", "fc2")] + \
+            [f"roi_heads.box_predictor.{k}.{n}" for k in range(3) for n in ("cls_score.linear", "bbox_pred.0", "bbox_pred.2")]
+
+    def run(seed):
+        g = torch.Generator().manual_seed(seed)
+        gt, props = _boxes(g, 6, 200, W=float(W), H=float(H))
+        big = torch.tensor([[12.0, 8.0, 300.0, 250.0], [40.0, 20.0, 316.0, 236.0]])      # sqrt(area) >= 224: pooled from P4
+        gt = torch.cat([gt, big]).contiguous()
+        props = torch.cat([props, big.repeat(4, 1) + torch.randn((8, 4), generator=g) * 6]).contiguous()
+        gc = torch.randint(0, 20, (8,), generator=g)
+        feats = [(torch.randn((1, 256, H >> (3 + l), W >> (3 + l)), generator=g) * 0.5).requires_grad_() for l in range(3)]
+        keys = torch.rand((props.shape[0] + gt.shape[0],), generator=g)
+        sd = dict(synthetic_sd)
+        for n in names:
+            for s in ("weight", "bias"):
+                sd[f"{n}.{s}"] = synthetic_sd[f"{n}.{s}"].clone().float().requires_grad_()
+        ref, rstages = OL.cascade_training_losses(feats, props, gt, gc, sd, M.OracleCfg(), (H, W), keys, batch=96)
+        sum(ref.values()).backward()
+        P = [f.detach().permute(0, 2, 3, 1).contiguous().to(dev) for f in feats]
+        out = det.losses(P, props.to(dev), gt.to(dev), gc.to(dev), (H, W), keys=keys.to(dev))
+        grads, dP = det.backward(P)
+        torch.cuda.synchronize()
+        flips = 0
+        for k in range(3):
+            assert torch.equal(det.last[k]["classes"].cpu().long(), rstages[k]["classes"]), k
+            for a in ("h1", "h2", "hb"):
+                flips += int(((det.last[k][a].cpu().view(rstages[k][a].shape) > 0) != (rstages[k][a] > 0)).sum())
+            for name in (f"loss_cls_stage{k}", f"loss_box_reg_stage{k}"):
+                assert abs(float(out[name]) - float(ref[name].detach())) <= 1e-4 * max(abs(float(ref[name].detach())), 1e-3), name
+
+        def check(mine, theirs, what):
+            scale = max(float(theirs.abs().max()), 1e-20)
+            err = float((mine - theirs).abs().max())
+            l2 = float((mine - theirs).norm()) / max(float(theirs.norm()), 1e-20)
+            if flips == 0:
+                assert err <= 1e-4 * scale, (what, err / scale)
+            assert l2 <= 3e-3 * max(flips, 1) and err <= 5e-2 * scale, (what, l2, err / scale, flips)
+
+        seen = 0
+        for k in range(3):
+            st = model.roi_heads.stages[k]
+            for conv, n in ((st["fc1"], f"roi_heads.box_head.{k}.fc1"), (st["fc2"], f"roi_heads.box_head.{k}.fc2"),
+                            (st["cls"], f"roi_heads.box_predictor.{k}.cls_score.linear"), (st["bb0"], f"roi_heads.box_predictor.{k}.bbox_pred.0"),
+                            (st["bb2"], f"roi_heads.box_predictor.{k}.bbox_pred.2")):
+                dw, db = grads[conv.name]
+                rw = sd[f"{n}.weight"].grad
+                if n.endswith("fc1"):                                      # reference flatten order (C,7,7) -> the pooled rows' (7,7,C)
+                    rw = rw.view(-1, 256, 7, 7).permute(0, 2, 3, 1).reshape(rw.shape[0], -1)
+                check(dw.cpu(), rw, n + ".weight")
+                check(db.cpu(), sd[f"{n}.bias"].grad, n + ".bias")
+                seen += 2
+        assert seen == 30
+        for l in range(3):                                                 # a level no box is pooled from has no gradient (P5 here)
+            rg = feats[l].grad[0].permute(1, 2, 0) if feats[l].grad is not None else torch.zeros(tuple(dP[l].shape))
+            check(dP[l].cpu(), rg, f"dP{l + 3}")
+        assert float(dP[0].abs().max()) > 0 and float(dP[1].abs().max()) > 0
+        return flips
+
+    counts = []
+    for seed in range(31, 39):
+        counts.append(run(seed))
+        if counts[-1] == 0:
+            break
+    print("ReLU flips per seed from 31:", counts)
+    assert counts[-1] == 0, counts

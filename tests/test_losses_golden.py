@@ -75,3 +75,29 @@ def test_oracle_target_assignment_matches_the_reference():
         assert np.array_equal(reg.numpy(), z[f"{tag}_reg_targets"]), tag
         assert np.array_equal(heat.numpy(), z[f"{tag}_heatmap"][:, 0]), tag
     assert len(z["full_pos_inds"]) > len(z["gt_boxes"]) and int((z["full_reg_targets"].max(axis=1) >= 0).sum()) > 100
+
+
+def test_oracle_matcher_and_sampler_hand_cases():
+    """The restated detectron2 pieces of the ROI heads' training forward (`oracle/losses.py`: pairwise_iou, Matcher + labelling,
+    subsample_labels by keys) on cases worked by hand; unpinned (detectron2 is not in the reference tree)."""
+    import pytest
+    gt = torch.tensor([[0.0, 0.0, 10.0, 10.0], [20.0, 20.0, 40.0, 40.0], [0.0, 0.0, 10.0, 10.0]])
+    gc = torch.tensor([3, 7, 5])
+    props = torch.tensor([[0.0, 0.0, 10.0, 10.0],        # IoU 1 with objects 0 and 2: the first wins
+                          [0.0, 0.0, 10.0, 5.0],         # IoU 0.5 with object 0
+                          [20.0, 20.0, 40.0, 36.0],      # IoU 0.8 with object 1
+                          [50.0, 50.0, 60.0, 60.0],      # no overlap
+                          [10.0, 10.0, 20.0, 20.0]])     # touches objects 0 and 1: intersection 0
+    iou = OL.pairwise_iou(gt, props)
+    assert torch.allclose(iou[:, 1], torch.tensor([0.5, 0.0, 0.5])) and float(iou[1, 2]) == pytest.approx(0.8) and float(iou[:, 4].max()) == 0.0
+    idx, vals, cls, gtb = OL.match_label(props, gt, gc, 0.6, 20)
+    assert idx.tolist()[:3] == [0, 0, 1] and cls.tolist() == [3, 20, 7, 20, 20]
+    assert torch.equal(gtb[2], gt[1]) and vals.tolist()[3:] == [0.0, 0.0]
+    assert OL.match_label(props, gt, gc, 0.5, 20)[2].tolist() == [3, 3, 7, 20, 20]            # >= at the threshold is foreground
+    e = OL.match_label(props, torch.zeros((0, 4)), torch.zeros((0,), dtype=torch.int64), 0.6, 20)
+    assert e[2].tolist() == [20] * 5 and float(e[3].abs().max()) == 0.0
+    # sampling: 2 of the 3 foreground rows (batch 8 x 1/4), then 6 background rows by smallest key; -1 rows never
+    cls = torch.tensor([20, 1, 20, -1, 4, 20, 20, 20, 9, 20, 20, 20])
+    keys = torch.tensor([0.9, 0.3, 0.1, 0.0, 0.2, 0.5, 0.5, 0.8, 0.7, 0.4, 0.95, 0.6])
+    assert OL.sample_by_keys(cls, keys, 20, 8, 0.25).tolist() == [1, 4, 2, 5, 6, 7, 9, 11]
+    assert OL.sample_by_keys(cls, keys, 20, 64, 0.25).tolist() == [1, 4, 8, 0, 2, 5, 6, 7, 9, 10, 11]

@@ -57,9 +57,13 @@ class ProposalTraining:
         return torch.cat(dxs), dw, db
 
     # ---- one step ------------------------------------------------------------------------------------------------------------------
-    def forward_backward(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, world_size: int = 1, reduce_counts=None):
+    def forward_backward(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, world_size: int = 1, reduce_counts=None,
+                         roi_half=None):
         """image_u8 [3,H,W] on the device, gt_boxes [N,4] fp32 on the device, `memory = (memory_f16, proj_indices)` or None ->
         (losses {name: float tensor on the device}, grads {layer or parameter name: tensors}).
+
+        `roi_half(P, head, shapes, off) -> (losses, grads, [dP3, dP4, dP5])`: the ROI heads' half of `forward_model` on the same
+        pyramid (`ForwardModelTraining`); its losses / gradients join the result, its pyramid gradients the backbone's backward.
 
         `reduce_counts(counts int32 [2]) -> counts` sums the positives / regression rows over the ranks (the reference's
         `reduce_sum`, centernet.py:263-265,293); both are then divided by `world_size`."""
@@ -93,6 +97,11 @@ class ProposalTraining:
         losses = {"loss_centernet_loc": losses_t[0], "loss_centernet_agn_pos": losses_t[1], "loss_centernet_agn_neg": losses_t[2]}
         # ---- backward
         grads: Dict[str, tuple] = {}
+        roi_dP = None
+        if roi_half is not None:
+            roi_losses, roi_grads, roi_dP = roi_half(P, head, shapes, off)
+            losses.update(roi_losses)
+            grads.update(roi_grads)
         # the levels' Scale parameters (centernet_head.py:153-155): d scale_l = sum over the level of d reg * raw = d raw * raw / scale_l
         prod = (d_head[:, 1:5] * head[:, 1:5]).sum(dim=1)
         grads["scales"] = torch.stack([prod[off[l]:off[l + 1]].sum() / pg.scales[l] for l in range(len(shapes))])
@@ -107,6 +116,9 @@ class ProposalTraining:
             grads[conv.name] = (dw, db)
             grads[conv.name + ".norm"] = (dgamma, dbeta)
         dP = [gx[off[l]:off[l + 1]].view(1, shapes[l][0], shapes[l][1], 256) for l in range(len(shapes))]
+        if roi_dP is not None:
+            for l, d in enumerate(roi_dP):
+                dP[l] = (dP[l] + d.view(dP[l].shape)).contiguous()
         bgrads, _ = self.bb.backward(saved, dP)
         grads.update(bgrads)
         return losses, grads
@@ -119,10 +131,13 @@ class ProposalTrainer:
     packed weights in place; the trunk's convs step a raw master and are re-folded with their FrozenBatchNorm (whose weight / bias are
     buffers, not parameters: timm.py:277-299); the map_merge projections are re-prepared; the level scales go back to the decoder."""
 
-    def __init__(self, model, sd: Dict[str, torch.Tensor]):
+    def __init__(self, model, sd: Dict[str, torch.Tensor], roi_heads: bool = False):
+        """`roi_heads=True` (`Trainer`): `forward_model` with both halves -- the 30 tensors of the cascade's box heads / predictors
+        join the optimizer and the ROI heads' losses and pyramid gradients the step."""
         from .. import solver
         self.model, self.dev = model, model.device
         self.step_fn = ProposalTraining(model, sd)
+        self.fm = ForwardModelTraining(model, sd, prop=self.step_fn) if roi_heads else None
         cfg = model.cfg
         dev = self.dev
         bbm, pg = model.backbone, model.proposal_generator
@@ -202,8 +217,33 @@ class ProposalTrainer:
                     loss.desc.level_scale[l] = v
         self.after.append(sync_scales)
 
+        if self.fm is not None:
+            det, rh = self.fm.det, model.roi_heads
+            for k, st in enumerate(rh.stages):
+                for conv, ref in ((st["fc1"], f"roi_heads.box_head.{k}.fc1"), (st["fc2"], f"roi_heads.box_head.{k}.fc2"),
+                                  (st["cls"], f"roi_heads.box_predictor.{k}.cls_score.linear"),
+                                  (st["bb0"], f"roi_heads.box_predictor.{k}.bbox_pred.0")):
+                    w, b = plain_conv(conv, None)                        # fc1's columns are in the pooled rows' (7,7,C) order
+                    add(f"{ref}.weight", w, lambda g, n=conv.name: g[n][0])
+                    add(f"{ref}.bias", b, lambda g, n=conv.name: g[n][1])
+                b32, ref = det.bb2_32[k], f"roi_heads.box_predictor.{k}.bbox_pred.2"
+                add(f"{ref}.weight", b32.w[:4], lambda g, n=st["bb2"].name: g[n][0])
+                add(f"{ref}.bias", b32.bias[:4], lambda g, n=st["bb2"].name: g[n][1])
+
+            def sync_roi_heads():                                     # the inference path's own objects for the same parameters
+                for k, st in enumerate(rh.stages):
+                    st["bb2"].w.copy_(det.bb2_32[k].w[:4])
+                    st["bb2"].bias.copy_(det.bb2_32[k].bias[:4])
+                    st["cls_bb0"].w[:512].copy_(st["cls"].w)
+                    st["cls_bb0"].w[512:].copy_(st["bb0"].w)
+                    st["cls_bb0"].bias[:512].copy_(st["cls"].bias)
+                    st["cls_bb0"].bias[512:].copy_(st["bb0"].bias)
+                    st["cls_bb0"].w_split = None
+            self.after.append(sync_roi_heads)
+
         def stale_caches():
-            for bw in list(self.step_fn._bw.values()) + list(self.step_fn.bb._bw.values()):
+            extra = list(self.fm.det._bw.values()) if self.fm is not None else []
+            for bw in list(self.step_fn._bw.values()) + list(self.step_fn.bb._bw.values()) + extra:
                 bw._flipped_of = None                            # rotated weights of the dgrad convs
                 bw.conv.w_split = None                           # bf16x3 pieces, if that arithmetic was in use
         self.after.append(stale_caches)
@@ -224,9 +264,15 @@ class ProposalTrainer:
         self.opt = ops.AdamW(self.groups, weight_decay=float(s.WEIGHT_DECAY), clip_value=float(clip.CLIP_VALUE) if bool(clip.ENABLED) else 0.0)
         self.iteration = 0
 
-    def step(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, lr_factor: float = 1.0):
-        """One training iteration on one frame -> the three proposal losses (device scalars, of the weights BEFORE the update)."""
-        losses, grads = self.step_fn.forward_backward(image_u8, gt_boxes, memory=memory)
+    def step(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, lr_factor: float = 1.0, gt_classes=None, proposals=None,
+             keys=None, generator=None):
+        """One training iteration on one frame -> the losses (device scalars, of the weights BEFORE the update): the three proposal
+        losses, with `roi_heads=True` also the cascade's six and loss_mask (`gt_classes` int32 [N] needed)."""
+        if self.fm is not None:
+            losses, grads = self.fm.forward_backward(image_u8, gt_boxes, gt_classes, memory=memory, proposals=proposals, keys=keys,
+                                                     generator=generator)
+        else:
+            losses, grads = self.step_fn.forward_backward(image_u8, gt_boxes, memory=memory)
         self.opt.step([self.getters[g["name"]](grads) for g in self.groups], lr_factor=lr_factor)
         for f in self.after:
             f()
@@ -365,3 +411,60 @@ class DetectorTraining:
             d_pool = (o["dx"].view(B, 7, 7, 256) * (1.0 / rh.num_stages)).contiguous()
             ops.roi_align_backward(dP[0], dP[1], dP[2], h3, w3, 256, rec["boxes"], None, B, 7, d_pool)
         return grads, dP
+
+
+class ForwardModelTraining:
+    """`CustomRCNNRecurrent.forward_model` (custom_rcnn.py:584-679) of one frame, forward + backward: both halves on one pyramid --
+    `ProposalTraining` (backbone with the memory read fused in, CenterNet head, targets, proposal losses) and `DetectorTraining` (the
+    cascade's losses on proposals decoded from the same head outputs, as `CenterNet.forward` does in training, centernet.py:214-219);
+    the ROI heads' pyramid gradients join the proposal head's before the backbone's backward.  Returns the reference's loss dict
+    (:665-673: detector losses + proposal losses) and the gradient of every parameter.
+
+    The training-mode proposal lists are clamped to the selection kernels' capacity (8192 candidate slots over the levels, 448 kept)
+    where the yaml asks for PRE / POST_NMS_TOPK_TRAIN 4000 / 2000: `self.clamped` says whether that happened."""
+
+    def __init__(self, model, sd: Dict[str, torch.Tensor], prop: Optional[ProposalTraining] = None):
+        self.model, self.dev = model, model.device
+        self.prop = prop if prop is not None else ProposalTraining(model, sd)
+        self.det = DetectorTraining(model)
+        c = model.cfg.MODEL.CENTERNET
+        levels = len(c.FPN_STRIDES)
+        self.pre, self.post = min(int(c.PRE_NMS_TOPK_TRAIN), 8192 // levels), min(int(c.POST_NMS_TOPK_TRAIN), 448)
+        self.clamped = self.pre < int(c.PRE_NMS_TOPK_TRAIN) or self.post < int(c.POST_NMS_TOPK_TRAIN)
+        self.nms_train, self.score_thresh = float(c.NMS_TH_TRAIN), float(c.INFERENCE_TH)
+        self._dec: Dict[tuple, ops.ProposalDecoder] = {}
+
+    def train_proposals(self, head: torch.Tensor, shapes) -> torch.Tensor:
+        """`predict_instances` with the training thresholds on the head's raw rows [P, 32] -> proposal boxes [R,4] (detached)."""
+        pg = self.prop.pg
+        key = (tuple(shapes), tuple(pg.scales))
+        if key not in self._dec:
+            cap = (self.post + 64 + 31) // 32 * 32
+            self._dec[key] = ops.ProposalDecoder(shapes, pg.strides, pg.scales, self.score_thresh, self.pre, self.post, self.nms_train, cap,
+                                                 self.dev, head_stride=int(head.shape[1]))
+        boxes, _, count = self._dec[key](head)
+        return boxes[:int(count.cpu()[0])].clone()
+
+    def forward_backward(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, memory=None, proposals=None,
+                         keys=None, generator=None, world_size: int = 1, reduce_counts=None):
+        """-> (losses: the nine training losses + loss_mask, grads: every layer's (dW, db) / parameter gradient).  `proposals` [R,4]
+        replaces the decoded list (tests); `keys` / `generator`: the sampling's random keys."""
+        H, W = int(image_u8.shape[1]), int(image_u8.shape[2])
+        self.last_proposals = None
+
+        def roi_half(P, head, shapes, off):
+            props = proposals if proposals is not None else self.train_proposals(head, shapes)
+            self.last_proposals = props
+            losses = self.det.losses(P[:3], props, gt_boxes, gt_classes, (H, W), keys=keys, generator=generator)
+            grads, dP = self.det.backward(P[:3])
+            return losses, grads, dP
+        return self.prop.forward_backward(image_u8, gt_boxes, memory=memory, world_size=world_size, reduce_counts=reduce_counts,
+                                          roi_half=roi_half)
+
+
+class Trainer(ProposalTrainer):
+    """One optimizer over every trainable parameter of the recurrent detector (build_custom_optimizer's groups, custom_solver.py:19-79)
+    and `forward_model`'s full loss dict per step: `ProposalTrainer` with the ROI heads' half."""
+
+    def __init__(self, model, sd: Dict[str, torch.Tensor]):
+        super().__init__(model, sd, roi_heads=True)

@@ -207,3 +207,97 @@ def test_cascade_training_backward_matches_autograd(synthetic_sd):
             break
     print("ReLU flips per seed from 31:", counts)
     assert counts[-1] == 0, counts
+
+
+def test_forward_model_training_step_both_halves(synthetic_sd):
+    """`forward_model` end to end (custom_rcnn.py:584-679) on the HIP kernels -- `ForwardModelTraining` / `Trainer`: image + memory ->
+    backbone -> CenterNet head -> proposal losses AND train-mode proposals -> cascade losses; one backward through ROI heads, proposal
+    head, FPN, memory fusion and trunk.  Against torch autograd on the oracle run on the same proposals and sampling keys: the ten
+    losses, and the gradients of parameters that see BOTH halves (trunk, FPN, map_merge) or one (tower, box heads) in the L2 norm
+    (robust against single ReLU flips, see the tests of the halves).  Then optimizer steps over all 126 tensors reduce the total loss
+    and the inference path runs on the stepped layers."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    dev = torch.device("cuda:0")
+    lr = 2e-5
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "SOLVER.BASE_LR", lr])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    fm = trainer.fm
+    assert fm.clamped and (fm.pre, fm.post) == (1638, 448)                # the yaml's 4000 / 2000 exceed the selection kernels
+    H, W, n_cells = 128, 160, 500
+    g = torch.Generator().manual_seed(105)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 2).half()
+    proj = torch.randint(0, n_cells, (H, W), generator=g)
+    gt = torch.tensor([[10.0, 12.0, 60.0, 70.0], [40.0, 30.0, 150.0, 120.0], [90.0, 8.0, 118.0, 40.0], [5.0, 80.0, 44.0, 124.0],
+                       [100.0, 60.0, 156.0, 126.0], [64.0, 64.0, 72.0, 72.0], [2.0, 2.0, 158.0, 126.0]])
+    gc = torch.tensor([1, 4, 4, 9, 0, 17, 12])
+    mem = (mem16.to(dev), proj.int().to(dev))
+    # the train-mode proposals of this frame (decoded from the head's outputs), then the checked pass on them with fixed keys
+    fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, generator=torch.Generator(device=dev).manual_seed(1))
+    props = fm.last_proposals.cpu()
+    assert 16 <= props.shape[0] <= 448 and bool((props[:, 2] >= props[:, 0]).all())
+    keys = torch.rand((props.shape[0] + gt.shape[0],), generator=g)
+    losses, grads = fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, proposals=props.to(dev), keys=keys.to(dev))
+    torch.cuda.synchronize()
+    # ---- torch autograd on the oracle
+    ocfg = M.OracleCfg(map_feature_weight=5.0)
+    trainable = lambda k, v: v.is_floating_point() and "running_" not in k and ".bn" not in k and ".downsample.1." not in k and \
+        "zs_weight" not in k and (k.startswith("backbone.") or "centernet_head" in k or "box_head" in k or "box_predictor" in k)
+    sd = {k: (v.clone().float().requires_grad_() if trainable(k, v) else v) for k, v in synthetic_sd.items()}
+    feats = M.backbone_forward(M.preprocess_image(img, ocfg), sd, ocfg, mem16, proj)
+    agn, reg = M.centernet_head(feats, sd)
+    shapes = [(f.shape[2], f.shape[3]) for f in feats]
+    pos, reg_t, heat = OL.centernet_targets(gt, shapes)
+    ref = OL.centernet_proposal_losses(torch.cat([a.permute(0, 2, 3, 1).reshape(-1) for a in agn]),
+                                       torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg]), heat, reg_t, pos)
+    rdet, rstages = OL.cascade_training_losses(feats[:3], props, gt, gc, sd, ocfg, (H, W), keys)
+    ref.update(rdet)
+    sum(ref.values()).backward()
+    assert set(losses) == set(ref) and len(ref) == 10
+    for k in range(3):
+        assert fm.det.last[k]["boxes"].shape[0] == rstages[k]["boxes"].shape[0]
+        assert int((fm.det.last[k]["classes"].cpu().long() != rstages[k]["classes"]).sum()) == 0, k
+    for name, v in ref.items():
+        assert abs(float(losses[name]) - float(v.detach())) <= 3e-4 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))
+    packed = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    base = "backbone.bottom_up.base"
+    h = "proposal_generator.centernet_head"
+    probe = [f"{base}.conv1.weight", f"{base}.layer2.1.conv2.weight", f"{base}.layer4.0.downsample.0.weight", "backbone.fpn_lateral3.weight",
+             "backbone.fpn_output4.weight", "backbone.fpn_output4.bias", "backbone.map_merge_projection1.weight",
+             "backbone.map_merge_projection3.bias", "backbone.top_block.p6.weight", f"{h}.bbox_tower.0.weight", f"{h}.bbox_tower.10.weight",
+             "roi_heads.box_head.0.fc1.weight", "roi_heads.box_head.1.fc2.bias", "roi_heads.box_predictor.2.cls_score.linear.weight",
+             "roi_heads.box_predictor.0.bbox_pred.0.weight", "roi_heads.box_predictor.1.bbox_pred.2.weight"]
+    for name in probe:
+        mine = trainer.getters[name](grads).cpu()
+        want = sd[name].grad
+        if name == f"{base}.conv1.weight":
+            want = F.pad(want.permute(0, 2, 3, 1), (0, 1)).reshape(64, -1)
+        elif name.endswith("fc1.weight"):
+            want = want.view(-1, 256, 7, 7).permute(0, 2, 3, 1).reshape(want.shape[0], -1)
+        elif want.dim() == 4 and "map_merge" not in name:
+            want = packed(want)
+        want = want.reshape(mine.shape)
+        l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
+        assert l2 <= 5e-3, (name, l2)
+    # the pyramid gradient of the ROI heads really reaches the backbone: without it the FPN gradient is a different one
+    _, g_prop = fm.prop.forward_backward(img.to(dev), gt.to(dev), memory=mem)
+    a, b = trainer.getters["backbone.fpn_output3.weight"](grads), trainer.getters["backbone.fpn_output3.weight"](g_prop)
+    assert float((a - b).norm()) > 1e-2 * float(a.norm())
+    # ---- optimizer steps over both halves' parameters
+    assert len(trainer.entries) == 96 + 30 and len(trainer.groups) == 126
+    gen = torch.Generator(device=dev).manual_seed(7)
+    first = sum(float(v) for v in trainer.step(img.to(dev), gt.to(dev), memory=mem, gt_classes=gc.int().to(dev), generator=gen).values())
+    last = first
+    for _ in range(7):
+        last = sum(float(v) for v in trainer.step(img.to(dev), gt.to(dev), memory=mem, gt_classes=gc.int().to(dev), generator=gen).values())
+    assert last < first, (first, last)
+    st = model.roi_heads.stages[1]
+    assert torch.equal(st["cls_bb0"].w[:512], st["cls"].w) and torch.equal(st["bb2"].w, fm.det.bb2_32[1].w[:4])
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    out = model([[SyntheticSequence(0, H=H, W=W, n_frames=1).frame(0)]])
+    assert len(out) == 1 and "instances" in out[0]
+    print("trainer, both halves: total loss %.4f -> %.4f after 8 steps at lr %.0e; %d proposals" % (first, last, lr, props.shape[0]))

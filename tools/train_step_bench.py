@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""Time of one training iteration of the proposal half (`modeling/training.py::ProposalTrainer.step`: forward with kept activations,
-target assignment, losses, backward through head / FPN / memory fusion / trunk, 96 AdamW launches, re-folding) on one synthetic
-640x640 frame with 24 ground-truth boxes.  Diagnostics for the training slices, not the headline metric.
+"""Time of one training iteration (`modeling/training.py`): by default the proposal half (`ProposalTrainer.step`: forward with kept
+activations, target assignment, losses, backward through head / FPN / memory fusion / trunk, 96 AdamW launches, re-folding); with
+`--roi-heads` the whole `forward_model` (`Trainer.step`: also train-mode proposals, matching / sampling, the cascade's three stages
+with their losses and backward, 126 AdamW launches) -- on one synthetic 640x640 frame with 24 ground-truth boxes.  Diagnostics for
+the training slices, not the headline metric.
 
-    python tools/train_step_bench.py [--size 640 640] [--steps 10] [--warmup 3]
+    python tools/train_step_bench.py [--roi-heads] [--size 640 640] [--steps 10] [--warmup 3]
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o train -- python3 tools/train_step_bench.py
 """
 import argparse
@@ -16,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from embodied_object_detection_amd import build_model, setup_cfg
 from embodied_object_detection_amd.checkpoint import synthetic_state_dict
-from embodied_object_detection_amd.modeling.training import ProposalTrainer
+from embodied_object_detection_amd.modeling.training import ProposalTrainer, Trainer
 
 
 def main():
@@ -24,13 +26,14 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[640, 640])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--roi-heads", action="store_true", help="the whole forward_model: both halves, all 126 parameter tensors")
     a = ap.parse_args()
     H, W = a.size
     dev = torch.device("cuda:0")
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5])
     sd = synthetic_state_dict(0)
     model = build_model(cfg, sd)
-    trainer = ProposalTrainer(model, sd)
+    trainer = Trainer(model, sd) if a.roi_heads else ProposalTrainer(model, sd)
     g = torch.Generator().manual_seed(0)
     n_cells = 200 * 200
     img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
@@ -39,17 +42,21 @@ def main():
     xy = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.6, H * 0.6])
     wh = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.35, H * 0.35]) + 8
     gt = torch.cat([xy, xy + wh], dim=1).to(dev)
+    kw = dict(gt_classes=torch.randint(0, 20, (24,), generator=g).int().to(dev), generator=torch.Generator(device=dev).manual_seed(0)) \
+        if a.roi_heads else {}
     losses = []
     for _ in range(a.warmup):
-        losses.append(sum(float(v) for v in trainer.step(img, gt, memory=(mem16, proj)).values()))
+        losses.append(sum(float(v) for v in trainer.step(img, gt, memory=(mem16, proj), **kw).values()))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = trainer.step(img, gt, memory=(mem16, proj))
+        out = trainer.step(img, gt, memory=(mem16, proj), **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     losses.append(sum(float(v) for v in out.values()))
-    print(json.dumps({"metric": "training_iterations_per_second_proposal_half", "value": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 2),
+    extra = {"proposals": int(trainer.fm.last_proposals.shape[0]), "roi_rows_per_stage": [int(r["boxes"].shape[0]) for r in trainer.fm.det.last],
+             "proposal_caps": [trainer.fm.pre, trainer.fm.post]} if a.roi_heads else {}
+    print(json.dumps({"metric": "training_iterations_per_second" + ("" if a.roi_heads else "_proposal_half"), **extra, "value": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 2),
                       "size": [H, W], "gt_boxes": 24, "steps": a.steps, "warmup": a.warmup, "dtype": "f32",
                       "total_loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
                       "note": "one frame per iteration, parameters stepped in the layers the inference path runs"}))

@@ -216,6 +216,11 @@ class CustomRCNNRecurrent:
         self.training = False
         return self
 
+    def train(self, mode: bool = True):
+        """Training mode: `forward` runs `forward_model` on every frame through the attached `modeling.training.Trainer`."""
+        self.training = bool(mode)
+        return self
+
     def to(self, *_a, **_k):
         return self
 
@@ -281,7 +286,12 @@ class CustomRCNNRecurrent:
     def forward(self, batched_inputs: List[List[dict]]):
         """Sequential pass over sequences and frames; the memory persists across calls (custom_rcnn.py:435-546)."""
         if self.training:
-            raise NotImplementedError("training forward is out of scope for the hot path (SURVEY §8f rank 4)")
+            # custom_rcnn.py:444-461: forward_model per frame, the loss terms summed.  There is no autograd graph on this path: the
+            # attached `modeling.training.Trainer` runs forward AND backward and keeps the gradients for its `optimizer_step()`.
+            if getattr(self, "trainer", None) is None:
+                raise RuntimeError("training mode needs a trainer: `modeling.training.Trainer(model, state_dict)` attaches itself to the "
+                                   "model; then `model.train(); losses = model(data); trainer.optimizer_step()`")
+            return self.trainer.forward_backward_frames(batched_inputs)
         if self.overlap_branches and self.pipeline_detection_pass:
             # The frame's own chain (memory read -> tower -> proposals -> proposal masks -> memory write) moves to a HIGH priority
             # stream for the duration of the call: the previous frame's detection pass trails at normal priority, and at equal

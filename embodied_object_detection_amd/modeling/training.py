@@ -468,3 +468,53 @@ class Trainer(ProposalTrainer):
 
     def __init__(self, model, sd: Dict[str, torch.Tensor]):
         super().__init__(model, sd, roi_heads=True)
+        self._acc = None
+        model.trainer = self                      # `model.train(); model(data)` reaches `forward_backward_frames` (meta_arch.forward)
+
+    @staticmethod
+    def _gt(frame):
+        inst = frame["instances"]
+        if isinstance(inst, dict):
+            boxes, classes = inst["gt_boxes"], inst["gt_classes"]
+        else:
+            boxes, classes = inst.gt_boxes, inst.gt_classes
+        boxes = boxes.tensor if hasattr(boxes, "tensor") else boxes
+        return torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4), torch.as_tensor(classes).reshape(-1).to(torch.int32)
+
+    def forward_backward_frames(self, batched_inputs, generator: Optional[torch.Generator] = None):
+        """The training branch of `CustomRCNNRecurrent.forward` (custom_rcnn.py:435-461): for every frame of every sequence the memory
+        the loader hands over (`frame['memory']` accumulated features [N,512], `frame['observations']` [N], `frame['proj_indices']`
+        [H,W]; loader.py:199-223) is normalised by its observation counts (`create_implicit_memory`, :762-774 -> the a4 kernel) and
+        `forward_model` runs on the frame; the loss terms are SUMMED over the frames (:455-460), and so are the gradients (one
+        `losses.backward()` per call in `train_mp3d.py:619-625`) -> the summed loss dict; `optimizer_step` applies them."""
+        dev = self.dev
+        total: Dict[str, torch.Tensor] = {}
+        acc = None
+        for seq in batched_inputs:
+            for frame in seq:
+                img = torch.as_tensor(frame["image"]).to(dev)
+                gt_boxes, gt_classes = self._gt(frame)
+                memory = None
+                if self.model.memory_type == "implicit_memory":
+                    mem = torch.as_tensor(frame["memory"]).to(dev, torch.float32).contiguous()
+                    obs = torch.as_tensor(frame["observations"]).to(dev, torch.float32).reshape(-1).contiguous()
+                    proj = torch.as_tensor(frame["proj_indices"]).to(dev).reshape(int(img.shape[1]), int(img.shape[2])).to(torch.int32).contiguous()
+                    memory = (ops.memory_normalize_f16(mem, obs), proj)
+                losses, grads = self.fm.forward_backward(img, gt_boxes.to(dev).contiguous(), gt_classes.to(dev), memory=memory,
+                                                         generator=generator)
+                gl = [self.getters[g["name"]](grads) for g in self.groups]
+                acc = [t.clone() for t in gl] if acc is None else [a.add_(t) for a, t in zip(acc, gl)]
+                for k, v in losses.items():
+                    total[k] = v.clone() if k not in total else total[k] + v
+        self._acc = acc
+        return total
+
+    def optimizer_step(self, lr_factor: float = 1.0):
+        """`optimizer.step()` + `scheduler.step()`'s factor (train_mp3d.py:625,633) on the gradients of the last `forward_backward_frames`."""
+        if self._acc is None:
+            raise RuntimeError("optimizer_step without gradients: call forward_backward_frames (or model(data) in training mode) first")
+        self.opt.step(self._acc, lr_factor=lr_factor)
+        for f in self.after:
+            f()
+        self._acc = None
+        self.iteration += 1

@@ -301,3 +301,71 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     out = model([[SyntheticSequence(0, H=H, W=W, n_frames=1).frame(0)]])
     assert len(out) == 1 and "instances" in out[0]
     print("trainer, both halves: total loss %.4f -> %.4f after 8 steps at lr %.0e; %d proposals" % (first, last, lr, props.shape[0]))
+
+
+def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
+    """`model.train(); losses = model(data); trainer.optimizer_step()` -- the reference's training iteration (train_mp3d.py:609-625
+    around custom_rcnn.py:435-461): every frame's memory is normalised from the loader's accumulated features and observation counts
+    (`create_implicit_memory`), `forward_model` runs per frame, losses and gradients are summed over the frames of the batch of
+    sequences, one optimizer step follows."""
+    from embodied_object_detection_amd import build_model, ops, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    from embodied_object_detection_amd.structures import Boxes, Instances
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "SOLVER.BASE_LR", 2e-5])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    model.train()
+    with pytest.raises(RuntimeError):
+        model([[]])                                                        # no trainer attached yet
+    trainer = Trainer(model, sd0)
+    H, W, n_cells = 128, 160, 400
+    g = torch.Generator().manual_seed(3)
+
+    def frame(i):
+        xy = torch.rand((5, 2), generator=g) * torch.tensor([W * 0.6, H * 0.6])
+        wh = torch.rand((5, 2), generator=g) * 50 + 10
+        inst = Instances((H, W))
+        inst.set("gt_boxes", Boxes(torch.cat([xy, xy + wh], dim=1)))
+        inst.set("gt_classes", torch.randint(0, 20, (5,), generator=g))
+        obs = torch.randint(0, 6, (n_cells,), generator=g).float()
+        return {"image": torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8), "instances": inst if i % 2 == 0 else
+                {"gt_boxes": inst.gt_boxes.tensor, "gt_classes": inst.gt_classes},
+                "memory": (torch.randn((n_cells, 512), generator=g) * obs.clamp(min=1)[:, None]).numpy(), "observations": obs.numpy(),
+                "proj_indices": torch.randint(0, n_cells, (H, W, 1), generator=g).numpy(), "sequence_name": f"s{i}", "memory_reset": i == 0}
+
+    data = [[frame(0), frame(1)], [frame(2)]]
+    # per frame, by hand
+    want_losses, want_grads = {}, None
+    for seq in data:
+        for f in seq:
+            gtb, gtc = Trainer._gt(f)
+            mem16 = ops.memory_normalize_f16(torch.from_numpy(f["memory"]).to(dev), torch.from_numpy(f["observations"]).to(dev))
+            rm = torch.from_numpy(f["memory"]).clone()                      # (from_numpy shares the array: the frame must stay as loaded)
+            ro = torch.from_numpy(f["observations"])
+            rm[ro > 1] = rm[ro > 1] / ro[ro > 1].unsqueeze(1)              # custom_rcnn.py:774
+            assert torch.equal(mem16.cpu(), rm.half())
+            l, gr = trainer.fm.forward_backward(f["image"].to(dev), gtb.to(dev), gtc.to(dev),
+                                                memory=(mem16, torch.from_numpy(f["proj_indices"]).to(dev).reshape(H, W).int()))
+            gl = [trainer.getters[g_["name"]](gr).clone() for g_ in trainer.groups]
+            want_grads = gl if want_grads is None else [a + b for a, b in zip(want_grads, gl)]
+            for k, v in l.items():
+                want_losses[k] = want_losses.get(k, 0.0) + float(v)
+    losses = model(data)
+    assert set(losses) == set(want_losses) and len(losses) == 10
+    for k, v in losses.items():
+        assert abs(float(v) - want_losses[k]) <= 1e-5 * max(abs(want_losses[k]), 1e-3), k
+    for a, b, g_ in zip(trainer._acc, want_grads, trainer.groups):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12), g_["name"]      # fp32 atomics in the ROIAlign backward
+    before = model.roi_heads.stages[0]["fc2"].w.clone()
+    trainer.optimizer_step()
+    assert trainer.iteration == 1 and trainer._acc is None and not torch.equal(before, model.roi_heads.stages[0]["fc2"].w)
+    with pytest.raises(RuntimeError):
+        trainer.optimizer_step()
+    again = sum(float(v) for v in model(data).values())
+    assert again < sum(want_losses.values())
+    model.eval()
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    out = model([[SyntheticSequence(0, H=H, W=W, n_frames=1).frame(0)]])
+    assert len(out) == 1 and "instances" in out[0]

@@ -233,3 +233,49 @@ def fill_missing(sd: Dict[str, torch.Tensor], seed: int = 0, num_classes: int = 
     for name in expected_shapes(num_classes):
         out[name] = sd[name] if name in sd else syn[name]
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Checkpoint OUT: the parameters a `modeling.training.Trainer` stepped, back in the reference's names and layouts, written in the
+# format `load_checkpoint` (and detectron2's DetectionCheckpointer, train_mp3d.py:523-531,659) reads.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def unpack_parameter(name: str, packed: torch.Tensor, shape: Tuple[int, ...]) -> torch.Tensor:
+    """A stepped tensor in the layout the kernels keep it in -> the reference's tensor of `shape`.
+    Convolutions: packed rows [Cout, (ky, kx, c)] (c padded to 4 for the stem) -> OIHW; `box_head.k.fc1`: columns in the pooled rows'
+    (7, 7, C) order -> the reference's flatten order (C, 7, 7); everything else is a reshape."""
+    t = packed.detach().to(torch.float32).cpu()
+    if len(shape) == 4:
+        O, I, KH, KW = shape
+        ipad = t.shape[1] // (KH * KW)
+        if t.shape[0] != O or ipad < I:
+            raise ValueError(f"{name}: packed {tuple(t.shape)} does not hold {shape}")
+        return t[:, :KH * KW * ipad].reshape(O, KH, KW, ipad)[..., :I].permute(0, 3, 1, 2).contiguous()
+    if len(shape) == 2 and name.endswith("fc1.weight") and "box_head" in name:
+        O, K = shape
+        c = K // 49
+        return t[:, :K].reshape(O, 7, 7, c).permute(0, 3, 1, 2).reshape(O, K).contiguous()
+    if len(shape) == 2:
+        return t[:shape[0], :shape[1]].contiguous()
+    return t.reshape(shape).contiguous()
+
+
+def export_state_dict(entries, base_sd: Dict[str, torch.Tensor], num_classes: int = 20) -> "OrderedDict[str, torch.Tensor]":
+    """`entries`: (reference parameter name, stepped tensor, ...) as `Trainer.entries` lists them; `base_sd`: the state dict the model was
+    built from (buffers and untrained tensors are taken from it) -> a complete reference-keyed state dict."""
+    shapes = expected_shapes(num_classes)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict((k, v.detach().clone() if torch.is_tensor(v) else v) for k, v in base_sd.items())
+    for e in entries:
+        name, tensor = e[0], e[1]
+        if name.endswith("centernet_head.scales"):                 # five `Scale` modules stepped as one tensor
+            for l, v in enumerate(tensor.detach().cpu().tolist()):
+                out[f"{name}.{l}.scale"] = torch.tensor([v], dtype=torch.float32)
+            continue
+        if name not in shapes:
+            raise KeyError(f"{name}: not a tensor of the reference's state dict")
+        out[name] = unpack_parameter(name, tensor, shapes[name])
+    return out
+
+
+def save_checkpoint(path: str, sd: Dict[str, torch.Tensor], iteration: int = 0) -> None:
+    """{'model': state dict, 'iteration': n}: what DetectionCheckpointer.save writes and `load_checkpoint` reads."""
+    torch.save({"model": OrderedDict((k, v) for k, v in sd.items()), "iteration": int(iteration)}, path)

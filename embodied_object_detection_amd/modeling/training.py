@@ -264,6 +264,12 @@ class ProposalTrainer:
         self.opt = ops.AdamW(self.groups, weight_decay=float(s.WEIGHT_DECAY), clip_value=float(clip.CLIP_VALUE) if bool(clip.ENABLED) else 0.0)
         self.iteration = 0
 
+    def state_dict(self, base_sd: Dict[str, torch.Tensor]):
+        """The stepped parameters in the reference's names and layouts, on top of `base_sd` (the state dict the model was built from):
+        what `DetectionCheckpointer` would save (`checkpoint.save_checkpoint` writes it; `load_checkpoint` + `build_model` read it)."""
+        from .. import checkpoint
+        return checkpoint.export_state_dict(self.entries, base_sd, self.model.roi_heads.num_classes)
+
     def step(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, lr_factor: float = 1.0, gt_classes=None, proposals=None,
              keys=None, generator=None):
         """One training iteration on one frame -> the losses (device scalars, of the weights BEFORE the update): the three proposal

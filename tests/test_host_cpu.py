@@ -503,3 +503,47 @@ def test_eval_loop_groups_ragged_scenes_for_a_lockstep_model():
     assert sorted(seen) == [(0, 20, 20), (1, 20, 20), (2, 5, 5), (3, 20, 20), (4, 7, 7)]
     assert seq["frames"] == par["frames"] == sum(lens)
     assert sorted(seq["records"].rows) == sorted(par["records"].rows) and len(seq["records"].rows) > 0
+
+
+def test_checkpoint_out_inverts_the_kernel_layouts(tmp_path):
+    """`checkpoint.unpack_parameter / export_state_dict / save_checkpoint`: the layouts a Trainer steps its tensors in (packed conv rows,
+    the stem's 4-channel taps, fc1's (7,7,C) columns, the five level scales as one tensor) go back to the reference's tensors exactly,
+    and the written file is what `load_checkpoint` reads (DetectionCheckpointer's {'model': ...} format)."""
+    import torch
+    from embodied_object_detection_amd import checkpoint, ops
+    sd = checkpoint.synthetic_state_dict(0)
+    shapes = checkpoint.expected_shapes(20)
+    base = "backbone.bottom_up.base"
+    entries = []
+    for name, cin_pad in ((f"{base}.conv1.weight", 4), (f"{base}.layer2.0.conv2.weight", None), (f"{base}.layer3.0.downsample.0.weight", None),
+                          ("backbone.fpn_output4.weight", None), ("proposal_generator.centernet_head.bbox_tower.3.weight", None)):
+        packed, _ = ops.pack_conv_weight(sd[name].float(), cin_pad)
+        entries.append((name, packed + 0.0))
+    entries.append(("backbone.map_merge_projection2.weight", sd["backbone.map_merge_projection2.weight"].reshape(256, 512).clone()))
+    w1 = sd["roi_heads.box_head.1.fc1.weight"]
+    entries.append(("roi_heads.box_head.1.fc1.weight", w1.view(-1, 256, 7, 7).permute(0, 2, 3, 1).reshape(w1.shape[0], -1).contiguous()))
+    b2 = torch.zeros((32, 1024))
+    b2[:4] = sd["roi_heads.box_predictor.0.bbox_pred.2.weight"]
+    entries.append(("roi_heads.box_predictor.0.bbox_pred.2.weight", b2[:4]))
+    entries.append(("roi_heads.box_head.0.fc2.bias", sd["roi_heads.box_head.0.fc2.bias"].clone()))
+    entries.append(("proposal_generator.centernet_head.scales", torch.tensor([1.5, 0.5, 2.0, 1.0, 0.25])))
+    out = checkpoint.export_state_dict(entries, sd)
+    assert list(out.keys()) == list(sd.keys())
+    h = "proposal_generator.centernet_head"
+    for k, v in sd.items():
+        if k.startswith(f"{h}.scales"):
+            continue
+        assert tuple(out[k].shape) == tuple(shapes.get(k, v.shape)) and torch.equal(out[k], v.float()), k
+    assert [float(out[f"{h}.scales.{l}.scale"]) for l in range(5)] == [1.5, 0.5, 2.0, 1.0, 0.25]
+    changed = dict(entries)["roi_heads.box_head.0.fc2.bias"]
+    changed += 1.0                                                     # a stepped tensor shows up in the export
+    out = checkpoint.export_state_dict(entries, sd)
+    assert torch.equal(out["roi_heads.box_head.0.fc2.bias"], sd["roi_heads.box_head.0.fc2.bias"] + 1.0)
+    path = str(tmp_path / "model_0000007.pth")
+    checkpoint.save_checkpoint(path, out, iteration=7)
+    back, report = checkpoint.load_checkpoint(path, verbose=False)
+    assert not report["missing"] and not report["shape_mismatch"] and torch.load(path, weights_only=False)["iteration"] == 7
+    assert all(torch.equal(back[k], out[k].float()) for k in back)
+    import pytest
+    with pytest.raises(KeyError):
+        checkpoint.export_state_dict([("roi_heads.no_such.weight", torch.zeros(3))], sd)

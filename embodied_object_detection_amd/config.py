@@ -159,7 +159,7 @@ def get_cfg() -> CfgNode:
         "SOLVER": {
             "LR_SCHEDULER_NAME": "WarmupMultiStepLR", "MAX_ITER": 40000, "BASE_LR": 0.001, "MOMENTUM": 0.9, "NESTEROV": False,
             "WEIGHT_DECAY": 0.0001, "WARMUP_FACTOR": 0.001, "WARMUP_ITERS": 1000, "WARMUP_METHOD": "linear", "IMS_PER_BATCH": 16,
-            "CHECKPOINT_PERIOD": 5000,
+            "CHECKPOINT_PERIOD": 5000, "TRAIN_ITER": -1,
             "CLIP_GRADIENTS": {"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0, "NORM_TYPE": 2.0},
             "USE_CUSTOM_SOLVER": False, "OPTIMIZER": "SGD", "BACKBONE_MULTIPLIER": 1.0, "CUSTOM_MULTIPLIER": 1.0,
             "CUSTOM_MULTIPLIER_NAME": [],

@@ -111,5 +111,30 @@ class SyntheticSequence:
             yield [self.frame(i) for i in range(e0, min(self.n_frames, e0 + EPISODE_LEN))]
 
 
+class SyntheticTrainingEpisodes:
+    """Episodes for the training loop when no data is on disk: the frames of `SyntheticSequence` with what the training loader adds
+    (loader.py:199-223 with MODEL.SEMMAP_PATH set): an accumulated memory `memory` [n_cells,512] with its observation counts
+    `observations` [n_cells] (seeded noise scaled by the counts).  `dataset[i]` = episode i as a list of frame dicts."""
+
+    def __init__(self, n_scenes: int, H: int = 640, W: int = 640, n_frames: int = 20, **kw):
+        self.scenes = [SyntheticSequence(s, H=H, W=W, n_frames=n_frames, **kw) for s in range(n_scenes)]
+        self.n_frames = n_frames
+
+    def __len__(self) -> int:
+        return len(self.scenes)
+
+    def __getitem__(self, index: int):
+        sc = self.scenes[index]
+        g = torch.Generator().manual_seed(7919 * (index + 1))
+        obs = torch.randint(0, 6, (sc.n_cells,), generator=g).float()
+        mem = (torch.randn((sc.n_cells, 512), generator=g) * obs.clamp(min=1.0)[:, None]).numpy()
+        frames = []
+        for i in range(self.n_frames):
+            f = sc.frame(i)
+            f["memory"], f["observations"] = mem, obs.numpy()
+            frames.append(f)
+        return frames
+
+
 def build_synthetic_dataset(n_sequences: int, **kw) -> List[SyntheticSequence]:
     return [SyntheticSequence(s, **kw) for s in range(n_sequences)]

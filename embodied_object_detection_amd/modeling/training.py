@@ -502,6 +502,9 @@ class Trainer(ProposalTrainer):
                 gt_boxes, gt_classes = self._gt(frame)
                 memory = None
                 if self.model.memory_type == "implicit_memory":
+                    if frame.get("observations") is None:
+                        raise ValueError("training reads frame['observations'] (custom_rcnn.py:765): point MODEL.SEMMAP_PATH at the "
+                                         "memory snapshots (`impicit_memory` / `observations` per episode file, loader.py:213-223)")
                     mem = torch.as_tensor(frame["memory"]).to(dev, torch.float32).contiguous()
                     obs = torch.as_tensor(frame["observations"]).to(dev, torch.float32).reshape(-1).contiguous()
                     proj = torch.as_tensor(frame["proj_indices"]).to(dev).reshape(int(img.shape[1]), int(img.shape[2])).to(torch.int32).contiguous()

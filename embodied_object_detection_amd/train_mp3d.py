@@ -7,8 +7,9 @@
         MODEL.MAP_FEAT_FUSION sum MODEL.MEMORY_TYPE implicit_memory MODEL.MAP_FEATURE_WEIGHT 5
 
 One process per GPU (detectron2 `launch` semantics): either started by `torch.distributed.run` (RANK / WORLD_SIZE in the
-environment) or spawned here for `--num-gpus N`; backend `nccl` (= RCCL over xGMI) on GPUs.  Training (`do_train`) is out
-of scope of the hot path.  The driver reads the reference's on-disk episodes when `MODEL.TEST_DATA_PATH` holds them
+environment) or spawned here for `--num-gpus N`; backend `nccl` (= RCCL over xGMI) on GPUs.  Without `--eval-only` the reference's
+`do_train` runs first (one process, as `train_mp3d.py:552-553` fixes it for the MP3D loader): `engine/train_loop.py` around the
+device step of `modeling/training.py`, then `do_test` on the trained model.  The driver reads the reference's on-disk episodes when `MODEL.TEST_DATA_PATH` holds them
 (`memory_data/*.h5`, `sensor_data/*.h5`, `JPEGImages/`: `data/mp3d.py`) and otherwise evaluates the
 deterministic synthetic scenes of SURVEY §8d.
 """
@@ -78,15 +79,55 @@ def do_test(cfg, model, args, rank: int, world: int):
     return out
 
 
+def do_train(cfg, args, rank: int, world: int):
+    """`do_train` (train_mp3d.py:509-659) with `DATALOADER.SAMPLER_TRAIN: MP3DLoader`: one process (the reference fixes world_size = 1
+    there, :552-553), episodes of `MODEL.TRAIN_DATA_PATH` (memory snapshots under `MODEL.SEMMAP_PATH`), or synthetic episodes when the
+    data is not on disk.  Returns the trained model (the same object serves `do_test`)."""
+    from . import build_model
+    from .checkpoint import fill_missing, load_checkpoint, synthetic_state_dict
+    from .engine import train_loop
+    from .modeling.training import Trainer
+    if world > 1:
+        raise NotImplementedError("the MP3D training loader runs on one process (train_mp3d.py:552-553: world_size = 1)")
+    num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+    if cfg.MODEL.WEIGHTS and os.path.exists(str(cfg.MODEL.WEIGHTS)):
+        sd = fill_missing(load_checkpoint(str(cfg.MODEL.WEIGHTS), num_classes)[0], 0, num_classes)
+    else:
+        sd = synthetic_state_dict(0, num_classes, cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH)
+    model = build_model(cfg, sd)
+    trainer = Trainer(model, sd)
+    data_root = str(cfg.MODEL.TRAIN_DATA_PATH)
+    ims = max(int(cfg.SOLVER.IMS_PER_BATCH) // world, 1)
+    if os.path.isdir(os.path.join(data_root, "memory_data")) and os.path.isdir(os.path.join(data_root, "sensor_data")):
+        from .data.mp3d import SMNetDetectionLoader, collate_smnet, map_mp3d_batch_to_coco
+        clip_path = cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH if cfg.MODEL.MEMORY_TYPE in ("semantic_gt", "map_gt") else None
+        loader = SMNetDetectionLoader(data_path=data_root, clip_path=clip_path, memory_type=cfg.MODEL.MEMORY_TYPE,
+                                      semmap_path=str(cfg.MODEL.SEMMAP_PATH))
+        batches, map_batch = train_loop.training_batches(loader, ims, seed=0, collate=collate_smnet), map_mp3d_batch_to_coco
+    else:
+        from .data.synthetic import SyntheticTrainingEpisodes
+        H, W = args.synthetic_size
+        ds = SyntheticTrainingEpisodes(args.synthetic_scenes, H=H, W=W, n_frames=min(args.synthetic_frames, 20))
+        batches, map_batch = train_loop.training_batches(ds, ims, seed=0), None
+    os.makedirs(str(cfg.OUTPUT_DIR), exist_ok=True)
+    rows = train_loop.do_train(cfg, model, trainer, batches, output_dir=str(cfg.OUTPUT_DIR), base_state_dict=sd, map_batch=map_batch,
+                               log=lambda r: print("[train] " + json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})))
+    if rows:
+        print(f"[train] {len(rows)} iterations, total loss {rows[0]['total_loss']:.4f} -> {rows[-1]['total_loss']:.4f}; "
+              f"{sum(r['time'] for r in rows) / len(rows) * 1e3:.1f} ms per iteration; proposal lists clamped: {trainer.fm.clamped}")
+    return model
+
+
 def main(args, rank: int = 0, world: int = 1, local_rank: int = 0):
     from . import build_model, setup_cfg
-    if not args.eval_only:
-        raise NotImplementedError("only --eval-only is in scope (training forward: SURVEY §8f rank 4)")
     opts = list(args.opts or [])
     if opts and opts[0] == "--":
         opts = opts[1:]
     opts += ["MODEL.DEVICE", f"cuda:{local_rank}"]
     cfg = setup_cfg(args.config_file or None, opts)
+    if not args.eval_only:
+        model = do_train(cfg, args, rank, world)                   # train_mp3d.py:740-741: do_train, then do_test on the trained model
+        return do_test(cfg, model, args, rank, world)
     if args.scenes_in_lockstep > 1 and args.lockstep_schedule == "launches":
         from .modeling.lockstep import LockstepScenes
         model = LockstepScenes(cfg, args.scenes_in_lockstep)

@@ -101,3 +101,34 @@ def test_oracle_matcher_and_sampler_hand_cases():
     keys = torch.tensor([0.9, 0.3, 0.1, 0.0, 0.2, 0.5, 0.5, 0.8, 0.7, 0.4, 0.95, 0.6])
     assert OL.sample_by_keys(cls, keys, 20, 8, 0.25).tolist() == [1, 4, 2, 5, 6, 7, 9, 11]
     assert OL.sample_by_keys(cls, keys, 20, 64, 0.25).tolist() == [1, 4, 8, 0, 2, 5, 6, 7, 9, 10, 11]
+
+
+def test_cascade_training_forward_matches_the_reference(golden_dir):
+    """`oracle/losses.py::cascade_training_losses` against `tests/golden/cascade_training.npz`: the reference's own
+    `DeticCascadeROIHeads.forward` run in TRAINING mode (detic_roi_heads.py:226-249, 88-147, 306-349) with three real
+    `DeticFastRCNNOutputLayers` + `ZeroShotClassifier`s (`gen_golden_cascade_training.py`; detectron2's matcher / sampler / pooler are
+    injected from the oracle's restatements there, so this pins the reference's OWN part: the stage chaining with the training-only
+    non-empty filter, the re-labelling per stage, the loss terms and their names, loss_mask without gt_masks)."""
+    import _inputs as I
+    from oracle import model as M
+    g = np.load(os.path.join(golden_dir, "cascade_training.npz"))
+    feats, boxes, scores = I.cascade_case()
+    sd = I.cascade_weights()
+    zs = torch.from_numpy(np.load(os.path.join(golden_dir, "cascade.npz"))["zs_weight"])
+    for k in range(3):
+        sd[f"roi_heads.box_predictor.{k}.cls_score.zs_weight"] = zs
+    gt, gc, keys = torch.from_numpy(g["gt_boxes"]), torch.from_numpy(g["gt_classes"]), torch.from_numpy(g["keys"])
+    with torch.no_grad():
+        losses, stages = OL.cascade_training_losses(feats, boxes, gt, gc, sd, M.OracleCfg(), I.CASCADE_HW, keys,
+                                                    ious=tuple(float(v) for v in g["ious"]), batch=int(g["batch"]))
+    names = [f"loss_{n}_stage{k}" for k in range(3) for n in ("cls", "box_reg")] + ["loss_mask"]
+    assert sorted(losses) == sorted(names)
+    for n in names:
+        assert abs(float(losses[n]) - float(g[n])) <= 1e-5 * max(abs(float(g[n])), 1e-3), (n, float(losses[n]), float(g[n]))
+    assert float(g["loss_box_reg_stage1"]) > 0 and float(g["loss_mask"]) == 0.0
+    for k in range(3):
+        np.testing.assert_allclose(stages[k]["boxes"].numpy(), g[f"stage{k}_boxes"], rtol=1e-5, atol=1e-4)
+    assert np.array_equal(stages[0]["boxes"].numpy(), g["stage0_boxes"])                        # the sampled rows themselves
+    assert np.array_equal(stages[0]["classes"].numpy(), g["sampled_classes"]) and int((g["sampled_classes"] < 20).sum()) == 8
+    allb = torch.cat([boxes, gt])
+    assert np.array_equal(allb[torch.from_numpy(g["sampled_rows"])].numpy(), g["stage0_boxes"]) and len(g["sampled_rows"]) == 32

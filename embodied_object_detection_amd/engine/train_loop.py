@@ -12,7 +12,7 @@ from __future__ import annotations
 import math
 import os
 import time
-from typing import Callable, Dict, Iterator, List, Optional, Sequence
+from typing import Callable, Dict, Iterator, List, Optional
 
 import torch
 

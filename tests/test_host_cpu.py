@@ -626,3 +626,23 @@ def test_do_train_loop_with_a_stub_step(tmp_path):
     bad = Diverged()
     with pytest.raises(FloatingPointError):
         train_loop.do_train(cfg, bad, tr, train_loop.training_batches(episodes, 1))
+
+
+def test_trainer_reads_ground_truth_of_both_frame_formats():
+    """`Trainer._gt`: the frame's ground truth as `map_mp3d_batch_to_coco` builds it (Instances with Boxes, train_mp3d.py:232-238) and as
+    the synthetic frames carry it (a dict of tensors) -> (boxes fp32 [N,4], classes int32 [N]); empty ground truth keeps its shapes."""
+    import numpy as np
+    import torch
+    from embodied_object_detection_amd.modeling.training import Trainer
+    from embodied_object_detection_amd.structures import Boxes, Instances
+    b = torch.tensor([[1.0, 2.0, 30.0, 40.0], [5.0, 6.0, 7.0, 8.0]])
+    c = torch.tensor([3, 19])
+    inst = Instances((48, 64))
+    inst.set("gt_boxes", Boxes(b))
+    inst.set("gt_classes", c)
+    for frame in ({"instances": inst}, {"instances": {"gt_boxes": b.double(), "gt_classes": c}},
+                  {"instances": {"gt_boxes": b.numpy(), "gt_classes": np.array([3, 19])}}):
+        gb, gc = Trainer._gt(frame)
+        assert gb.dtype == torch.float32 and gc.dtype == torch.int32 and torch.equal(gb, b) and gc.tolist() == [3, 19]
+    gb, gc = Trainer._gt({"instances": {"gt_boxes": torch.zeros((0, 4)), "gt_classes": torch.zeros((0,), dtype=torch.int64)}})
+    assert tuple(gb.shape) == (0, 4) and tuple(gc.shape) == (0,)

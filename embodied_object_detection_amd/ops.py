@@ -774,8 +774,12 @@ def sample_proposals(classes: torch.Tensor, keys: torch.Tensor, num_classes: int
     assert classes.dtype == torch.int32 and keys.dtype == torch.float32 and keys.numel() == R
     idx = torch.zeros((batch_size_per_image,), dtype=torch.int32, device=classes.device)
     counts = torch.zeros((2,), dtype=torch.int32, device=classes.device)
+    # the ABI takes the fraction as a float; hand over the mid-point of the bucket of detectron2's `int(batch * fraction)` (a double
+    # product) so that the float product truncates to the same count for every fraction (0.7 x 10 is 7 in double and 6.9999999 in float)
+    max_pos = int(batch_size_per_image * positive_fraction)
+    fraction = min((max_pos + 0.5) / batch_size_per_image, 1.0)
     st = _lib.load().eod_sample_proposals(classes.data_ptr(), keys.data_ptr(), R, num_classes, batch_size_per_image,
-                                          float(positive_fraction), idx.data_ptr(), counts.data_ptr(), _stream())
+                                          float(fraction), idx.data_ptr(), counts.data_ptr(), _stream())
     if st == -5:
         raise _lib.EodError(f"eod_sample_proposals: {R} proposals exceed the sampling kernel's capacity of 8192 rows")
     check(st, "eod_sample_proposals")

@@ -20,7 +20,7 @@ from __future__ import annotations
 import math
 import os
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -276,6 +276,38 @@ def export_state_dict(entries, base_sd: Dict[str, torch.Tensor], num_classes: in
     return out
 
 
-def save_checkpoint(path: str, sd: Dict[str, torch.Tensor], iteration: int = 0) -> None:
-    """{'model': state dict, 'iteration': n}: what DetectionCheckpointer.save writes and `load_checkpoint` reads."""
-    torch.save({"model": OrderedDict((k, v) for k, v in sd.items()), "iteration": int(iteration)}, path)
+def save_checkpoint(path: str, sd: Dict[str, torch.Tensor], iteration: int = 0, optimizer: Optional[Dict] = None,
+                    scheduler: Optional[Dict] = None) -> None:
+    """What DetectionCheckpointer.save writes (train_mp3d.py:521-523,654): {'model': state dict, 'iteration': n} and, when given, the
+    checkpointables 'optimizer' / 'scheduler'; the directory's `last_checkpoint` file names the newest save (fvcore
+    `Checkpointer.tag_last_checkpoint`), which is what `--resume` follows."""
+    obj = {"model": OrderedDict((k, v) for k, v in sd.items()), "iteration": int(iteration)}
+    if optimizer is not None:
+        obj["optimizer"] = optimizer
+    if scheduler is not None:
+        obj["scheduler"] = scheduler
+    torch.save(obj, path)
+    with open(os.path.join(os.path.dirname(os.path.abspath(path)), "last_checkpoint"), "w") as fh:
+        fh.write(os.path.basename(path))
+
+
+def last_checkpoint(output_dir: str) -> Optional[str]:
+    """fvcore `Checkpointer.get_checkpoint_file`: the file `last_checkpoint` names, or None (`resume_or_load` then falls back to
+    MODEL.WEIGHTS and the run starts at iteration 0)."""
+    tag = os.path.join(output_dir, "last_checkpoint")
+    if not os.path.exists(tag):
+        return None
+    with open(tag) as fh:
+        name = fh.read().strip()
+    path = os.path.join(output_dir, name)
+    return path if os.path.exists(path) else None
+
+
+def load_training_state(path: str) -> Dict:
+    """The non-model part of a checkpoint written by `save_checkpoint`: {'iteration', 'optimizer', 'scheduler'} for
+    `engine.train_loop.do_train(resume_state=...)`.  A file without a scheduler entry (weights only) resumes the schedule at
+    its stored iteration."""
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    it = int(obj.get("iteration", -1)) if isinstance(obj, dict) else -1
+    return {"iteration": it, "optimizer": obj.get("optimizer") if isinstance(obj, dict) else None,
+            "scheduler": (obj.get("scheduler") if isinstance(obj, dict) else None) or {"last_epoch": max(it, 0)}}

@@ -719,6 +719,221 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
 }
 
 // ------------------------------------------------------------------------------------------------------
+// CenterNet proposals, wide lists (the TRAINING thresholds: PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS_TH_TRAIN 0.9,
+// Base-C2_L_R5021k_640b64_4x_recurrent.yaml:45-49 -> centernet.py:214-219,603-745): up to 16384 merged candidates and 4096 kept
+// boxes, beyond what one workgroup's LDS holds.  Three launches behind cn_level_topk_kernel:
+//   cn_rank_decode_kernel   every candidate finds its rank in the merged (sqrt-score desc, position asc) order by binary searches
+//                           in the per-level lists (they are sorted already) and writes its decoded box there: a merge without a sort
+//   nms_matrix_kernel       the upper triangle of the [n, n/64] suppression bit matrix, one 64 x 64 block per wave, whole chip
+//   nms_scan_kernel         one workgroup per scene walks the list in chunks of 64: diagonal block resolved in one wave's registers,
+//                           the kept rows OR-ed into the removed set by all 16 waves (next chunk's rows prefetched unconditionally),
+//                           stops by the '>= kth' rule of centernet.py:733-741 and writes the kept boxes in order
+// ------------------------------------------------------------------------------------------------------
+#define WIDE_MAX_SLOTS 16384
+#define WIDE_MAX_WORDS (WIDE_MAX_SLOTS / 64)
+#define WIDE_MAX_CAP 4096
+
+// number of keys of a (descending by score) level list whose score is > s (strict = 1) or >= s (strict = 0)
+__device__ __forceinline__ int cn_count_above(const u64* __restrict__ keys, int n, float s, int strict) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const float v = key_score(keys[mid]);
+    const bool above = strict ? (v > s) : (v >= s);
+    if (above) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void cn_rank_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_out) {
+  const int total_slots = p.pk_off[p.levels];
+  const int scene = blockIdx.y;
+  p.cand_keys += (size_t)scene * total_slots;
+  p.cand_cnt += scene * 8;
+  sorted_boxes += (size_t)scene * total_slots * 4;
+  sorted_scores += (size_t)scene * total_slots;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) {
+    int n = 0;
+    for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
+    n_out[scene] = n;
+  }
+  if (s >= total_slots) return;
+  int level = 0;
+  while (level + 1 < p.levels && s >= p.pk_off[level + 1]) ++level;
+  if (s - p.pk_off[level] >= p.cand_cnt[level]) return;
+  const u64 k = p.cand_keys[s];
+  const float sc = key_score(k);
+  const unsigned g = key_index(k);
+  // rank = number of candidates that precede k in (score desc, position asc) order.  A level list is sorted by the HEAT; sqrt is
+  // monotone, so the keys of one sqrt-score form a run [a, b) -- inside it the positions are counted one by one (two heats can share
+  // a sqrt in fp32, and quantised logits give long runs)
+  int rank = 0;
+  for (int l = 0; l < p.levels; ++l) {
+    const u64* lk = p.cand_keys + p.pk_off[l];
+    const int nl = p.cand_cnt[l];
+    const int a = cn_count_above(lk, nl, sc, 1), b = cn_count_above(lk, nl, sc, 0);
+    rank += a;
+    for (int q = a; q < b; ++q) rank += key_index(lk[q]) < g ? 1 : 0;
+  }
+  const int i = (int)g - p.level_off[level];
+  const int w = p.level_w[level];
+  const int stride = p.level_stride[level];
+  const int gy_i = i / w, gx_i = i - gy_i * w;
+  const float gx = (float)(gx_i * stride + stride / 2);
+  const float gy = (float)(gy_i * stride + stride / 2);
+  const float* h = p.head + cn_head_row(p, scene, level, i) * p.head_stride;
+  const float scl = p.level_scale[level];
+  const float st = (float)stride;
+  const float r0 = fmaxf(h[1] * scl, 0.f) * st;
+  const float r1 = fmaxf(h[2] * scl, 0.f) * st;
+  const float r2 = fmaxf(h[3] * scl, 0.f) * st;
+  const float r3 = fmaxf(h[4] * scl, 0.f) * st;
+  const float x1 = gx - r0, y1 = gy - r1;
+  float x2 = gx + r2, y2 = gy + r3;
+  x2 = fmaxf(x2, x1 + 0.01f);
+  y2 = fmaxf(y2, y1 + 0.01f);
+  reinterpret_cast<float4*>(sorted_boxes)[rank] = make_float4(x1, y1, x2, y2);
+  sorted_scores[rank] = sc;
+}
+
+// bit (j & 63) of M[i][j >> 6], j > i: IoU(box i, box j) > thr.  Block = 4 waves = 4 column words of one 64-row block.
+__global__ __launch_bounds__(256) void nms_matrix_kernel(const float* __restrict__ sorted_boxes, const int* __restrict__ n_ptr,
+                                                          int total_slots, int words, float thr, u64* __restrict__ M) {
+  const int scene = blockIdx.z;
+  const int n = n_ptr[scene];
+  const int rb = blockIdx.y, cw = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cw < rb || rb * 64 >= n || cw * 64 >= n) return;              // wave-uniform
+  const float4* boxes = reinterpret_cast<const float4*>(sorted_boxes) + (size_t)scene * total_slots;
+  M += (size_t)scene * total_slots * words;
+  const int i = rb * 64 + lane, j = cw * 64 + lane;
+  const float4 bi = i < n ? boxes[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 bj = j < n ? boxes[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+  const int jn = min(64, n - cw * 64);
+  u64 bits = 0;
+  for (int c = 0; c < jn; ++c) {
+    const float a1 = __shfl(bj.x, c, 64), b1 = __shfl(bj.y, c, 64), a2 = __shfl(bj.z, c, 64), b2 = __shfl(bj.w, c, 64);
+    if (cw * 64 + c > i && iou_over(bi.x, bi.y, bi.z, bi.w, area_i, a1, b1, a2, b2, thr)) bits |= 1ull << c;
+  }
+  if (i < n) M[(size_t)i * words + cw] = bits;
+}
+
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores,
+                                                         const int* __restrict__ n_ptr, int total_slots, int words,
+                                                         const u64* __restrict__ M, int max_keep, ScanOut o) {
+  __shared__ u64 removed[WIDE_MAX_WORDS];
+  __shared__ u64 sh_kept;
+  __shared__ int sh_total, sh_stop;
+  __shared__ float sh_kth;
+  const int scene = blockIdx.x;
+  const int n = n_ptr[scene];
+  const float4* boxes = reinterpret_cast<const float4*>(sorted_boxes) + (size_t)scene * total_slots;
+  const float* scores = sorted_scores + (size_t)scene * total_slots;
+  M += (size_t)scene * total_slots * words;
+  o = scene_outputs(o, scene);
+  const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+  const int nw = (n + 63) >> 6;
+  for (int w = tid; w < WIDE_MAX_WORDS; w += 1024) removed[w] = 0;
+  if (tid == 0) {
+    sh_total = 0;
+    sh_stop = 0;
+    sh_kth = -1.0f;
+  }
+  __syncthreads();
+  // Every wave owns four rows of a chunk (grp, grp + 16, grp + 32, grp + 48), a lane the words c + 1 + lane + 64 q behind the
+  // diagonal.  The rows of chunk c + 1 are requested before chunk c is resolved: nothing on the serial path waits for HBM.
+  constexpr int Q = WIDE_MAX_WORDS / 64;
+  u64 nxt[4][Q];
+  u64 nd = 0;
+  float nsc = 0.f;
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = c * 64 + grp + 16 * r;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int w = c + 1 + lane + 64 * q;
+        nxt[r][q] = (row < n && w < nw) ? M[(size_t)row * words + w] : 0ull;
+      }
+    }
+    if (grp == 0) {
+      const int row = c * 64 + lane;
+      nd = row < n ? M[(size_t)row * words + c] : 0ull;
+      nsc = row < n ? scores[row] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int c = 0; c < nw; ++c) {
+    u64 cur[4][Q];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) cur[r][q] = nxt[r][q];
+    const u64 diag = nd;
+    const float sc = nsc;
+    if (c + 1 < nw) fetch(c + 1);
+    const int lim = min(64, n - c * 64);
+    if (grp == 0) {
+      u64 rem = removed[c];
+      if (lim < 64) rem |= ~0ull << lim;
+      u64 kept = 0;
+      for (int i = 0; i < lim; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag & 0xFFFFFFFFull), i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), i);
+        if (!((rem >> i) & 1ull)) {
+          kept |= 1ull << i;
+          rem |= ((u64)hi << 32) | lo;
+        }
+      }
+      // the cut: the first max_keep kept boxes, then every kept box whose score equals the max_keep-th's (centernet.py:733-741)
+      const int total0 = sh_total;
+      const bool mine = (kept >> lane) & 1ull;
+      const int r = total0 + __popcll(kept & ((1ull << lane) - 1ull));
+      float kth = sh_kth;
+      const u64 at_k = __ballot(mine && r == max_keep - 1);
+      if (at_k) kth = __shfl(sc, __ffsll((long long)at_k) - 1, 64);
+      const bool take = mine && (r < max_keep || sc >= kth);
+      const u64 taken = __ballot(take);
+      const bool over = __ballot(mine && !take) != 0;
+      if (take && r < o.cap) {
+        reinterpret_cast<float4*>(o.out_boxes)[r] = boxes[c * 64 + lane];
+        o.out_scores[r] = sc;
+      }
+      if (lane == 0) {
+        const int total = total0 + __popcll(taken);
+        sh_total = total;
+        sh_kth = kth;
+        sh_kept = taken;
+        // every later score is <= this chunk's last: past the cut only equal scores can still be taken
+        int stop = over ? 1 : 0;
+        if (!stop && total >= max_keep) {
+          const int nx = (c + 1) * 64;
+          if (nx >= n || scores[nx] < kth) stop = 1;
+        }
+        sh_stop = stop;
+      }
+    }
+    __syncthreads();
+    if (sh_stop) break;
+    const u64 kept = sh_kept;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      u64 acc = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((kept >> (grp + 16 * r)) & 1ull) acc |= cur[r][q];
+      const int w = c + 1 + lane + 64 * q;
+      if (acc && w < nw) atomicOr(&removed[w], acc);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) *o.out_count = sh_total < o.cap ? sh_total : o.cap;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // fast_rcnn_inference in one launch: threshold + sort + per-class NMS + top-k (+ unique rows)
 // ------------------------------------------------------------------------------------------------------
 // All detections of one proposal row carry the row's class-agnostic box, so per-class NMS never needs an IoU between two
@@ -1101,17 +1316,89 @@ SelWs carve(void* base, int cap_sort, int keep_cap, int cand_slots) {
 
 }  // namespace
 
+// Wide lists (levels * pre_nms_topk > 8192, the training thresholds): the packed candidate slots are bounded by the pyramid's
+// positions; behind the narrow layout sit the candidate count per scene and the suppression bit matrix.
+struct WideWs {
+  int slots;       // bound of the packed candidate slots of one scene
+  int words;       // 64-bit words per matrix row
+  int* n;          // [batch]
+  u64* matrix;     // [batch][slots][words]
+  size_t bytes;
+};
+
+static WideWs carve_wide(void* base, size_t narrow_bytes, int total_positions, int levels, int pre_nms_topk, int nb) {
+  WideWs w{};
+  w.slots = std::min(total_positions, levels * pre_nms_topk);
+  w.words = (w.slots + 63) / 64;
+  char* b = static_cast<char*>(base);
+  size_t off = narrow_bytes;
+  w.n = reinterpret_cast<int*>(b ? b + off : nullptr);
+  off += align_up(EOD_MAX_BATCH * sizeof(int));
+  w.matrix = reinterpret_cast<u64*>(b ? b + off : nullptr);
+  off += align_up((size_t)nb * w.slots * w.words * sizeof(u64));
+  w.bytes = off;
+  return w;
+}
+
 extern "C" size_t eod_proposals_workspace_bytes(int total_positions, int levels, int pre_nms_topk, int batch) {
-  (void)total_positions;
   const int slots = levels * pre_nms_topk, nb = batch > 1 ? batch : 1;
+  if (slots > 8192) {
+    const int ws = std::max(std::min(total_positions, slots), 1);
+    const size_t narrow = carve(nullptr, ws * nb, ws, ws * nb).bytes;
+    return carve_wide(nullptr, narrow, total_positions, levels, pre_nms_topk, nb).bytes;
+  }
   return carve(nullptr, slots * nb, slots, slots * nb).bytes;
+}
+
+// centernet.py:603-745 with lists beyond one workgroup's LDS (see the kernels above)
+static int centernet_proposals_wide(const EodProposalDesc* d, hipStream_t s) {
+  const int total = d->level_off[d->levels];
+  int packed = 0, max_level = 0;
+  for (int l = 0; l < d->levels; ++l) {
+    const int n = d->level_off[l + 1] - d->level_off[l];
+    if (n <= 0 || n > EOD_SORT_MAX || d->level_w[l] <= 0 || n % d->level_w[l] != 0) return EOD_ERR_CAPACITY;
+    packed += std::min(n, d->pre_nms_topk);
+    max_level = std::max(max_level, n);
+  }
+  if (packed > WIDE_MAX_SLOTS || d->cap < d->post_nms_topk || d->cap > WIDE_MAX_CAP) return EOD_ERR_CAPACITY;
+  const int nb = d->batch > 1 ? d->batch : 1;
+  if (nb > EOD_MAX_BATCH) return EOD_ERR_BAD_DIMS;
+  const int ws = std::min(total, d->levels * d->pre_nms_topk);          // >= packed
+  const SelWs w = carve(d->workspace, ws * nb, ws, ws * nb);
+  const WideWs ww = carve_wide(d->workspace, w.bytes, total, d->levels, d->pre_nms_topk, nb);
+  if (d->workspace_bytes < ww.bytes) return EOD_ERR_CAPACITY;
+  CnArgs a{};
+  a.batch = nb;
+  a.head = d->head_out; a.head_stride = d->head_stride; a.levels = d->levels;
+  for (int l = 0; l <= d->levels; ++l) a.level_off[l] = d->level_off[l];
+  for (int l = 0; l < d->levels; ++l) {
+    a.level_w[l] = d->level_w[l];
+    a.level_stride[l] = d->level_stride[l];
+    a.level_scale[l] = d->level_scale[l];
+  }
+  a.score_thresh = d->score_thresh; a.topk = d->pre_nms_topk; a.cand_keys = w.cand_keys; a.cand_cnt = w.cand_cnt;
+  a.pk_off[0] = 0;
+  for (int l = 0; l < d->levels; ++l) a.pk_off[l + 1] = a.pk_off[l] + std::min(d->level_off[l + 1] - d->level_off[l], d->pre_nms_topk);
+  if (max_level <= 8192)
+    hipLaunchKernelGGL(cn_level_topk_kernel<8>, dim3(d->levels, nb), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL(cn_level_topk_kernel<16>, dim3(d->levels, nb), dim3(1024), 0, s, a);
+  // the kernels below address the scenes' lists with the PACKED slot count as their stride
+  const int words = (packed + 63) / 64;
+  hipLaunchKernelGGL(cn_rank_decode_kernel, dim3((packed + 255) / 256, nb), dim3(256), 0, s, a, w.sorted_boxes, w.sorted_scores, ww.n);
+  hipLaunchKernelGGL(nms_matrix_kernel, dim3((words + 3) / 4, words, nb), dim3(256), 0, s, w.sorted_boxes, ww.n, packed, words,
+                     d->nms_thresh, ww.matrix);
+  ScanOut o{d->out_boxes, d->out_scores, nullptr, nullptr, d->out_count, d->cap, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(nb), dim3(1024), 0, s, w.sorted_boxes, w.sorted_scores, ww.n, packed, words, ww.matrix,
+                     d->post_nms_topk, o);
+  return eod_launch_status();
 }
 
 extern "C" int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream) {
   if (!d || !d->head_out || !d->out_boxes || !d->out_scores || !d->out_count || !d->workspace) return EOD_ERR_NULL;
   if (d->levels < 1 || d->levels > 5 || d->pre_nms_topk < 1 || d->head_stride < 5) return EOD_ERR_BAD_DIMS;
   const int slots = d->levels * d->pre_nms_topk;
-  if (slots > 8192) return EOD_ERR_CAPACITY;
+  if (slots > 8192) return centernet_proposals_wide(d, (hipStream_t)stream);
   for (int l = 0; l < d->levels; ++l) {
     const int n = d->level_off[l + 1] - d->level_off[l];
     if (n <= 0 || n > EOD_SORT_MAX || d->level_w[l] <= 0 || n % d->level_w[l] != 0) return EOD_ERR_CAPACITY;

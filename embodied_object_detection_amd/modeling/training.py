@@ -212,9 +212,12 @@ class ProposalTrainer:
         def sync_scales():
             pg.scales = [float(v) for v in self.scales.cpu().tolist()]
             pg._plans.clear()                                    # the decoders carry the scales in their descriptors
-            for loss in self.step_fn._loss.values():
+            descs = [loss.desc for loss in self.step_fn._loss.values()]
+            if self.fm is not None:
+                descs += [dec.desc for dec in self.fm._dec.values()]
+            for d in descs:
                 for l, v in enumerate(pg.scales):
-                    loss.desc.level_scale[l] = v
+                    d.level_scale[l] = v
         self.after.append(sync_scales)
 
         if self.fm is not None:
@@ -248,6 +251,11 @@ class ProposalTrainer:
                 bw.conv.w_split = None                           # bf16x3 pieces, if that arithmetic was in use
         self.after.append(stale_caches)
         s = cfg.SOLVER
+        if bool(cfg.FP16):
+            # custom_rcnn.py:607-618 runs the backbone under autocast on a half image and train_mp3d.py:577-578,628-631 scales the loss
+            # with a GradScaler; this step computes in fp32 throughout.  Silently training in another arithmetic is not an option.
+            raise NotImplementedError("FP16: True (autocast backbone + GradScaler, custom_rcnn.py:607-618, train_mp3d.py:577-631) is not "
+                                      "implemented: the training step computes in fp32.  Pass `FP16 False` to train in fp32.")
         if str(s.OPTIMIZER) != "ADAMW":
             raise NotImplementedError("the device optimizer is AdamW (SOLVER.OPTIMIZER ADAMW, Base-...recurrent.yaml)")
         frozen = []
@@ -269,6 +277,15 @@ class ProposalTrainer:
         what `DetectionCheckpointer` would save (`checkpoint.save_checkpoint` writes it; `load_checkpoint` + `build_model` read it)."""
         from .. import checkpoint
         return checkpoint.export_state_dict(self.entries, base_sd, self.model.roi_heads.num_classes)
+
+    def optimizer_state(self) -> Dict:
+        """The optimizer's moments and step counts by reference parameter name (the 'optimizer' entry of a checkpoint)."""
+        return self.opt.state_dict()
+
+    def load_optimizer_state(self, sd: Dict) -> None:
+        """`--resume` (train_mp3d.py:524): continue with the stored moments / step counts instead of a cold AdamW."""
+        self.opt.load_state_dict(sd)
+        self.iteration = max((int(e["step"]) for e in sd.values()), default=0)
 
     def step(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, memory=None, lr_factor: float = 1.0, gt_classes=None, proposals=None,
              keys=None, generator=None):
@@ -296,8 +313,7 @@ class DetectorTraining:
     Runs on the layers of the inference path (`roi_heads.stages`): matching / sampling / logits / losses are the kernels of
     `csrc/train_losses.hip`, the rest the hot path's ROIAlign and GEMMs at N = the sampled row count.  Also returns each stage's
     loss gradients w.r.t. the predictor outputs (d scores, d deltas) and keeps the activations a backward pass needs.  The
-    proposals are an input: the reference draws them with PRE/POST_NMS_TOPK_TRAIN 4000 / 2000, beyond the capacity of the
-    inference-sized selection kernels (8192 candidate slots, 512 kept)."""
+    proposals are an input (`ForwardModelTraining.train_proposals` decodes them with PRE / POST_NMS_TOPK_TRAIN 4000 / 2000)."""
 
     def __init__(self, model):
         cfg = model.cfg
@@ -332,9 +348,12 @@ class DetectorTraining:
         _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[0], self.C)
         if keys is None:
             keys = torch.rand((boxes.shape[0],), device=self.dev, generator=generator)
+        else:
+            keys = keys[:boxes.shape[0]].contiguous()              # one key per row; a caller that cannot know R may pass more
         idx, counts = ops.sample_proposals(cls, keys, self.C, self.batch, self.frac)
         n = int(counts.cpu()[1])                                   # the reference's nonzero() / randperm sizes
         rows = idx[:n].long()
+        self.last_rows = rows
         return boxes.index_select(0, rows), cls.index_select(0, rows), gtb.index_select(0, rows), rows
 
     def run_stage(self, P, boxes: torch.Tensor, k: int):
@@ -426,29 +445,33 @@ class ForwardModelTraining:
     the ROI heads' pyramid gradients join the proposal head's before the backbone's backward.  Returns the reference's loss dict
     (:665-673: detector losses + proposal losses) and the gradient of every parameter.
 
-    The training-mode proposal lists are clamped to the selection kernels' capacity (8192 candidate slots over the levels, 448 kept)
-    where the yaml asks for PRE / POST_NMS_TOPK_TRAIN 4000 / 2000: `self.clamped` says whether that happened."""
+    The training-mode proposal lists have the yaml's sizes (PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS_TH_TRAIN 0.9,
+    Base-C2_L_R5021k_640b64_4x_recurrent.yaml:45-49): `eod_centernet_proposals` takes its wide path (rank merge of the per-level
+    lists, suppression bit matrix over the chip, one scanning workgroup; csrc/select.hip)."""
 
     def __init__(self, model, sd: Dict[str, torch.Tensor], prop: Optional[ProposalTraining] = None):
         self.model, self.dev = model, model.device
         self.prop = prop if prop is not None else ProposalTraining(model, sd)
         self.det = DetectorTraining(model)
         c = model.cfg.MODEL.CENTERNET
-        levels = len(c.FPN_STRIDES)
-        self.pre, self.post = min(int(c.PRE_NMS_TOPK_TRAIN), 8192 // levels), min(int(c.POST_NMS_TOPK_TRAIN), 448)
-        self.clamped = self.pre < int(c.PRE_NMS_TOPK_TRAIN) or self.post < int(c.POST_NMS_TOPK_TRAIN)
+        self.pre, self.post = int(c.PRE_NMS_TOPK_TRAIN), int(c.POST_NMS_TOPK_TRAIN)
         self.nms_train, self.score_thresh = float(c.NMS_TH_TRAIN), float(c.INFERENCE_TH)
         self._dec: Dict[tuple, ops.ProposalDecoder] = {}
 
+    def decoder(self, shapes, head_stride: int) -> ops.ProposalDecoder:
+        """One decoder per pyramid shape; the level scales are trained parameters and are patched into its descriptor after every
+        optimizer step (`ProposalTrainer.sync_scales`)."""
+        pg = self.prop.pg
+        key = (tuple(shapes), head_stride)
+        if key not in self._dec:
+            cap = (self.post + 48 + 31) // 32 * 32                      # room for the '>= kth' ties (centernet.py:739)
+            self._dec[key] = ops.ProposalDecoder(shapes, pg.strides, pg.scales, self.score_thresh, self.pre, self.post, self.nms_train, cap,
+                                                 self.dev, head_stride=head_stride)
+        return self._dec[key]
+
     def train_proposals(self, head: torch.Tensor, shapes) -> torch.Tensor:
         """`predict_instances` with the training thresholds on the head's raw rows [P, 32] -> proposal boxes [R,4] (detached)."""
-        pg = self.prop.pg
-        key = (tuple(shapes), tuple(pg.scales))
-        if key not in self._dec:
-            cap = (self.post + 64 + 31) // 32 * 32
-            self._dec[key] = ops.ProposalDecoder(shapes, pg.strides, pg.scales, self.score_thresh, self.pre, self.post, self.nms_train, cap,
-                                                 self.dev, head_stride=int(head.shape[1]))
-        boxes, _, count = self._dec[key](head)
+        boxes, _, count = self.decoder(shapes, int(head.shape[1]))(head)
         return boxes[:int(count.cpu()[0])].clone()
 
     def forward_backward(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, memory=None, proposals=None,

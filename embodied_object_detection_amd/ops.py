@@ -823,6 +823,24 @@ class AdamW:
         self.steps = [0] * len(groups)
         self.lib = _lib.load()
 
+    def state_dict(self) -> Dict:
+        """{parameter name: {'step', 'exp_avg', 'exp_avg_sq'}} on the host -- what DetectionCheckpointer stores for the optimizer
+        (train_mp3d.py:521-523), keyed by the reference's parameter names instead of torch's positional ids."""
+        return {g["name"]: {"step": self.steps[i], "exp_avg": self.state[i][0].cpu(), "exp_avg_sq": self.state[i][1].cpu()}
+                for i, g in enumerate(self.groups)}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        missing = [g["name"] for g in self.groups if g["name"] not in sd]
+        if missing:
+            raise KeyError(f"optimizer state without {len(missing)} of this model's parameters (first: {missing[0]})")
+        for i, g in enumerate(self.groups):
+            e = sd[g["name"]]
+            if tuple(e["exp_avg"].shape) != tuple(self.state[i][0].shape):
+                raise ValueError(f"optimizer state of {g['name']}: shape {tuple(e['exp_avg'].shape)} != {tuple(self.state[i][0].shape)}")
+            self.steps[i] = int(e["step"])
+            self.state[i][0].copy_(e["exp_avg"])
+            self.state[i][1].copy_(e["exp_avg_sq"])
+
     def step(self, grads: Sequence[Optional[torch.Tensor]], lr_factor: float = 1.0):
         """`grads[i]`: gradient of group i's tensor (None: no gradient this iteration, the tensor is skipped as torch does)."""
         for i, (g, grad) in enumerate(zip(self.groups, grads)):

@@ -55,14 +55,19 @@ def param_groups_from_cfg(cfg, named_parameters) -> List[Dict]:
 
 
 def warmup_cosine_lr_factor(it: int, max_iter: int, warmup_iters: int, warmup_factor: float, warmup_method: str = "linear") -> float:
-    """detectron2 `WarmupCosineLR.get_lr` / `_get_warmup_factor_at_iter`: factor on every group's base rate at iteration `it`."""
-    if it >= warmup_iters:
-        w = 1.0
-    elif warmup_method == "constant":
-        w = warmup_factor
-    elif warmup_method == "linear":
-        alpha = it / warmup_iters
-        w = warmup_factor * (1 - alpha) + alpha
-    else:
-        raise ValueError(f"Unknown warmup method: {warmup_method}")
-    return w * 0.5 * (1.0 + math.cos(math.pi * it / max_iter))
+    """detectron2 `build_lr_scheduler` for LR_SCHEDULER_NAME WarmupCosineLR (called at train_mp3d.py:519): `LRMultiplier` over
+    `WarmupParamScheduler(CosineParamScheduler(1, 0), warmup_factor, min(warmup_iters / max_iter, 1), method)`: the factor on every
+    group's base rate when `it` scheduler steps have been taken.  Past the warmup it is the cosine at it / max_iter; inside, a line
+    from warmup_factor x cosine(0) to the cosine's value where the warmup ends ("linear") or warmup_factor x cosine(0) ("constant")."""
+    cosine = lambda where: 0.5 * (1.0 + math.cos(math.pi * where))
+    where = it / max_iter
+    wlen = min(warmup_iters / max_iter, 1.0)
+    if where >= wlen:
+        return cosine(min(where, 1.0))
+    start = warmup_factor * cosine(0.0)
+    if warmup_method == "constant":
+        return start
+    if warmup_method == "linear":
+        a = where / wlen
+        return cosine(wlen) * a + start * (1.0 - a)
+    raise ValueError(f"Unknown warmup method: {warmup_method}")

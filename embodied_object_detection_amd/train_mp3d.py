@@ -68,7 +68,15 @@ def do_test(cfg, model, args, rank: int, world: int):
         offs = dict(enumerate(episode_offsets([args.synthetic_frames] * args.synthetic_scenes)))
         eps = [min(20, args.synthetic_frames - e0) for e0 in range(0, args.synthetic_frames, 20)]           # episodes of 20
         per_rank = [eps * len(shard_scenes(args.synthetic_scenes, r, world)) for r in range(world)]
-    res = inference_on_scenes(model, scenes, rank, max_rows=max(rows_needed(e) for e in per_rank), scene_episode_offset=offs)
+    # detectron2's `inference_context` (train_mp3d.py:142,366-378): evaluate in eval mode, hand the model back as it came
+    was_training = bool(getattr(model, "training", False))
+    if was_training:
+        model.eval()
+    try:
+        res = inference_on_scenes(model, scenes, rank, max_rows=max(rows_needed(e) for e in per_rank), scene_episode_offset=offs)
+    finally:
+        if was_training:
+            model.train()
     buf = gather_records(res["records"], rank, world, model.device)
     out = None
     if rank == 0:
@@ -90,8 +98,17 @@ def do_train(cfg, args, rank: int, world: int):
     if world > 1:
         raise NotImplementedError("the MP3D training loader runs on one process (train_mp3d.py:552-553: world_size = 1)")
     num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
-    if cfg.MODEL.WEIGHTS and os.path.exists(str(cfg.MODEL.WEIGHTS)):
-        sd = fill_missing(load_checkpoint(str(cfg.MODEL.WEIGHTS), num_classes)[0], 0, num_classes)
+    # checkpointer.resume_or_load(MODEL.WEIGHTS, resume) (train_mp3d.py:524-527): with --resume the output directory's last
+    # checkpoint (weights, optimizer, scheduler, iteration) if there is one, else MODEL.WEIGHTS as weights only
+    from .checkpoint import last_checkpoint, load_training_state
+    resume_state = None
+    weights = str(cfg.MODEL.WEIGHTS) if cfg.MODEL.WEIGHTS else ""
+    if args.resume and last_checkpoint(str(cfg.OUTPUT_DIR)) is not None:
+        weights = last_checkpoint(str(cfg.OUTPUT_DIR))
+        resume_state = load_training_state(weights)
+        print(f"[train] resuming from {weights} (iteration {resume_state['iteration']})")
+    if weights and os.path.exists(weights):
+        sd = fill_missing(load_checkpoint(weights, num_classes)[0], 0, num_classes)
     else:
         sd = synthetic_state_dict(0, num_classes, cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH)
     model = build_model(cfg, sd)
@@ -110,11 +127,12 @@ def do_train(cfg, args, rank: int, world: int):
         ds = SyntheticTrainingEpisodes(args.synthetic_scenes, H=H, W=W, n_frames=min(args.synthetic_frames, 20))
         batches, map_batch = train_loop.training_batches(ds, ims, seed=0), None
     os.makedirs(str(cfg.OUTPUT_DIR), exist_ok=True)
-    rows = train_loop.do_train(cfg, model, trainer, batches, output_dir=str(cfg.OUTPUT_DIR), base_state_dict=sd, map_batch=map_batch,
+    rows = train_loop.do_train(cfg, model, trainer, batches, resume_state=resume_state, output_dir=str(cfg.OUTPUT_DIR), base_state_dict=sd,
+                               map_batch=map_batch, do_test=lambda: do_test(cfg, model, args, rank, world),
                                log=lambda r: print("[train] " + json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})))
     if rows:
         print(f"[train] {len(rows)} iterations, total loss {rows[0]['total_loss']:.4f} -> {rows[-1]['total_loss']:.4f}; "
-              f"{sum(r['time'] for r in rows) / len(rows) * 1e3:.1f} ms per iteration; proposal lists clamped: {trainer.fm.clamped}")
+              f"{sum(r['time'] for r in rows) / len(rows) * 1e3:.1f} ms per iteration; train-mode proposal lists {trainer.fm.pre} / {trainer.fm.post}")
     return model
 
 

@@ -258,6 +258,7 @@ def cascade_training_losses(feats, prop_boxes: torch.Tensor, gt_boxes: torch.Ten
     boxes = torch.cat([prop_boxes, gt_boxes]) if append_gt else prop_boxes          # label_and_sample_proposals (:232)
     _, _, cls, gtb = match_label(boxes, gt_boxes, gt_classes, ious[0], cfg.num_classes)
     rows = sample_by_keys(cls, keys, cfg.num_classes, batch, positive_fraction)
+    sampled_rows = rows
     boxes, cls, gtb = boxes[rows], cls[rows], gtb[rows]
     losses, stages = {}, []
     for k in range(3):
@@ -274,7 +275,7 @@ def cascade_training_losses(feats, prop_boxes: torch.Tensor, gt_boxes: torch.Ten
             ab = F.relu(F.linear(a2, sd[f"roi_heads.box_predictor.{k}.bbox_pred.0.weight"], sd[f"roi_heads.box_predictor.{k}.bbox_pred.0.bias"]))
         losses[f"loss_cls_stage{k}"] = sigmoid_cross_entropy_loss(logits, cls)
         losses[f"loss_box_reg_stage{k}"] = box_reg_loss(boxes, gtb, deltas, cls, cfg.num_classes, M.CASCADE_WEIGHTS[k], smooth_l1_beta)
-        stages.append(dict(boxes=boxes, classes=cls, gt_boxes=gtb, logits=logits, deltas=deltas, h1=a1, h2=a2, hb=ab))
+        stages.append(dict(boxes=boxes, classes=cls, gt_boxes=gtb, logits=logits, deltas=deltas, h1=a1, h2=a2, hb=ab, rows=sampled_rows))
         boxes = O.apply_deltas(deltas.detach(), boxes, M.CASCADE_WEIGHTS[k])       # predict_boxes (:124)
     losses["loss_mask"] = torch.zeros(())                                           # _get_empty_mask_loss, MASK_ON
     return losses, stages

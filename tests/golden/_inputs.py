@@ -159,6 +159,30 @@ def centernet_decode_case(variant: str = "plain", seed: int = 31):
     return agn, reg
 
 
+DECODE_TRAIN_HW = (512, 640)       # P3 = 64x80 = 5120 positions > PRE_NMS_TOPK_TRAIN (4000); 6820 positions > POST_NMS_TOPK_TRAIN (2000)
+
+
+def centernet_decode_train_case(seed: int = 77):
+    """Raw head outputs for a 512x640 image, continuous logits: the training thresholds' per-level cut (4000) and post-NMS cut (2000)
+    are both reached; boxes of 2-6 strides overlap their grid neighbours enough for NMS 0.9 to suppress some."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = DECODE_TRAIN_HW
+    agn, reg = [], []
+    for l, s in enumerate((8, 16, 32, 64, 128)):
+        h, w = (H + s - 1) // s, (W + s - 1) // s
+        a = torch.randn((1, 1, h, w), generator=g) * 1.5 - 0.5
+        a[0, 0, ::9, ::11] = -20.0                     # sigmoid < 1e-4: not a candidate
+        r = torch.rand((1, 4, h, w), generator=g) * 2.0 + 1.0
+        r = r * (1.0 + 0.02 * torch.randn((1, 1, h, w), generator=g))
+        # a smooth field: neighbouring positions predict nearly the same box corners -> IoU > 0.9 pairs exist
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        r[0, 0] = 3.0 + (xx % 4) * 1.0
+        r[0, 2] = 6.0 - (xx % 4) * 1.0
+        agn.append(a)
+        reg.append(r)
+    return agn, reg
+
+
 CASCADE_HW = (128, 160)
 
 

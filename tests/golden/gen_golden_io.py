@@ -17,7 +17,11 @@ over the product's HDF5 binding (`data/h5io.py`, libhdf5 through ctypes -- h5py 
 detectron2-owned helpers the loader calls (`PathManager.open`, `_apply_exif_orientation`, `convert_PIL_to_numpy`) are restated
 from their published semantics.  No reference source or bytecode is copied.
 
-    python tests/golden/gen_golden_io.py            # writes tests/golden/mp3d_loader.npz, mp3d_driver.json
+* `mp3d_train_driver.json` -- `do_train` (`Detic/train_mp3d.py:509-659`) with a stub model / optimizer / checkpointer: the episodes
+  of every iteration, the iteration numbering, the lr of every iteration, the checkpoint rhythm (names, stored `iteration`), the
+  periodic `do_test`, the writers' rhythm and the start of a resumed run.
+
+    python tests/golden/gen_golden_io.py            # writes tests/golden/mp3d_loader.npz, mp3d_driver.json, mp3d_train_driver.json
 """
 from __future__ import annotations
 
@@ -271,6 +275,200 @@ def gen_driver(driver_mod, loader_mod, root):
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# do_train (train_mp3d.py:509-659) with a stub model: the loop's own control flow
+# ------------------------------------------------------------------------------------------------
+# detectron2 / fvcore pieces the loop calls, restated from their published semantics (not in the reference tree: "unpinned"):
+class _TrainingSampler:
+    """detectron2 `TrainingSampler(size, shuffle=True, seed)`: an infinite stream of seeded permutations.  The reference passes no seed
+    (`shared_random_seed()`: the order differs from run to run); the fixture fixes it so that the stream can be compared."""
+    SEED = 20
+
+    def __init__(self, size, shuffle=True, seed=None):
+        self.size, self.shuffle, self.seed = size, shuffle, _TrainingSampler.SEED if seed is None else int(seed)
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed)
+        while True:
+            yield from (torch.randperm(self.size, generator=g).tolist() if self.shuffle else list(range(self.size)))
+
+
+def _warmup_cosine_scheduler(cfg, optimizer):
+    """detectron2 `build_lr_scheduler` for WarmupCosineLR: LRMultiplier(WarmupParamScheduler(CosineParamScheduler(1, 0), warmup_factor,
+    min(warmup_iters / max_iter, 1), method), max_iter): the multiplier of iteration i is evaluated at where = i / max_iter."""
+    import math
+    s = cfg.SOLVER
+    max_iter, wi, wf = int(s.MAX_ITER), int(s.WARMUP_ITERS), float(s.WARMUP_FACTOR)
+    wlen = min(wi / max_iter, 1.0)
+
+    def mult(i):
+        where = i / max_iter if i < max_iter else 1.0 - 1e-12            # LRMultiplier clamps the last step
+        cos = 0.5 * (1.0 + math.cos(math.pi * where))
+        if where >= wlen:
+            return cos
+        end = 0.5 * (1.0 + math.cos(math.pi * wlen))                     # the warmup ends on the cosine's value there
+        start = wf * 1.0                                                   # warmup_factor x the schedule's value at 0
+        a = where / wlen
+        return end * a + start * (1 - a) if str(s.WARMUP_METHOD) == "linear" else start
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, mult)
+
+
+class _Checkpointer:
+    """fvcore `Checkpointer` as `DetectionCheckpointer(model, dir, optimizer=, scheduler=)`: `save(name, **extra)` stores the model,
+    every checkpointable's `state_dict()` and the extra state (recorded: name, extra, the checkpointables' names, the scheduler's
+    `last_epoch`); `resume_or_load(path, resume=True)` loads the last checkpoint -- `load_state_dict` on every checkpointable -- and
+    returns its extra state; with `resume=False` it loads `path` as weights only and returns what that file holds besides them."""
+    found = {}          # the last checkpoint of the output directory: {"iteration": i, "optimizer": sd, "scheduler": sd} or {}
+    saves = None
+
+    def __init__(self, model, save_dir="", **checkpointables):
+        self.objs = dict(checkpointables)
+
+    def resume_or_load(self, path, *, resume=True):
+        f = _Checkpointer.found
+        if resume and f:
+            for k, obj in self.objs.items():
+                obj.load_state_dict(f[k])
+            return {"iteration": f["iteration"]}
+        return {"iteration": f["iteration"]} if f else {}       # MODEL.WEIGHTS with an 'iteration' entry: do_train must ignore it (:526-527)
+
+    def save(self, name, **extra):
+        _Checkpointer.saves.append([name + ".pth", {k: int(v) for k, v in extra.items()}, sorted(self.objs),
+                                    int(self.objs["scheduler"].last_epoch)])
+
+
+class _PeriodicCheckpointer:
+    """fvcore `PeriodicCheckpointer.step`: save `model_{iteration:07d}` when (iteration + 1) % period == 0, `model_final` when
+    iteration >= max_iter - 1; both with `iteration=` the number it was handed."""
+
+    def __init__(self, checkpointer, period, max_iter=None, max_to_keep=None, file_prefix="model"):
+        self.c, self.period, self.max_iter, self.prefix = checkpointer, int(period), max_iter, file_prefix
+
+    def step(self, iteration, **kw):
+        iteration = int(iteration)
+        if (iteration + 1) % self.period == 0:
+            self.c.save("{}_{:07d}".format(self.prefix, iteration), iteration=iteration, **kw)
+        if self.max_iter is not None and iteration >= self.max_iter - 1:
+            self.c.save(f"{self.prefix}_final", iteration=iteration, **kw)
+
+
+class _EventStorage:
+    """detectron2 `EventStorage(start_iter)`: `iter`, `step()`, `put_scalar(s)`; records the `lr` scalar with the iteration it is filed under."""
+    rows = None
+
+    def __init__(self, start_iter=0):
+        self.iter = start_iter
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def step(self):
+        self.iter += 1
+
+    def put_scalars(self, **kw):
+        if "total_loss" in kw:
+            _EventStorage.rows.append({"storage_iter": self.iter, "total_loss": float(kw["total_loss"])})
+
+    def put_scalar(self, name, value, smoothing_hint=True):
+        if name == "lr":
+            _EventStorage.rows[-1]["lr"] = float(value)
+
+
+class _Writer:
+    writes = None
+
+    def __init__(self, *a, **k):
+        pass
+
+    def write(self):
+        _Writer.writes.append(len(_EventStorage.rows))
+
+
+class _StubTrainModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(()))
+        self.calls = []
+
+    def forward(self, data):
+        assert self.training
+        self.calls.append([[ep[0]["sequence_name"], len(ep), [bool(f["memory_reset"]) for f in ep], type(ep[0]["instances"]).__name__]
+                           for ep in data])
+        n = len(self.calls)
+        return {"loss_a": self.w * (2.0 / n), "loss_b": self.w * self.w * (1.0 / n)}
+
+
+def _ns(d):
+    return types.SimpleNamespace(**{k: _ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def gen_train_driver(driver_mod, loader_mod, root):
+    """`do_train` (train_mp3d.py:509-659) on the written dataset, cfg.DATALOADER.SAMPLER_TRAIN 'MP3DLoader': which episodes reach
+    `model(data)` per iteration (IMS_PER_BATCH of them through collate_smnet + map_mp3d_batch_to_coco), under which iteration number
+    the losses / lr are filed, the lr of every iteration (optimizer.step before scheduler.step), which iterations save which
+    checkpoint under which name with which `iteration`, when `do_test` runs (TEST.EVAL_PERIOD), when the writers write, and where a
+    resumed run starts.  The DataLoader is the reference's own call with its worker processes switched off (num_workers 0)."""
+    from torch.utils.data import DataLoader
+    comm = sys.modules["detectron2.utils.comm"]
+    comm.reduce_dict = lambda d: d
+    comm.is_main_process = lambda: True
+    comm.synchronize = lambda: None
+    driver_mod.TrainingSampler = _TrainingSampler
+    driver_mod.build_lr_scheduler = _warmup_cosine_scheduler
+    driver_mod.build_custom_optimizer = lambda cfg, model: torch.optim.SGD(model.parameters(), lr=float(cfg.SOLVER.BASE_LR))
+    driver_mod.DetectionCheckpointer = _Checkpointer
+    driver_mod.PeriodicCheckpointer = _PeriodicCheckpointer
+    driver_mod.EventStorage = _EventStorage
+    driver_mod.CommonMetricPrinter = _Writer
+    driver_mod.JSONWriter = lambda *a, **k: types.SimpleNamespace(write=lambda: None)
+    driver_mod.TensorboardXWriter = lambda *a, **k: types.SimpleNamespace(write=lambda: None)
+    driver_mod.DataLoader = lambda ds, **k: DataLoader(ds, **{**k, "num_workers": 0, "pin_memory": False, "multiprocessing_context": None})
+    tests = []
+    driver_mod.do_test = lambda cfg, model: tests.append(len(_EventStorage.rows))
+    out = {"sampler_seed": _TrainingSampler.SEED}
+    cases = {
+        "plain": dict(max_iter=7, train_iter=-1, period=3, eval_period=0, ims=2, resume=False, found={}),
+        "period2_eval2": dict(max_iter=6, train_iter=-1, period=2, eval_period=2, ims=1, resume=False, found={}),
+        "train_iter_cap": dict(max_iter=9, train_iter=4, period=5, eval_period=0, ims=1, resume=False, found={}),
+        "resumed": dict(max_iter=7, train_iter=-1, period=3, eval_period=0, ims=2, resume=True, found={"iteration": 3}),
+        "weights_not_resumed": dict(max_iter=3, train_iter=-1, period=2, eval_period=0, ims=1, resume=False, found={"iteration": 3}),
+        "logged": dict(max_iter=27, train_iter=-1, period=100, eval_period=0, ims=1, resume=False, found={}),
+    }
+    for name, c in cases.items():
+        cfg = _ns({"SOLVER": {"USE_CUSTOM_SOLVER": True, "OPTIMIZER": "ADAMW", "MAX_ITER": c["max_iter"], "TRAIN_ITER": c["train_iter"],
+                              "CHECKPOINT_PERIOD": c["period"], "IMS_PER_BATCH": c["ims"], "BASE_LR": 0.01, "WARMUP_ITERS": 2,
+                              "WARMUP_FACTOR": 0.1, "WARMUP_METHOD": "linear", "CLIP_GRADIENTS": {"CLIP_TYPE": "value"},
+                              "BACKBONE_MULTIPLIER": 1.0},
+                   "OUTPUT_DIR": "/nonexistent", "WITH_IMAGE_LABELS": False, "INPUT": {"CUSTOM_AUG": ""},
+                   "DATALOADER": {"SAMPLER_TRAIN": "MP3DLoader"}, "FP16": False, "TEST": {"EVAL_PERIOD": c["eval_period"]},
+                   "MODEL": {"WEIGHTS": "", "MEMORY_TYPE": "implicit_memory", "SEMMAP_PATH": "", "TRAIN_DATA_PATH": root,
+                             "ROI_BOX_HEAD": {"ZEROSHOT_WEIGHT_PATH": ""}}})
+        found = {}
+        if c["found"]:
+            # the state a run of `it` iterations of this configuration leaves behind: optimizer and scheduler stepped `it` times
+            it = c["found"]["iteration"]
+            m0 = _StubTrainModel()
+            o0 = driver_mod.build_custom_optimizer(cfg, m0)
+            s0 = _warmup_cosine_scheduler(cfg, o0)
+            for _ in range(it):
+                o0.step()
+                s0.step()
+            found = {"iteration": it, "optimizer": o0.state_dict(), "scheduler": s0.state_dict()}
+        _Checkpointer.found, _Checkpointer.saves = found, []
+        _EventStorage.rows, _Writer.writes = [], []
+        del tests[:]
+        model = _StubTrainModel()
+        driver_mod.do_train(cfg, model, resume=c["resume"])
+        out[name] = {"cfg": {k: v for k, v in c.items() if k != "found"}, "found_iteration": c["found"].get("iteration"),
+                     "model_calls": model.calls, "rows": _EventStorage.rows, "saves": list(_Checkpointer.saves),
+                     "do_test_after_rows": list(tests), "writer_after_rows": list(_Writer.writes), "training": bool(model.training)}
+    return out
+
+
 def main():
     out = HERE
     loader_mod, driver_mod = load_reference_io_modules()
@@ -284,13 +482,17 @@ def main():
             res, ld = gen_loader(loader_mod, root, jpegs, out)
             gen_frame_dicts(driver_mod, loader_mod, ld, res)
             drv = gen_driver(driver_mod, loader_mod, root)
+            trn = gen_train_driver(driver_mod, loader_mod, root)
         finally:
             os.chdir(cwd)
     np.savez_compressed(os.path.join(out, "mp3d_loader.npz"), **res)
     with open(os.path.join(out, "mp3d_driver.json"), "w") as fh:
         json.dump(drv, fh, separators=(",", ":"), sort_keys=True)
         fh.write("\n")
-    for f in ("mp3d_loader.npz", "mp3d_driver.json"):
+    with open(os.path.join(out, "mp3d_train_driver.json"), "w") as fh:
+        json.dump(trn, fh, separators=(",", ":"), sort_keys=True)
+        fh.write("\n")
+    for f in ("mp3d_loader.npz", "mp3d_driver.json", "mp3d_train_driver.json"):
         print(f, os.path.getsize(os.path.join(out, f)) // 1024, "KiB")
 
 

@@ -226,7 +226,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     model = build_model(cfg, sd0)
     trainer = Trainer(model, sd0)
     fm = trainer.fm
-    assert fm.clamped and (fm.pre, fm.post) == (1638, 448)                # the yaml's 4000 / 2000 exceed the selection kernels
+    assert (fm.pre, fm.post, fm.nms_train) == (4000, 2000, 0.9)           # Base-C2_L_R5021k_640b64_4x_recurrent.yaml:45-49
     H, W, n_cells = 128, 160, 500
     g = torch.Generator().manual_seed(105)
     img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
@@ -239,7 +239,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     # the train-mode proposals of this frame (decoded from the head's outputs), then the checked pass on them with fixed keys
     fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, generator=torch.Generator(device=dev).manual_seed(1))
     props = fm.last_proposals.cpu()
-    assert 16 <= props.shape[0] <= 448 and bool((props[:, 2] >= props[:, 0]).all())
+    assert 16 <= props.shape[0] <= 2000 and bool((props[:, 2] >= props[:, 0]).all())
     keys = torch.rand((props.shape[0] + gt.shape[0],), generator=g)
     losses, grads = fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, proposals=props.to(dev), keys=keys.to(dev))
     torch.cuda.synchronize()
@@ -303,6 +303,90 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     print("trainer, both halves: total loss %.4f -> %.4f after 8 steps at lr %.0e; %d proposals" % (first, last, lr, props.shape[0]))
 
 
+def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(synthetic_sd):
+    """`forward_model` at 640x640 on the reference's training configuration, each side on its OWN data-dependent choices: the oracle
+    decodes its own train-mode proposals from its own head outputs (PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS 0.9:
+    centernet.py:214-219,603-745) and draws its own 512-row sample from the shared random keys (detic_roi_heads.py:232); nothing is
+    handed from one side to the other but the image, the memory, the ground truth and the keys.  Asserted: the proposal list (count,
+    order, boxes to 1e-3 px), the sampled rows and their classes bit-exact, the ten losses to 3e-4 relative, probe gradients in L2."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "SOLVER.BASE_LR", 2e-5])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    fm = trainer.fm
+    H, W, n_cells = 640, 640, 4000
+    g = torch.Generator().manual_seed(211)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 2).half()
+    proj = torch.randint(0, n_cells, (H // 16, W // 16), generator=g).repeat_interleave(16, 0).repeat_interleave(16, 1).contiguous()
+    xy = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.8, H * 0.8])
+    wh = torch.exp(torch.rand((24, 2), generator=g) * 3.0 + 2.5)               # 12 .. 245 px
+    gt = torch.cat([xy, torch.minimum(xy + wh, torch.tensor([W - 1.0, H - 1.0]))], dim=1).contiguous()
+    gc = torch.randint(0, 20, (24,), generator=g)
+    keys = torch.rand((2048 + 64 + gt.shape[0],), generator=g)                # one per row of proposals + ground truth; R is data dependent
+    mem = (mem16.to(dev), proj.int().to(dev))
+    losses, grads = fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, keys=keys.to(dev))
+    torch.cuda.synchronize()
+    props = fm.last_proposals.cpu()
+    # ---- the oracle, on its own
+    ocfg = M.OracleCfg(map_feature_weight=5.0)
+    tcfg = M.OracleCfg(map_feature_weight=5.0, pre_nms_topk=4000, post_nms_topk=2000, nms_th_proposal=0.9)
+    trainable = lambda k, v: v.is_floating_point() and "running_" not in k and ".bn" not in k and ".downsample.1." not in k and \
+        "zs_weight" not in k and (k.startswith("backbone.") or "centernet_head" in k or "box_head" in k or "box_predictor" in k)
+    sd = {k: (v.clone().float().requires_grad_() if trainable(k, v) else v) for k, v in synthetic_sd.items()}
+    feats = M.backbone_forward(M.preprocess_image(img, ocfg), sd, ocfg, mem16, proj)
+    agn, reg = M.centernet_head(feats, sd)
+    with torch.no_grad():
+        oprops, oscores = M.centernet_proposals([a.detach() for a in agn], [r.detach() for r in reg], tcfg)
+    assert props.shape == oprops.shape and props.shape[0] >= 2000, (props.shape, oprops.shape)
+    assert float((props - oprops).abs().max()) <= 1e-3, float((props - oprops).abs().max())
+    shapes = [(f.shape[2], f.shape[3]) for f in feats]
+    pos, reg_t, heat = OL.centernet_targets(gt, shapes)
+    ref = OL.centernet_proposal_losses(torch.cat([a.permute(0, 2, 3, 1).reshape(-1) for a in agn]),
+                                       torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg]), heat, reg_t, pos)
+    rdet, rstages = OL.cascade_training_losses(feats[:3], oprops, gt, gc, sd, ocfg, (H, W), keys)
+    ref.update(rdet)
+    sum(ref.values()).backward()
+    # the sample: 512 rows of ~2000 + 24, a quarter foreground at most -- really sub-sampled, unlike a 448-row list
+    rows = fm.det.last_rows.cpu()
+    assert rows.shape[0] == 512 and torch.equal(rows, rstages[0]["rows"])
+    n_fg = int((rstages[0]["classes"] != 20).sum())
+    assert 24 <= n_fg <= 128, n_fg
+    for k in range(3):
+        assert fm.det.last[k]["boxes"].shape[0] == rstages[k]["boxes"].shape[0]
+        assert torch.equal(fm.det.last[k]["classes"].cpu().long(), rstages[k]["classes"]), k
+    assert set(losses) == set(ref) and len(ref) == 10
+    for name, v in ref.items():
+        assert abs(float(losses[name]) - float(v.detach())) <= 3e-4 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))
+    packed = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    base = "backbone.bottom_up.base"
+    h = "proposal_generator.centernet_head"
+    probe = [f"{base}.conv1.weight", f"{base}.layer3.2.conv2.weight", "backbone.fpn_lateral4.weight", "backbone.fpn_output3.weight",
+             "backbone.map_merge_projection2.weight", "backbone.top_block.p7.weight", f"{h}.bbox_tower.3.weight",
+             "roi_heads.box_head.0.fc1.weight", "roi_heads.box_head.2.fc2.weight", "roi_heads.box_predictor.1.cls_score.linear.weight",
+             "roi_heads.box_predictor.2.bbox_pred.0.weight"]
+    worst = 0.0
+    for name in probe:
+        mine = trainer.getters[name](grads).cpu()
+        want = sd[name].grad
+        if name == f"{base}.conv1.weight":
+            want = F.pad(want.permute(0, 2, 3, 1), (0, 1)).reshape(64, -1)
+        elif name.endswith("fc1.weight"):
+            want = want.view(-1, 256, 7, 7).permute(0, 2, 3, 1).reshape(want.shape[0], -1)
+        elif want.dim() == 4 and "map_merge" not in name:
+            want = packed(want)
+        want = want.reshape(mine.shape)
+        l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
+        worst = max(worst, l2)
+        assert l2 <= 5e-3, (name, l2)
+    print("640x640 training parity: %d proposals, %d sampled rows (%d foreground), worst probe gradient L2 %.2e" %
+          (props.shape[0], rows.shape[0], n_fg, worst))
+
+
 def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
     """`model.train(); losses = model(data); trainer.optimizer_step()` -- the reference's training iteration (train_mp3d.py:609-625
     around custom_rcnn.py:435-461): every frame's memory is normalised from the loader's accumulated features and observation counts
@@ -319,6 +403,11 @@ def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
     model.train()
     with pytest.raises(RuntimeError):
         model([[]])                                                        # no trainer attached yet
+    # the shipped yaml says FP16: True (autocast backbone + GradScaler in the reference): refused, never silently fp32
+    model.cfg.FP16 = True
+    with pytest.raises(NotImplementedError, match="FP16"):
+        Trainer(model, sd0)
+    model.cfg.FP16 = False
     trainer = Trainer(model, sd0)
     # checkpoint OUT, before any step: the kernels' layouts go back to the reference's tensors exactly
     exported = trainer.state_dict(synthetic_sd)

@@ -552,7 +552,8 @@ def test_checkpoint_out_inverts_the_kernel_layouts(tmp_path):
 def test_do_train_loop_with_a_stub_step(tmp_path):
     """`engine/train_loop.py` (train_mp3d.py:509-659, host side) around a stub device step: TrainingSampler's seeded infinite shuffles,
     IMS_PER_BATCH episodes per iteration, the loss dict summed and asserted finite, WarmupCosineLR's factor handed to the optimizer
-    step, PeriodicCheckpointer's rhythm (every CHECKPOINT_PERIOD iterations + model_final), train() / eval() around the loop."""
+    step, PeriodicCheckpointer's rhythm as the reference's loop drives it, the resume rule (`tests/test_io_golden.py` holds the same
+    loop to the reference's own `do_train`)."""
     import math
     import pytest
     import torch
@@ -601,24 +602,37 @@ def test_do_train_loop_with_a_stub_step(tmp_path):
             return {"w": base["w"] + self.iteration}
 
     model, tr = Model(), StubTrainer()
-    seen = []
+    seen, tests = [], []
     rows = train_loop.do_train(cfg, model, tr, train_loop.training_batches(episodes, 2, seed=3), output_dir=str(tmp_path), base_state_dict=sd,
-                               map_batch=lambda d: [("mapped", ep) for ep in d], log=seen.append, log_period=3)
-    assert len(rows) == 7 and model.mode == "eval" and all(d[0][0] == "mapped" and len(d) == 2 for d in model.calls)
-    assert [r["iteration"] for r in rows] == list(range(1, 8)) and [r["iteration"] for r in seen] == [3, 6, 7]
+                               map_batch=lambda d: [("mapped", ep) for ep in d], log=seen.append, do_test=lambda: tests.append(1))
+    assert len(rows) == 7 and model.mode == "train" and all(d[0][0] == "mapped" and len(d) == 2 for d in model.calls)
+    assert [r["iteration"] for r in rows] == list(range(1, 8)) and [r["iteration"] for r in seen] == [7] and not tests
     for i, r in enumerate(rows):
         f = solver.warmup_cosine_lr_factor(i, 7, 2, 0.1, "linear")
         assert tr.factors[i] == f and r["lr"] == 0.01 * f and abs(r["total_loss"] - 3.0 / (i + 1)) < 1e-6
     assert tr.factors[0] == 0.1 and abs(tr.factors[2] - 0.5 * (1 + math.cos(math.pi * 2 / 7))) < 1e-12
+    # inside the warmup the factor is a line from warmup_factor to the cosine's value where the warmup ends (WarmupParamScheduler)
+    assert abs(tr.factors[1] - (0.5 * 0.1 + 0.5 * 0.5 * (1 + math.cos(math.pi * 2 / 7)))) < 1e-12
     files = sorted(p.name for p in tmp_path.iterdir())
-    assert files == ["model_0000002.pth", "model_0000005.pth", "model_final.pth"]            # PeriodicCheckpointer's names: the 0-based iteration
+    # PeriodicCheckpointer.step sees the loop's 1-based iteration (train_mp3d.py:605,654): (i + 1) % 3 == 0 -> i = 2, 5; the tag file
+    assert files == ["last_checkpoint", "model_0000002.pth", "model_0000005.pth", "model_final.pth"]
+    two = torch.load(str(tmp_path / "model_0000002.pth"), weights_only=False)
+    assert two["iteration"] == 2 and torch.equal(two["model"]["w"], torch.full((3,), 2.0)) and two["scheduler"] == {"last_epoch": 2}
     final = torch.load(str(tmp_path / "model_final.pth"), weights_only=False)
     assert final["iteration"] == 7 and torch.equal(final["model"]["w"], torch.full((3,), 7.0))
-    # resume: start_iter continues the schedule; SOLVER.TRAIN_ITER caps the run (train_mp3d.py:529)
-    rows2 = train_loop.do_train(cfg, model, tr, train_loop.training_batches(episodes, 1), start_iter=5)
-    assert [r["iteration"] for r in rows2] == [6, 7]
+    assert checkpoint.last_checkpoint(str(tmp_path)) == str(tmp_path / "model_final.pth")
+    # resume (train_mp3d.py:524-525 + :605): from the checkpoint of 2 finished iterations the loop continues at the number 4
+    st = checkpoint.load_training_state(str(tmp_path / "model_0000002.pth"))
+    assert st["iteration"] == 2 and st["scheduler"] == {"last_epoch": 2} and st["optimizer"] is None
+    tr2 = StubTrainer()
+    rows2 = train_loop.do_train(cfg, model, tr2, train_loop.training_batches(episodes, 1), resume_state=st)
+    assert [r["iteration"] for r in rows2] == [4, 5, 6, 7]
+    assert tr2.factors == [solver.warmup_cosine_lr_factor(i, 7, 2, 0.1, "linear") for i in (2, 3, 4, 5)]
+    # SOLVER.TRAIN_ITER caps the loop (:529) but not the schedule (:519)
     cfg.SOLVER.TRAIN_ITER = 2
-    assert len(train_loop.do_train(cfg, model, tr, train_loop.training_batches(episodes, 1))) == 2
+    tr3 = StubTrainer()
+    assert len(train_loop.do_train(cfg, model, tr3, train_loop.training_batches(episodes, 1))) == 2
+    assert tr3.factors[1] == solver.warmup_cosine_lr_factor(1, 7, 2, 0.1, "linear")
 
     class Diverged(Model):
         def __call__(self, data):

@@ -181,3 +181,71 @@ def test_eval_driver_matches_the_reference_driver(fx, root, test_type):
     d2, g2, q2 = records_by_image(np.stack(merged))
     assert sorted(set(d2) | set(g2)) == uids and q2 == quart
     assert all(np.array_equal(g2[u]["boxes"], gts[u]["boxes"]) for u in gts)
+
+
+def test_do_train_matches_the_reference_loop(golden_dir, root):
+    """`engine/train_loop.do_train` against the reference's OWN `do_train` (train_mp3d.py:509-659, run with a stub model / optimizer /
+    checkpointer on this dataset by `gen_golden_io.py::gen_train_driver`): per iteration the episodes that reach `model(data)`
+    (IMS_PER_BATCH of them, through collate_smnet + map_mp3d_batch_to_coco, in TrainingSampler's seeded order), the number the
+    iteration is filed under, its learning rate; which saves happen under which name with which stored iteration and scheduler
+    position; the periodic `do_test`; the writers' rhythm; a resumed run; SOLVER.TRAIN_ITER; MODEL.WEIGHTS with an iteration entry."""
+    from embodied_object_detection_amd import setup_cfg
+    from embodied_object_detection_amd.data.mp3d import SMNetDetectionLoader, collate_smnet, map_mp3d_batch_to_coco
+    from embodied_object_detection_amd.engine import train_loop
+    with open(os.path.join(golden_dir, "mp3d_train_driver.json")) as fh:
+        ref = json.load(fh)
+    loader = SMNetDetectionLoader(data_path=root, memory_type="implicit_memory", semmap_path="")
+
+    class Model:
+        def __init__(self):
+            self.calls, self.training = [], False
+
+        def train(self, mode=True):
+            self.training = mode
+
+        def eval(self):
+            self.training = False
+
+        def __call__(self, data):
+            assert self.training
+            self.calls.append([[ep[0]["sequence_name"], len(ep), [bool(f["memory_reset"]) for f in ep], type(ep[0]["instances"]).__name__]
+                               for ep in data])
+            n = len(self.calls)
+            return {"loss_a": torch.tensor(2.0 / n), "loss_b": torch.tensor(1.0 / n)}
+
+    class StubTrainer:
+        def __init__(self):
+            self.factors = []
+
+        def optimizer_step(self, lr_factor=1.0):
+            self.factors.append(lr_factor)
+
+    for name, want in ref.items():
+        if name == "sampler_seed":
+            continue
+        c = want["cfg"]
+        cfg = setup_cfg(None, ["SOLVER.MAX_ITER", c["max_iter"], "SOLVER.TRAIN_ITER", c["train_iter"], "SOLVER.CHECKPOINT_PERIOD", c["period"],
+                               "SOLVER.IMS_PER_BATCH", c["ims"], "SOLVER.BASE_LR", 0.01, "SOLVER.WARMUP_ITERS", 2, "SOLVER.WARMUP_FACTOR", 0.1,
+                               "SOLVER.WARMUP_METHOD", "linear", "SOLVER.LR_SCHEDULER_NAME", "WarmupCosineLR", "TEST.EVAL_PERIOD", c["eval_period"]])
+        model, tr = Model(), StubTrainer()
+        saves, tests, logged = [], [], []
+        sched = {"n": 0}
+        resume_state = None
+        if c["resume"] and want["found_iteration"] is not None:
+            # what a run of `found_iteration` iterations leaves in its last checkpoint
+            resume_state = {"iteration": want["found_iteration"], "optimizer": None, "scheduler": {"last_epoch": want["found_iteration"]}}
+        rows = train_loop.do_train(cfg, model, tr, train_loop.training_batches(loader, c["ims"], seed=ref["sampler_seed"], collate=collate_smnet),
+                                   resume_state=resume_state, map_batch=map_mp3d_batch_to_coco,
+                                   on_save=lambda n, it: saves.append([n, it, (resume_state["scheduler"]["last_epoch"] if resume_state else 0) + len(tr.factors)]),
+                                   do_test=lambda: tests.append(len(tr.factors)), log=lambda r: logged.append(len(tr.factors)))
+        got_calls = [[[e[0], e[1], e[2]] for e in it] for it in model.calls]
+        assert got_calls == [[[e[0], e[1], e[2]] for e in it] for it in want["model_calls"]], name
+        assert all(e[3] == "Instances" for it in model.calls for e in it)
+        assert [r["iteration"] for r in rows] == [r["storage_iter"] for r in want["rows"]], name
+        for r, w in zip(rows, want["rows"]):
+            assert abs(r["lr"] - w["lr"]) <= 1e-12 * max(abs(w["lr"]), 1e-12), (name, r["iteration"], r["lr"], w["lr"])
+        assert [[n, it, ep] for n, it, ep in saves] == [[s[0], s[1]["iteration"], s[3]] for s in want["saves"]], (name, saves, want["saves"])
+        assert all(s[2] == ["optimizer", "scheduler"] for s in want["saves"])
+        assert tests == want["do_test_after_rows"], name
+        assert logged == want["writer_after_rows"], name
+        assert model.training == want["training"], name

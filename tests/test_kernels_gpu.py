@@ -1,5 +1,6 @@
 """Kernel-level parity: every HIP entry point (through the C ABI) against the CPU oracle on seeded inputs."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -506,6 +507,57 @@ def test_centernet_proposals_match_oracle(dev, level_hw, topk, post):
     assert n == rb.shape[0]
     close(s[:n], rs, rtol=1e-6, atol=1e-6)
     close(b[:n], rb, rtol=1e-5, atol=1e-4)
+
+
+def _pyramid_hw(H, W):
+    return [((H + s - 1) // s, (W + s - 1) // s) for s in M.FPN_STRIDES]
+
+
+@pytest.mark.parametrize("hw,nms,variant", [((640, 640), 0.9, "plain"), ((640, 640), 0.5, "plain"), ((640, 640), 0.9, "ties"),
+                                            ((960, 960), 0.9, "plain"), ((512, 640), 0.9, "golden")])
+def test_centernet_train_proposals_match_oracle(dev, hw, nms, variant, golden_dir):
+    """The TRAINING proposal lists (PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS_TH_TRAIN 0.9; centernet.py:214-219 ->
+    predict_instances / nms_and_topK with `self.training`): the wide path of `eod_centernet_proposals` (rank merge, suppression bit
+    matrix, scanning workgroup) against the oracle's decode of the same head outputs -- same proposals in the same order.  NMS 0.5
+    makes the suppression matter (a third of the candidates goes), `ties` quantises the logits (long runs of equal scores: the
+    rank merge's run walk and the '>= kth' rule), 960x960 has 14 400 positions on the finest level and 8 789 merged candidates;
+    `golden` is the case the reference's own `CenterNet` decoded in training mode (tests/golden/centernet_decode_train.npz)."""
+    from embodied_object_detection_amd import ops
+    pre, post = 4000, 2000
+    if variant == "golden":
+        import _inputs as I
+        agn, reg = I.centernet_decode_train_case()
+        level_hw = [tuple(a.shape[2:]) for a in agn]
+        scales = [1.0] * 5
+        gd = np.load(os.path.join(golden_dir, "centernet_decode_train.npz"))
+        pre, post = int(gd["pre_post"][0]), int(gd["pre_post"][1])
+    else:
+        level_hw = _pyramid_hw(*hw)
+        agn, reg = _head_case(level_hw, seed=17)
+        scales = [0.9, 1.0, 1.1, 1.2, 0.8]
+        if variant == "ties":
+            agn = [torch.round(a * 4.0) / 4.0 for a in agn]
+            reg = [r * 0.1 for r in reg]
+    cfg = M.OracleCfg(pre_nms_topk=pre, post_nms_topk=post, nms_th_proposal=nms)
+    rb, rs = M.centernet_proposals(agn, [F.relu(r * s) for r, s in zip(reg, scales)], cfg)
+    if variant == "golden":
+        np.testing.assert_array_equal(rs.numpy(), gd["scores"])
+        np.testing.assert_array_equal(rb.numpy(), gd["boxes"])
+    head = torch.cat([torch.cat([nhwc(a).reshape(-1, 1), nhwc(r).reshape(-1, 4)], dim=1) for a, r in zip(agn, reg)]).contiguous()
+    cap = 4096 if variant == "ties" else post + 48
+    dec = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, scales, cfg.inference_th, pre, post, nms, cap=cap, device=dev)
+    b, s, c = dec(head.to(dev))
+    n = int(c.item())
+    assert n == rb.shape[0], (n, rb.shape[0])
+    assert n >= post and (variant != "ties" or n > post)
+    if variant == "ties":
+        # the order among EQUAL scores: position order in both, so the lists still agree entry by entry
+        assert n > post + 48
+    close(s[:n], rs, rtol=1e-6, atol=1e-6)
+    close(b[:n], rb, rtol=1e-5, atol=1e-4)
+    # a second call on the same decoder (workspace reuse) gives the same list
+    b2, s2, c2 = dec(head.to(dev))
+    assert int(c2.item()) == n and torch.equal(b2[:n], b[:n])
 
 
 def test_centernet_proposals_keep_ties(dev):

@@ -164,6 +164,23 @@ def test_centernet_decode_topk_nms_kth(golden_dir):
     np.testing.assert_array_equal(g["plain_level_counts"], [1000, 308, 76, 19, 5])
 
 
+def test_centernet_decode_with_the_training_thresholds(golden_dir):
+    """The proposals `CenterNet.forward` hands to the ROI heads in TRAINING (centernet.py:214-219 -> predict_instances /
+    nms_and_topK with `self.training`: PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS_TH_TRAIN 0.9): the reference's own decode of a
+    512x640 head output (5 120 positions on the finest level, 5 678 merged candidates) against the oracle's, bit for bit."""
+    g = _load(golden_dir, "centernet_decode_train.npz")
+    agn, reg = I.centernet_decode_train_case()
+    cfg = M.OracleCfg(pre_nms_topk=4000, post_nms_topk=2000, nms_th_proposal=0.9)
+    boxes, scores = M.centernet_proposals(agn, reg, cfg)
+    np.testing.assert_array_equal(g["level_counts"], [4000, 1264, 316, 79, 19])
+    np.testing.assert_array_equal(scores.numpy(), g["scores"])
+    np.testing.assert_array_equal(boxes.numpy(), g["boxes"])
+    assert boxes.shape[0] == 2000
+    # the suppression matters on this case: without NMS the best 2000 are a different list
+    free = M.centernet_proposals(agn, reg, M.OracleCfg(pre_nms_topk=4000, post_nms_topk=2000, nms_th_proposal=1.0))[1]
+    assert not np.array_equal(free.numpy(), g["scores"])
+
+
 def test_cascade_box_heads_score_merge(golden_dir):
     """a12 against `DeticCascadeROIHeads._forward_box/_run_stage/_create_proposals_from_boxes` (detic_roi_heads.py:88-222,306-349)
     and `DeticFastRCNNOutputLayers.forward/predict_probs` (detic_fast_rcnn.py:437-466,325-339)."""

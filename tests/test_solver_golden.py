@@ -49,13 +49,19 @@ def test_unknown_optimizer_is_refused():
 
 
 def test_warmup_cosine_schedule():
-    """detectron2 WarmupCosineLR with the recurrent yaml's numbers (MAX_ITER 10000, WARMUP_ITERS 1000, WARMUP_FACTOR 0.001)."""
+    """detectron2's `build_lr_scheduler` for WarmupCosineLR (LRMultiplier over WarmupParamScheduler(CosineParamScheduler(1, 0), ...))
+    with the recurrent yaml's numbers (MAX_ITER 10000, WARMUP_ITERS 1000, WARMUP_FACTOR 0.001): inside the warmup a LINE from
+    warmup_factor to the cosine's value at the warmup's end (not the older class's product of the two)."""
     from embodied_object_detection_amd.solver import warmup_cosine_lr_factor as f
+    cos = lambda w: 0.5 * (1 + math.cos(math.pi * w))
     assert f(0, 10000, 1000, 0.001) == pytest.approx(0.001)
-    assert f(500, 10000, 1000, 0.001) == pytest.approx((0.001 * 0.5 + 0.5) * 0.5 * (1 + math.cos(math.pi * 0.05)))
-    assert f(1000, 10000, 1000, 0.001) == pytest.approx(0.5 * (1 + math.cos(math.pi * 0.1)))
+    assert f(500, 10000, 1000, 0.001) == pytest.approx(0.5 * 0.001 + 0.5 * cos(0.1))
+    assert f(1000, 10000, 1000, 0.001) == pytest.approx(cos(0.1))
+    assert f(6000, 10000, 1000, 0.001) == pytest.approx(cos(0.6))
     assert f(10000, 10000, 1000, 0.001) == pytest.approx(0.0, abs=1e-12)
-    assert f(3, 10, 5, 0.2, "constant") == pytest.approx(0.2 * 0.5 * (1 + math.cos(math.pi * 0.3)))
+    assert f(3, 10, 5, 0.2, "constant") == pytest.approx(0.2)
+    assert f(7, 10, 5, 0.2, "constant") == pytest.approx(cos(0.7))
+    assert f(3, 4, 100, 0.5) == pytest.approx(0.5 * 0.25 + cos(1.0) * 0.75)        # warmup longer than the run: clipped at where = 1
 
 
 @pytest.mark.gpu

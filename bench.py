@@ -43,9 +43,11 @@ def parse():
     ap.add_argument("--cell", type=float, default=0.2)
     ap.add_argument("--memory-thresh", type=float, default=0.3, help="MODEL.MEMORY_CLS_SCORE_THRESH (0.0 = worst-case write path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="stop the CPU baseline after this many seconds of frames")
-    ap.add_argument("--cpu-frames", type=int, default=20, help="timed CPU frames (SURVEY 8d: >= 20; the budget usually stops earlier)")
-    ap.add_argument("--cpu-warmup", type=int, default=1, help="untimed CPU warm-up frames (SURVEY 8d: 5)")
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="stop the CPU baseline after this many seconds of frames")
+    ap.add_argument("--cpu-frames", type=int, default=20, help="timed CPU frames (SURVEY 8d: >= 20)")
+    ap.add_argument("--cpu-warmup", type=int, default=5, help="untimed CPU warm-up frames (SURVEY 8d: 5)")
+    ap.add_argument("--no-config5", action="store_true", help="skip variants.config5_960_batch4 (BASELINE configs[4] at full size)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip variants.train_step_640 (one training iteration of forward_model)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--no-variants", dest="variants", action="store_false", help="skip the extra (non-headline) variant timings")
     ap.add_argument("--concurrent-scenes", type=int, default=0, help="with --batch: scenes in flight at once (0 = BatchedSequences decides)")
@@ -324,7 +326,7 @@ def cpu_baseline(sd, frames, args, budget_s):
             "sample": f"{n} consecutive timed frame(s) of the same synthetic recurrent sequence after {n_warm} warm-up frame(s), "
                       f"median {med * 1e3:.0f} ms/frame (min {min(times) * 1e3:.0f}, max {max(times) * 1e3:.0f}); oracle/ torch fp32; "
                       f"stopped by {'the frame count' if n >= args.cpu_frames else f'the {budget_s:.0f} s budget'} "
-                      f"(SURVEY 8d asks for 5 + >= 20 frames: --cpu-warmup 5 --cpu-frames 20 --cpu-budget-s 600)",
+                      f"(SURVEY 8d's protocol: 5 warm-up + >= 20 timed frames)",
             "median_ms_per_frame": round(med * 1e3, 1), "timed_frames": n, "warmup_frames": n_warm,
             "per_stage_s_per_frame": stages, "cpu_model": model_name,
             "cores_note": f"{torch.get_num_threads()} threads = this job's CPU share (affinity / cgroup quota, capped at 32) of the "
@@ -350,32 +352,30 @@ def relaunch_under_torchrun(args) -> int:
     return subprocess.call(cmd)
 
 
-def bench_batched(args):
-    """configs[4]: B sequences per GPU, the memory-independent trunk batched (N = B), one JSON line (single rank)."""
+def run_batched(H, W, map_w, map_h, cell, B, warmup, steps, lockstep="launches", memory_thresh=0.3, concurrent_scenes=0, sd=None) -> dict:
+    """configs[4]: B sequences per GPU in lock-step, a step = B frames through the boundary -> the line's fields (single rank)."""
     from embodied_object_detection_amd import setup_cfg
     from embodied_object_detection_amd.checkpoint import synthetic_state_dict
     from embodied_object_detection_amd.data.synthetic import SyntheticSequence
     from embodied_object_detection_amd.modeling.batched import BatchedSequences
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    H, W = args.size
-    map_w, map_h = args.grid
-    B = args.batch
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "MODEL.MEMORY_CLS_SCORE_THRESH", args.memory_thresh, "MODEL.DEVICE", "cuda:0"])
-    if args.lockstep == "launches":
+                           "MODEL.MEMORY_CLS_SCORE_THRESH", memory_thresh, "MODEL.DEVICE", "cuda:0"])
+    sd = sd if sd is not None else synthetic_state_dict(0)
+    if lockstep == "launches":
         from embodied_object_detection_amd.modeling.lockstep import LockstepScenes
-        model = LockstepScenes(cfg, B, synthetic_state_dict(0))
+        model = LockstepScenes(cfg, B, sd)
         how = (f"N = {B} through every stage of the frame: one launch per stage for all scenes (trunk, memory read, tower, proposal "
                f"decoding, cascade, selections, both mask passes over the concatenated ROI lists, memory write of the {B} states, paste)")
     else:
-        model = BatchedSequences(cfg, B, synthetic_state_dict(0), concurrent_scenes=args.concurrent_scenes)
+        model = BatchedSequences(cfg, B, sd, concurrent_scenes=concurrent_scenes)
         how = (f"the memory-independent trunk + FPN top-down run once per step with N = {B}, the scenes continue on their own streams "
                f"({len(set(id(s_) for s_ in model.streams))} in flight)")
-    n = args.warmup + args.steps
+    n = warmup + steps
     eps = []
     for b in range(B):
-        seq = SyntheticSequence(100 + b, H=H, W=W, n_frames=n, map_w=map_w, map_h=map_h, cell=args.cell)
+        seq = SyntheticSequence(100 + b, H=H, W=W, n_frames=n, map_w=map_w, map_h=map_h, cell=cell)
         fr = []
         for i in range(n):
             f = seq.frame(i)
@@ -384,21 +384,123 @@ def bench_batched(args):
             fr.append(f)
         eps.append(fr)
     torch.cuda.synchronize()
-    log(f"{B} x {n} frames resident")
-    model([e[:args.warmup] for e in eps])
+    log(f"{B} x {n} frames of {H}x{W} resident")
+    model([e[:warmup] for e in eps])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = model([e[args.warmup:] for e in eps])
+    outs = model([e[warmup:] for e in eps])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     nd = float(np.mean([len(o["instances"]) for ob in outs for o in ob]))
-    print(json.dumps({
-        "metric": f"frames/sec ({H}x{W}, implicit_memory, {B} sequences batched per GPU)", "value": round(args.steps * B / el, 3),
-        "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+    del model, eps, outs
+    torch.cuda.empty_cache()
+    return {
+        "metric": f"frames/sec ({H}x{W}, implicit_memory, {B} sequences batched per GPU)", "value": round(steps * B / el, 3),
+        "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[4]: {B} independent sequences in lock-step per GPU, {H}x{W}, memory grid "
-                               f"{map_w}x{map_h} @ {args.cell} m; a step = {B} frames through the boundary (Instances materialised); "
-                               + how, "batch": B, "lockstep": args.lockstep, "detections_per_frame_mean": round(nd, 1)}}), flush=True)
+                               f"{map_w}x{map_h} @ {cell} m; a step = {B} frames through the boundary (Instances materialised); "
+                               + how, "batch": B, "lockstep": lockstep, "detections_per_frame_mean": round(nd, 1)}}
+
+
+def bench_batched(args):
+    H, W = args.size
+    map_w, map_h = args.grid
+    print(json.dumps(run_batched(H, W, map_w, map_h, args.cell, args.batch, args.warmup, args.steps, args.lockstep, args.memory_thresh,
+                                 args.concurrent_scenes)), flush=True)
+
+
+def config5_variant(sd, memory_thresh: float) -> dict:
+    """BASELINE.json configs[4] at full size inside the default run: 4 sequences in lock-step at 960x960 with a 512x512 memory grid
+    (N = 262 144 cells), and the HBM-bound class (memory read + fusion) measured on a single 960x960 scene, where
+    the full-map byte count is 581 MB and the class is no longer launch-sized."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.data.synthetic import SyntheticSequence
+    H = W = 960
+    map_w = map_h = 512
+    cell = 0.08
+    line = run_batched(H, W, map_w, map_h, cell, 4, warmup=4, steps=12, sd=sd, memory_thresh=memory_thresh)
+    out = {"value": line["value"], "unit": "frames/s", "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"],
+           "batch": 4, "detections_per_frame_mean": line["config"]["detections_per_frame_mean"],
+           "note": "BASELINE.json configs[4]: LockstepScenes(cfg, 4) at 960x960, memory grid 512x512 @ 0.08 m; a step = 4 frames through "
+                   "the boundary (Instances materialised), N = 4 through every stage; `python bench.py --size 960 960 --grid 512 512 "
+                   "--cell 0.08 --batch 4` is the same measurement as its own line"}
+    try:
+        dev = torch.device("cuda:0")
+        cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                               "MODEL.MEMORY_CLS_SCORE_THRESH", memory_thresh, "MODEL.DEVICE", "cuda:0"])
+        model = build_model(cfg, sd)
+        seq = SyntheticSequence(7, H=H, W=W, n_frames=10, map_w=map_w, map_h=map_h, cell=cell)
+        frames = []
+        for i in range(10):
+            f = seq.frame(i)
+            f["image"] = f["image"].to(dev)
+            f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
+            frames.append(f)
+        model([frames[:6]])
+        t0 = time.perf_counter()
+        model([frames[:6]])
+        torch.cuda.synchronize()
+        out["single_sequence_frames_per_s"] = round(6 / (time.perf_counter() - t0), 2)
+        probe = hbm_class_probe(model, frames, 7, H, W, seq.n_cells, reps=15, gather_frames=[6, 8])
+        out["roofline_hbm"] = {k: probe[k] for k in ("bound", "class", "kernels", "achieved", "peak", "unit", "frac", "algorithmic_bytes",
+                                                     "avg_us_total", "by_definition", "dirty_rows_this_frame", "memory_cells",
+                                                     "memory_write_a16_a19")}
+        del model, frames
+        torch.cuda.empty_cache()
+    except Exception as e:      # diagnostics only
+        log(f"config5 hbm probe failed: {e!r}")
+    return out
+
+
+def train_step_variant(sd) -> dict:
+    """One training iteration of `forward_model` (custom_rcnn.py:584-679 + the optimizer step, train_mp3d.py:609-633) at 640x640:
+    `Trainer.step` on one frame with 24 ground-truth boxes -- both halves forward and backward, train-mode proposals at the yaml's
+    4000 / 2000, 512 sampled ROI rows per cascade stage, AdamW over all 126 parameter tensors.  FLOPs: 2 x MAC of every conv / linear
+    layer forward, twice that again for the backward (input gradient + weight gradient)."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    H = W = 640
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "MODEL.DEVICE", "cuda:0", "FP16", False])
+    sd = {k: v.clone() for k, v in sd.items()}
+    model = build_model(cfg, sd)
+    trainer = Trainer(model, sd)
+    g = torch.Generator().manual_seed(0)
+    n_cells = 200 * 200
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
+    mem16 = (torch.randn((n_cells, 512), generator=g) * 2).half().to(dev)
+    proj = torch.randint(0, n_cells, (H, W), generator=g).int().to(dev)
+    xy = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.6, H * 0.6])
+    wh = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.35, H * 0.35]) + 8
+    gt = torch.cat([xy, xy + wh], dim=1).to(dev)
+    kw = dict(gt_classes=torch.randint(0, 20, (24,), generator=g).int().to(dev), generator=torch.Generator(device=dev).manual_seed(0))
+    warm, steps = 3, 8
+    first = None
+    for _ in range(warm):
+        out = trainer.step(img, gt, memory=(mem16, proj), **kw)
+        first = first if first is not None else sum(float(v) for v in out.values())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = trainer.step(img, gt, memory=(mem16, proj), **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    last = sum(float(v) for v in out.values())
+    rows = [int(r["boxes"].shape[0]) for r in trainer.fm.det.last]
+    fr = frame_roofline(H, W, float(np.mean(rows)), 0.0, 1.0, "fp32", n_mask_rois=0.0)["by_stage_gflop"]
+    fwd = sum(fr.values())
+    res = {"value": round(1.0 / dt, 3), "unit": "training iterations/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warm,
+           "dtype": "f32", "proposals": int(trainer.fm.last_proposals.shape[0]), "proposal_list_sizes": [trainer.fm.pre, trainer.fm.post],
+           "roi_rows_per_stage": rows, "gt_boxes": 24, "forward_gflop": round(fwd, 1), "algorithmic_gflop_per_iteration": round(3 * fwd, 1),
+           "achieved_tflops": round(3 * fwd / dt / 1e3, 2), "frac_of_fp32_mfma_peak": round(3 * fwd / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "total_loss_first_last": [round(first, 4), round(last, 4)],
+           "note": "Trainer.step: forward_model forward + backward + AdamW over 126 tensors on one 640x640 frame, parameters stepped in the "
+                   "layers the inference path runs; FP16: False (the yaml's autocast / GradScaler path is refused, not emulated)"}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -690,6 +792,18 @@ def main():
                     torch.cuda.empty_cache()
             except Exception as e:      # never lose the headline to a variant
                 log(f"lock-step variant failed: {e!r}")
+            if (H, W) == (640, 640) and not args.no_config5:
+                try:
+                    variants["config5_960_batch4"] = config5_variant(sd, args.memory_thresh)
+                    log(f"config5 960x960 batch of 4: {variants['config5_960_batch4']['value']} frames/s")
+                except Exception as e:
+                    log(f"config5 variant failed: {e!r}")
+            if (H, W) == (640, 640) and not args.no_train_step:
+                try:
+                    variants["train_step_640"] = train_step_variant(sd)
+                    log(f"training iteration at 640x640: {variants['train_step_640']['ms_per_step']} ms")
+                except Exception as e:
+                    log(f"train-step variant failed: {e!r}")
 
     roofline_hbm = None
     if rank == 0:

@@ -54,7 +54,8 @@ class EodCenterNetLossDesc(C.Structure):
         ("level_scale", C.c_float * 8), ("agn_heatmap", C.c_void_p), ("reg_targets", C.c_void_p), ("pos_inds", C.c_void_p),
         ("n_pos", C.c_int32), ("hm_focal_alpha", C.c_float), ("hm_focal_beta", C.c_float), ("loss_gamma", C.c_float),
         ("sigmoid_clamp", C.c_float), ("ignore_high_fp", C.c_float), ("pos_weight", C.c_float), ("neg_weight", C.c_float),
-        ("reg_weight", C.c_float), ("num_pos_avg", C.c_float), ("reg_norm", C.c_float), ("d_head_out", C.c_void_p),
+        ("reg_weight", C.c_float), ("num_pos_avg", C.c_float), ("reg_norm", C.c_float), ("counts_local", C.c_void_p),
+        ("counts_total", C.c_void_p), ("world_size", C.c_float), ("d_head_out", C.c_void_p),
         ("losses", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
@@ -87,6 +88,20 @@ class EodDetDesc(C.Structure):
         ("out_unique_rows", C.c_void_p), ("out_unique_count", C.c_void_p), ("unique_cap", C.c_int32),
         ("out_rep_of", C.c_void_p), ("out_rep_list", C.c_void_p), ("out_rep_count", C.c_void_p), ("batch", C.c_int32),
     ]
+
+
+class EodStageTailDesc(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("zs", C.c_void_p), ("prob_acc", C.c_void_p), ("accumulate", C.c_int32), ("feat_norm_out", C.c_void_p),
+                ("count", C.c_void_p), ("R_cap", C.c_int32), ("D", C.c_int32), ("C1", C.c_int32), ("temp", C.c_float), ("zs_mem", C.c_void_p),
+                ("prop_scores", C.c_void_p), ("mem_scores_out", C.c_void_p), ("final_inv_stages", C.c_float), ("batch", C.c_int32),
+                ("hb", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("hb_dim", C.c_int32), ("w2_ld", C.c_int32),
+                ("boxes_in", C.c_void_p), ("boxes_out", C.c_void_p), ("deltas_out", C.c_void_p), ("wx", C.c_float), ("wy", C.c_float),
+                ("ww", C.c_float), ("wh", C.c_float), ("clip", C.c_int32), ("img_w", C.c_float), ("img_h", C.c_float)]
+
+
+class EodAdamWTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t),
+                ("lr", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32)]
 
 
 class EodMemWriteDesc(C.Structure):
@@ -134,6 +149,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "eod_match_label": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eod_match_label_proposals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_sample_proposals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_zs_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "eod_zs_logits_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
@@ -144,6 +161,7 @@ SIGNATURES = {
     "eod_centernet_proposals": (C.c_int, [C.POINTER(EodProposalDesc), C.c_void_p]),
     "eod_zs_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "eod_cascade_stage_tail": (C.c_int, [C.POINTER(EodStageTailDesc), C.c_void_p]),
     "eod_apply_deltas": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "eod_cascade_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
@@ -178,6 +196,7 @@ SIGNATURES = {
     "eod_relu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "eod_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, C.c_int, C.c_double, C.c_void_p]),
+    "eod_adamw_step_multi": (C.c_int, [C.POINTER(EodAdamWTensor), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),
     "eod_memory_write_workspace_bytes": (C.c_size_t, [C.c_int] * 6),

@@ -54,11 +54,56 @@ __device__ __forceinline__ void stage_class_matrix(const float* __restrict__ zs,
     }
   }
 }
+// The rest of a cascade stage's predictor in the same launch (eod_cascade_stage_tail): bbox_pred.2 (Linear 1024 -> 4 on the ReLU'd
+// bbox_pred.0 output, detic_fast_rcnn.py:109-116) and Box2BoxTransform.apply_deltas onto the stage's boxes (detic_roi_heads.py:121-122,
+// 314).  One wave per row like the classifier: lane l owns inputs 16 l .. 16 l + 15 of the row, four butterfly sums.
+struct BoxTail {
+  const float* hb;        // [R, K] bbox_pred.0 output; null = no tail
+  const float* w2;        // [4][ld] bbox_pred.2 weight rows
+  const float* b2;        // [4]
+  int K, ld;
+  const float* boxes_in;  // [R,4]
+  float* boxes_out;       // [R,4]
+  float* deltas_out;      // [R,4] or null
+  float wx, wy, ww, wh;
+  int clip;
+  float img_w, img_h;
+};
+
+__device__ __forceinline__ void box_tail_row(const BoxTail& t, int row, int lane) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = lane * 16; k0 < t.K; k0 += 64 * 16) {
+    f32x4 h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = *reinterpret_cast<const f32x4*>(t.hb + (size_t)row * t.K + k0 + 4 * q);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(t.w2 + (size_t)o * t.ld + k0 + 4 * q);
+        acc[o] += h[q].x * w.x; acc[o] += h[q].y * w.y; acc[o] += h[q].z * w.z; acc[o] += h[q].w * w.w;
+      }
+    }
+  }
+  float d[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) d[o] = wave_reduce_sum(acc[o]) + t.b2[o];
+  if (lane == 0) {
+    if (t.deltas_out) {
+      t.deltas_out[row * 4 + 0] = d[0]; t.deltas_out[row * 4 + 1] = d[1]; t.deltas_out[row * 4 + 2] = d[2]; t.deltas_out[row * 4 + 3] = d[3];
+    }
+    const float x1 = t.boxes_in[row * 4 + 0], y1 = t.boxes_in[row * 4 + 1], x2 = t.boxes_in[row * 4 + 2], y2 = t.boxes_in[row * 4 + 3];
+    float ox1, oy1, ox2, oy2;
+    eod_apply_deltas_one(d, x1, y1, x2, y2, t.wx, t.wy, t.ww, t.wh, t.clip, t.img_w, t.img_h, ox1, oy1, ox2, oy2);
+    t.boxes_out[row * 4 + 0] = ox1; t.boxes_out[row * 4 + 1] = oy1; t.boxes_out[row * 4 + 2] = ox2; t.boxes_out[row * 4 + 3] = oy2;
+  }
+}
+
 __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restrict__ feat, const float* __restrict__ zs,
                                                            float* __restrict__ prob_acc, int accumulate, float* __restrict__ featn_out,
                                                            const int* __restrict__ count, int R_cap, int D, int C1, float temp,
                                                            const float* __restrict__ zs_mem, const float* __restrict__ prop_scores,
-                                                           float* __restrict__ mem_scores, float final_inv_stages, int batch) {
+                                                           float* __restrict__ mem_scores, float final_inv_stages, int batch, BoxTail tail) {
   EOD_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float zt[ZS_MAX_C * 512];
   // R_cap % 4 == 0 whenever the rows are a batch of lists: a workgroup's four rows belong to one list
@@ -68,6 +113,7 @@ __global__ __launch_bounds__(256) void zs_classify_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool active = row < R_cap * batch && row_has_work(count, R_cap, row);
+  if (active && tail.hb) box_tail_row(tail, row, lane);
   float x[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) x[q] = 0.f;
@@ -305,7 +351,27 @@ extern "C" int eod_zs_classify(const float* feat, const float* zs, float* prob_a
   if (batch > 1 && (batch > EOD_MAX_BATCH || R_cap % 4 != 0)) return EOD_ERR_BAD_DIMS;
   const int nb = batch > 1 ? batch : 1;
   hipLaunchKernelGGL(zs_classify_kernel, dim3((R_cap * nb + 3) / 4), dim3(256), 0, (hipStream_t)stream, feat, zs, prob_acc, accumulate,
-                     feat_norm_out, count, R_cap, D, C1, temp, zs_mem, prop_scores, mem_scores_out, final_inv_stages, nb);
+                     feat_norm_out, count, R_cap, D, C1, temp, zs_mem, prop_scores, mem_scores_out, final_inv_stages, nb, BoxTail{});
+  return eod_launch_status();
+}
+
+extern "C" int eod_cascade_stage_tail(const EodStageTailDesc* d, eod_stream_t stream) {
+  if (!d || !d->feat || !d->zs || !d->prob_acc || !d->hb || !d->w2 || !d->b2 || !d->boxes_in || !d->boxes_out) return EOD_ERR_NULL;
+  if (d->zs_mem && (!d->prop_scores || !d->mem_scores_out)) return EOD_ERR_NULL;
+  if (d->final_inv_stages > 0.f && !d->prop_scores) return EOD_ERR_NULL;
+  if (d->D != 512 || d->C1 < 2 || d->R_cap <= 0 || d->hb_dim <= 0 || d->hb_dim % 16 != 0 || d->w2_ld < d->hb_dim || d->w2_ld % 4 != 0)
+    return EOD_ERR_BAD_DIMS;
+  if (d->C1 > ZS_MAX_C) return EOD_ERR_CAPACITY;
+  if (!eod_aligned16(d->feat) || (d->feat_norm_out && !eod_aligned16(d->feat_norm_out)) || !eod_aligned16(d->zs) ||
+      (d->zs_mem && !eod_aligned16(d->zs_mem)) || !eod_aligned16(d->hb) || !eod_aligned16(d->w2))
+    return EOD_ERR_ALIGN;
+  if (d->batch > 1 && (d->batch > EOD_MAX_BATCH || d->R_cap % 4 != 0)) return EOD_ERR_BAD_DIMS;
+  const int nb = d->batch > 1 ? d->batch : 1;
+  BoxTail t{d->hb, d->w2, d->b2, d->hb_dim, d->w2_ld, d->boxes_in, d->boxes_out, d->deltas_out, d->wx, d->wy, d->ww, d->wh,
+            d->clip, d->img_w, d->img_h};
+  hipLaunchKernelGGL(zs_classify_kernel, dim3((d->R_cap * nb + 3) / 4), dim3(256), 0, (hipStream_t)stream, d->feat, d->zs, d->prob_acc,
+                     d->accumulate, d->feat_norm_out, d->count, d->R_cap, d->D, d->C1, d->temp, d->zs_mem, d->prop_scores,
+                     d->mem_scores_out, d->final_inv_stages, nb, t);
   return eod_launch_status();
 }
 

@@ -21,6 +21,7 @@
 // 32 consecutive channels of one position per half wave -- coalesced as the rows lie in memory.  A workgroup owns one 32x32 tile
 // of dW_l; its four waves take a quarter of the positions each and are added in wave order (deterministic).
 #include "eod_common.h"
+#include <algorithm>
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 #include <cmath>
@@ -148,6 +149,49 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, 
     mi = mi + (gi - mi) * one_minus_b1;
     const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi + (-step_size) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// The same update for up to ADAMW_MULTI tensors in ONE launch (the training step has 126 parameter tensors: 126 launches of a few
+// microseconds each were 4 % of the iteration's kernel time and 126 launch boundaries).  The tensors' constants travel in the
+// kernel arguments; a workgroup finds its tensor by the prefix of the tensors' workgroup counts.  Element for element the
+// arithmetic of adamw_step_kernel.
+#define ADAMW_MULTI 24
+struct AdamWMulti {
+  float* p[ADAMW_MULTI];
+  const float* g[ADAMW_MULTI];
+  float* m[ADAMW_MULTI];
+  float* v[ADAMW_MULTI];
+  unsigned long long n[ADAMW_MULTI];
+  float decay[ADAMW_MULTI], step_size[ADAMW_MULTI], bc2_sqrt[ADAMW_MULTI];
+  unsigned block_end[ADAMW_MULTI];     // exclusive end of tensor t's workgroups
+  int count;
+  float one_minus_b1, b2, one_minus_b2, eps, clip;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWMulti a) {
+  int t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.block_end[t]) ++t;
+  const unsigned first = t ? a.block_end[t - 1] : 0u;
+  const size_t nb = a.block_end[t] - first;
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  const size_t n = a.n[t];
+  const float decay = a.decay[t], step_size = a.step_size[t], bc2_sqrt = a.bc2_sqrt[t];
+  for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
+    float gi = g[i];
+    if (a.clip > 0.f) gi = fminf(fmaxf(gi, -a.clip), a.clip);
+    float pi = p[i] * decay;
+    float mi = m[i];
+    mi = mi + (gi - mi) * a.one_minus_b1;
+    const float vi = v[i] * a.b2 + a.one_minus_b2 * (gi * gi);
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
     pi = pi + (-step_size) * (mi / denom);
     p[i] = pi;
     m[i] = mi;
@@ -637,6 +681,38 @@ extern "C" int eod_adamw_step(float* param, const float* grad, float* exp_avg, f
   hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                      (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
                      (float)sqrt(bc2), (float)eps, (float)clip_value);
+  return eod_launch_status();
+}
+
+extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
+                                    eod_stream_t stream) {
+  if (!tensors) return EOD_ERR_NULL;
+  if (count < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return EOD_ERR_BAD_DIMS;
+  for (int i = 0; i < count; ++i) {
+    const EodAdamWTensor& t = tensors[i];
+    if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return EOD_ERR_NULL;
+    if (t.n == 0 || t.step < 1 || !(t.lr >= 0.0)) return EOD_ERR_BAD_DIMS;
+  }
+  for (int i0 = 0; i0 < count; i0 += ADAMW_MULTI) {
+    AdamWMulti a{};
+    a.count = std::min(ADAMW_MULTI, count - i0);
+    a.one_minus_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.clip = (float)clip_value;
+    unsigned blocks = 0;
+    for (int k = 0; k < a.count; ++k) {
+      const EodAdamWTensor& t = tensors[i0 + k];
+      const double bc1 = 1.0 - pow(beta1, (double)t.step), bc2 = 1.0 - pow(beta2, (double)t.step);
+      a.p[k] = t.param; a.g[k] = t.grad; a.m[k] = t.exp_avg; a.v[k] = t.exp_avg_sq; a.n[k] = t.n;
+      a.decay[k] = (float)(1.0 - t.lr * t.weight_decay);
+      a.step_size[k] = (float)(t.lr / bc1);
+      a.bc2_sqrt[k] = (float)sqrt(bc2);
+      size_t nb = (t.n + 1023) / 1024;                  // four elements per thread and pass
+      if (nb > 1024) nb = 1024;
+      blocks += (unsigned)nb;
+      a.block_end[k] = blocks;
+    }
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return eod_launch_status();
 }
 

@@ -504,7 +504,12 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(const _Float16* X, co
                                                             const float* __restrict__ sinv, const float* __restrict__ bias,
                                                             float* P, ProjArgs a) {
   EOD_CHAIN_PRIO();
-  const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
+  // Workgroups that share an XCD (id % 8 under the round-robin dispatch) take CONSECUTIVE (tile, half) pairs: both halves of a row
+  // tile read the same pooled fragments through one L2, and a level's 0.5 MB weight panel is fetched by the XCDs that hold its
+  // tiles only (P4 by two, P5 by one) instead of by all eight -- the 8 L2s are not coherent with each other, every one that sees a
+  // panel fetches its own copy (PMC FETCH_SIZE: 32.3 MB per launch against 18.8 MB of operands before this mapping).
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t = vb >> 1, half = vb & 1;
   const int lvl = t >= a.tile_off[2] ? 2 : (t >= a.tile_off[1] ? 1 : 0);
   if (a.batch > 1) {
     // scene b of a batch: its own pooled rows; `feats` is level major over the scenes, level l of scene b starts at row

@@ -22,6 +22,12 @@ struct CnLossArgs {
   float lv_scale[8];
   float alpha, beta, gamma, clampv, ignore_fp;
   float c_pos, c_neg, c_reg;   // pos_weight / num_pos_avg, neg_weight / num_pos_avg, reg_weight / reg_norm
+  // counts on the device (no host round trip between the target assignment and the losses): counts_local[0] = length of `pos`
+  // (clamped to n_pos = its capacity), counts_total = {positives, regression rows} summed over the ranks; the three constants
+  // above are then weight / max(count / world, 1), evaluated by every thread as the host evaluates them
+  const int* counts_local;
+  const int* counts_total;
+  float w_pos, w_neg, w_reg, world;
   float* d_head;        // [P, stride]
   double* partial;      // [blocks][2]
   float* losses;        // [3]: loc, agn_pos, agn_neg
@@ -33,7 +39,19 @@ __device__ __forceinline__ float half_on_tie(float a, float b, bool take_less) {
   return (take_less ? a < b : a > b) ? 1.f : 0.f;
 }
 
+__device__ __forceinline__ void cn_loss_constants(CnLossArgs& a) {
+  if (!a.counts_total) return;
+  const float num_pos_avg = fmaxf((float)((double)a.counts_total[0] / (double)a.world), 1.f);
+  const float reg_norm = fmaxf((float)((double)a.counts_total[1] / (double)a.world), 1.f);
+  a.c_pos = a.w_pos / num_pos_avg;
+  a.c_neg = a.w_neg / num_pos_avg;
+  a.c_reg = a.w_reg / reg_norm;
+  const int n = a.counts_local[0];
+  a.n_pos = n < a.n_pos ? (n < 0 ? 0 : n) : a.n_pos;
+}
+
 __global__ __launch_bounds__(256) void centernet_loss_dense_kernel(CnLossArgs a) {
+  cn_loss_constants(a);
   __shared__ double red[2][4];
   double neg_sum = 0.0, loc_sum = 0.0;
   const float an = a.alpha >= 0.f ? 1.f - a.alpha : 1.f;
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(256) void centernet_loss_dense_kernel(CnLossArgs a)
 }
 
 __global__ __launch_bounds__(256) void centernet_loss_pos_kernel(CnLossArgs a, int dense_blocks) {
+  cn_loss_constants(a);
   __shared__ double red[4];
   double pos_sum = 0.0;
   const float ap = a.alpha >= 0.f ? a.alpha : 1.f;
@@ -381,7 +400,10 @@ extern "C" int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t st
   if (d->level_off[0] != 0 || d->level_off[d->levels] != d->P) return EOD_ERR_BAD_DIMS;
   for (int l = 0; l < d->levels; ++l)
     if (d->level_off[l + 1] < d->level_off[l]) return EOD_ERR_BAD_DIMS;
-  if (!(d->num_pos_avg >= 1.f) || !(d->reg_norm >= 1.f) || !(d->sigmoid_clamp > 0.f && d->sigmoid_clamp < 0.5f)) return EOD_ERR_BAD_DIMS;
+  const bool dev_counts = d->counts_total != nullptr;
+  if (dev_counts && (!d->counts_local || !(d->world_size >= 1.f))) return EOD_ERR_BAD_DIMS;
+  if (!dev_counts && (!(d->num_pos_avg >= 1.f) || !(d->reg_norm >= 1.f))) return EOD_ERR_BAD_DIMS;
+  if (!(d->sigmoid_clamp > 0.f && d->sigmoid_clamp < 0.5f)) return EOD_ERR_BAD_DIMS;
   if (d->workspace_bytes < eod_centernet_loss_workspace_bytes()) return EOD_ERR_CAPACITY;
   CnLossArgs a{};
   a.head = d->head_out; a.stride = d->head_stride; a.heat = d->agn_heatmap; a.reg_t = d->reg_targets;
@@ -390,7 +412,12 @@ extern "C" int eod_centernet_loss(const EodCenterNetLossDesc* d, eod_stream_t st
   for (int l = 0; l < d->levels; ++l) a.lv_scale[l] = d->level_scale[l];
   a.alpha = d->hm_focal_alpha; a.beta = d->hm_focal_beta; a.gamma = d->loss_gamma; a.clampv = d->sigmoid_clamp;
   a.ignore_fp = d->ignore_high_fp;
-  a.c_pos = d->pos_weight / d->num_pos_avg; a.c_neg = d->neg_weight / d->num_pos_avg; a.c_reg = d->reg_weight / d->reg_norm;
+  if (dev_counts) {
+    a.counts_local = d->counts_local; a.counts_total = d->counts_total; a.world = d->world_size;
+    a.w_pos = d->pos_weight; a.w_neg = d->neg_weight; a.w_reg = d->reg_weight;
+  } else {
+    a.c_pos = d->pos_weight / d->num_pos_avg; a.c_neg = d->neg_weight / d->num_pos_avg; a.c_reg = d->reg_weight / d->reg_norm;
+  }
   a.d_head = d->d_head_out; a.partial = static_cast<double*>(d->workspace); a.losses = d->losses;
   int blocks = (d->P + 255) / 256;
   if (blocks > kDenseBlocksMax) blocks = kDenseBlocksMax;
@@ -424,6 +451,10 @@ struct MatchArgs {
   const float* gtb; const int* gtc; int G;
   float thr; int C;
   int* matched; float* iou; int* cls; float* out_gtb;
+  // eod_match_label_proposals: `boxes` is a capacity-sized proposal list with its count on the device; row i of the R = cap + G
+  // rows is proposal i (i < count), ground-truth box i - count (add_ground_truth_to_proposals, when `append`), or no row at all
+  // (class -1: ignored by the sampling); `all_boxes` [R,4] receives the rows' boxes
+  const int* count; int cap; int append; float* all_boxes;
 };
 
 __global__ __launch_bounds__(256) void match_label_kernel(MatchArgs a) {
@@ -431,9 +462,24 @@ __global__ __launch_bounds__(256) void match_label_kernel(MatchArgs a) {
   __shared__ float g[256 * 5];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f, barea = 0.f;
+  bool valid = i < a.R;
   if (i < a.R) {
-    bx0 = a.boxes[i * 4]; by0 = a.boxes[i * 4 + 1]; bx1 = a.boxes[i * 4 + 2]; by1 = a.boxes[i * 4 + 3];
-    barea = (bx1 - bx0) * (by1 - by0);                                   // Boxes.area
+    const float* src = a.boxes + (size_t)i * 4;
+    if (a.count) {
+      int n = *a.count;
+      n = n < 0 ? 0 : (n > a.cap ? a.cap : n);
+      if (i >= n) {
+        valid = a.append && i - n < a.G;
+        src = a.gtb + (size_t)(valid ? i - n : 0) * 4;
+      }
+    }
+    if (valid) {
+      bx0 = src[0]; by0 = src[1]; bx1 = src[2]; by1 = src[3];
+      barea = (bx1 - bx0) * (by1 - by0);                                 // Boxes.area
+    }
+    if (a.all_boxes) {
+      a.all_boxes[i * 4] = bx0; a.all_boxes[i * 4 + 1] = by0; a.all_boxes[i * 4 + 2] = bx1; a.all_boxes[i * 4 + 3] = by1;
+    }
   }
   float best = -1.f;
   int bi = 0;
@@ -464,6 +510,11 @@ __global__ __launch_bounds__(256) void match_label_kernel(MatchArgs a) {
     }
   }
   if (i >= a.R) return;
+  if (!valid) {                                                            // beyond the list: no row (ignored by the sampling)
+    a.matched[i] = 0; a.iou[i] = 0.f; a.cls[i] = -1;
+    a.out_gtb[i * 4] = 0.f; a.out_gtb[i * 4 + 1] = 0.f; a.out_gtb[i * 4 + 2] = 0.f; a.out_gtb[i * 4 + 3] = 0.f;
+    return;
+  }
   if (a.G == 0) {                                                          // Matcher on an empty matrix: match 0, label 0
     a.matched[i] = 0; a.iou[i] = 0.f; a.cls[i] = a.C;
     a.out_gtb[i * 4] = 0.f; a.out_gtb[i * 4 + 1] = 0.f; a.out_gtb[i * 4 + 2] = 0.f; a.out_gtb[i * 4 + 3] = 0.f;
@@ -606,7 +657,22 @@ extern "C" int eod_match_label(const float* boxes, int R, const float* gt_boxes,
   if (!boxes || !matched_idx || !matched_iou || !out_classes || !out_gt_boxes) return EOD_ERR_NULL;
   if (G > 0 && (!gt_boxes || !gt_classes)) return EOD_ERR_NULL;
   if (R <= 0 || G < 0 || num_classes <= 0 || !(iou_thresh >= 0.f && iou_thresh <= 1.f)) return EOD_ERR_BAD_DIMS;
-  MatchArgs a{boxes, R, gt_boxes, gt_classes, G, iou_thresh, num_classes, matched_idx, matched_iou, out_classes, out_gt_boxes};
+  MatchArgs a{boxes, R, gt_boxes, gt_classes, G, iou_thresh, num_classes, matched_idx, matched_iou, out_classes, out_gt_boxes,
+              nullptr, 0, 0, nullptr};
+  hipLaunchKernelGGL(match_label_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return eod_launch_status();
+}
+
+extern "C" int eod_match_label_proposals(const float* prop_boxes, const int32_t* prop_count, int cap, const float* gt_boxes,
+                                         const int32_t* gt_classes, int G, int append_gt, float iou_thresh, int num_classes,
+                                         float* all_boxes, int32_t* matched_idx, float* matched_iou, int32_t* out_classes,
+                                         float* out_gt_boxes, eod_stream_t stream) {
+  if (!prop_boxes || !prop_count || !all_boxes || !matched_idx || !matched_iou || !out_classes || !out_gt_boxes) return EOD_ERR_NULL;
+  if (G > 0 && (!gt_boxes || !gt_classes)) return EOD_ERR_NULL;
+  if (cap <= 0 || G < 0 || num_classes <= 0 || !(iou_thresh >= 0.f && iou_thresh <= 1.f)) return EOD_ERR_BAD_DIMS;
+  const int R = cap + (append_gt ? G : 0);
+  MatchArgs a{prop_boxes, R, gt_boxes, gt_classes, G, iou_thresh, num_classes, matched_idx, matched_iou, out_classes, out_gt_boxes,
+              prop_count, cap, append_gt ? 1 : 0, all_boxes};
   hipLaunchKernelGGL(match_label_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   return eod_launch_status();
 }

@@ -109,7 +109,8 @@ class BackboneBackward:
                     raise ValueError("pass the map_merge_projection weights (merge_weights=) to back-propagate into the memory branch")
                 self._merge_bw = ops.MemoryProjectorBackward(self.merge_weights, self.bb.device)
             H, W = saved["HW"]
-            mb = self._merge_bw([t.view(-1, 256) for t in g_out], saved["pooled"], H, W, bb.map_feature_weight)
+            # the memory table is an input of the training step, not a parameter (loader.py:199-223): only dW / db are needed
+            mb = self._merge_bw([t.view(-1, 256) for t in g_out], saved["pooled"], H, W, bb.map_feature_weight, need_input_grad=False)
             for i in range(3):
                 grads[f"map_merge_projection{i + 1}"] = (mb["dW"][i], mb["db"][i])
         # output convs -> gradients of the merged laterals; top-down add: the coarser level also collects the 2x2 block sums

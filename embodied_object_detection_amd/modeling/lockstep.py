@@ -354,6 +354,15 @@ class LockstepScenes:
             st["cls_bb0"](self.h2, B * R, 1, 1, relu=True, out=feat, split=(512, self.hb), **seg)
             last = s_i == rh.num_stages - 1
             rescore = s_i == 0 and update_mem
+            if rh.fuse_stage_tail and not rh.fold_deltas:
+                # classifier tail + bbox_pred.2 + apply_deltas in one launch, as the single-scene model runs them (roi_heads._cascade)
+                ops.cascade_stage_tail(feat, st["zs"], self.prob, s_i > 0, self.featn0 if s_i == 0 else None, prop_count, R, C1, rh.norm_temp,
+                                       self.hb, st["bb2"], boxes, self.boxes[s_i + 1], rh.cascade_weights[s_i], not last, float(W), float(H),
+                                       zs_mem=m.zs_weight if rescore else None, prop_scores=prop_scores if (last or rescore) else None,
+                                       mem_scores_out=self.mem_scores if rescore else None,
+                                       final_inv_stages=1.0 / rh.num_stages if last else 0.0, deltas_out=self.deltas, batch=B)
+                boxes = self.boxes[s_i + 1]
+                continue
             ops.zs_classify(feat, st["zs"], self.prob, s_i > 0, self.featn0 if s_i == 0 else None, prop_count, R, C1, rh.norm_temp,
                             zs_mem=m.zs_weight if rescore else None, prop_scores=prop_scores if (last or rescore) else None,
                             mem_scores_out=self.mem_scores if rescore else None,

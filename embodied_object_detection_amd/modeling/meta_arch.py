@@ -36,7 +36,7 @@ _SCHED_STREAMS: Dict[int, Tuple[torch.cuda.Stream, ...]] = {}
 # t+2 has been enqueued, so that the host never waits for a detection pass that still trails on the GPU (the host needs ~3.7 ms
 # to enqueue a frame, about as long as the GPU needs to run one).
 RESULT_SETS = 3
-PYRAMID_SETS = 4        # current frame, the frame before (its detection pass may trail), and up to two frames computed ahead
+PYRAMID_SETS = 6        # current frame, the frame before (its detection pass may trail), and up to four frames computed ahead
 
 
 def _sched_streams(device: torch.device) -> Tuple[torch.cuda.Stream, ...]:
@@ -146,9 +146,18 @@ class CustomRCNNRecurrent:
         # how many coming frames of an episode the look-ahead computes at once (their images are all there when `forward` is
         # called): 2 = the memory-independent trunk + FPN top-down of frames t+1 and t+2 as ONE N = 2 pass every second frame
         # (planned like one image: bitwise the N = 1 results).  Measured at 640x640: the pass costs 1.23 ms per image instead of 1.61
-        # (tools/trunk_batch_time.py) and the frames without a trunk beside them have a 1.7 ms front instead of 2.3 -- but the
-        # frames WITH the double trunk lose the same: 187.1 frames/s either way.  Default 1.
-        self.lookahead_frames = 1
+        # (tools/trunk_batch_time.py).  With a window of the same size (round 3) the frames WITH the double trunk lost what the
+        # others gained; inside a deeper window (`lookahead_depth`) the N = 2 pass has two frame periods to finish: default 2.
+        self.lookahead_frames = 2
+        # how many coming frames may be AHEAD at any time (>= lookahead_frames; PYRAMID_SETS - 2 at most).  With depth == batch size
+        # a pass starts when the last frame computed ahead has been consumed and must be over one frame later -- the trunk's ~75
+        # launches then span the whole frame (profiles/r03_frame_schedule.txt: 0.24 -> 3.60 ms of a 3.5 ms frame) and the next frame
+        # waits for them: the look-ahead is a second critical chain.  A deeper window decouples it: a pass is started while frames
+        # are still ahead and has several frame periods to finish (only its throughput matters, and N = 2 passes cost 24 % less per
+        # image).  None = lookahead_frames (the round-3 schedule).  Measured at 640x640 (tools/knob_ab.py, one call): batch 1 /
+        # window 1 287 frames/s, 1 / 2 287, 2 / 3 301, 2 / 4 299.
+        self.lookahead_depth: Optional[int] = 3
+        self._ahead: List[dict] = []        # frames computed (or being computed) ahead, in order: image, Hp, Wp, event
         self.front_event: Optional[torch.cuda.Event] = None      # one-stream schedule only: recorded after the box cascade
         # where the (deferred, low-priority) detection mask pass may start: "cascade" (as soon as the detections exist),
         # "proposal_masks" / "memory_write" (behind this frame's critical chain: it then runs beside the NEXT frame's
@@ -321,7 +330,7 @@ class CustomRCNNRecurrent:
                 if self.implicit_memory is None:
                     raise RuntimeError("first frame of a scene must carry memory_reset=True (custom_rcnn.py:485 reads unset state)")
                 refresh = self.test_type in ("default", "episodic") or (self.test_type == "longterm" and i == 0)
-                nxt = input_seq[i + 1:i + 1 + max(1, int(self.lookahead_frames))] or None      # the frames that follow, in order
+                nxt = input_seq[i + 1:i + 1 + PYRAMID_SETS] or None                            # the frames that follow, in order
                 last = nxt is None and input_seq is batched_inputs[-1]
                 t0 = _time.perf_counter()
                 self.inference_frame(frame, refresh_memory_snapshot=refresh, materialize=False, next_frame=nxt,
@@ -380,10 +389,11 @@ class CustomRCNNRecurrent:
             p = p.to(torch.int32)
         return p.to(self.device, non_blocking=True).contiguous()
 
-    def _enqueue_trunk(self, frames: List[dict], after: torch.cuda.Event):
+    def _enqueue_trunk(self, frames: List[dict], after: torch.cuda.Event, first: int = 0):
         """Bottom-up pass + FPN top-down convs of the coming frame(s) on the look-ahead stream, ordered after `after` (an event of
-        the main stream recorded once the previous look-ahead has been consumed and the previous frame has fully finished).  Frame b
-        of the list is written into pyramid set (current + 1 + b); more than one frame = one batched pass."""
+        the main stream recorded once the previous frame has fully finished).  Frame b of the list is written into pyramid set
+        (current + 1 + first + b) -- `first` frames are ahead already; more than one frame = one batched pass.  The frames join
+        `self._ahead` with the pass's own event."""
         if self._trunk_stream is None:
             # high priority like the side stream: its ~75 launches are small and must not queue behind the mask GEMMs' thousands
             # of workgroups
@@ -391,7 +401,8 @@ class CustomRCNNRecurrent:
             self._ev_trunk = torch.cuda.Event()
         ts = self._trunk_stream
         ts.wait_event(after)
-        sets = [(self._pyramid + 1 + b) % PYRAMID_SETS for b in range(len(frames))]
+        done = torch.cuda.Event()
+        sets = [(self._pyramid + 1 + first + b) % PYRAMID_SETS for b in range(len(frames))]
         for st in sets:
             if st in self._pyr_reader:
                 ts.wait_event(self._pyr_reader[st])      # a trailing detection pass may still read that set
@@ -411,9 +422,9 @@ class CustomRCNNRecurrent:
                     views = self.backbone._plan(Hp, Wp, st)[3]
                     for l in range(3):
                         views[l].copy_(p345[l][b:b + 1])
-            self._ev_trunk.record(ts)
+            done.record(ts)
             self._mark("trunk_lookahead", ts)
-        self._prefetched = [(f["image"], Hp, Wp) for f in frames]
+        self._ahead = self._ahead + [dict(image=f["image"], Hp=Hp, Wp=Wp, event=done) for f in frames]
 
     def inference_frame(self, frame: dict, refresh_memory_snapshot: bool = True, materialize: bool = True,
                         next_frame=None, trailing_detection_pass: bool = False):
@@ -440,45 +451,56 @@ class CustomRCNNRecurrent:
                 self._refresh_memory_snapshot()
             mem_f16 = self._mem_f16
 
-        pre_list, self._prefetched = self._prefetched, None
-        if isinstance(pre_list, tuple):            # (image, Hp, Wp) handed over by BatchedSequences
-            pre_list = [pre_list]
-        if pre_list:
-            # whatever was started ahead (used or not) must be finished before this frame touches any pyramid set
-            torch.cuda.current_stream(self.device).wait_event(self._ev_trunk)
-        hit = bool(pre_list) and pre_list[0][0] is frame["image"]
-        pre = pre_list[0] if hit else None
-        # frames computed ahead beyond this one stay valid only if the caller really passes them next (checked frame by frame)
-        still_ahead = pre_list[1:] if hit else []
+        cur = torch.cuda.current_stream(self.device)
+        ext, self._prefetched = self._prefetched, None
+        if isinstance(ext, tuple):                 # (image, Hp, Wp) computed into the next set by BatchedSequences, its event in _ev_trunk
+            self._ahead = [dict(image=ext[0], Hp=ext[1], Wp=ext[2], event=self._ev_trunk)]
+        ahead = self._ahead
+        hit = bool(ahead) and ahead[0]["image"] is frame["image"]
+        if ahead and not hit:
+            for e in ahead:                        # the hint was wrong: what runs ahead must be over before any set or the trunk's
+                cur.wait_event(e["event"])         # own buffers are touched again
+            ahead = []
+        pre = None
+        if hit:
+            pre = ahead.pop(0)
+            cur.wait_event(pre["event"])           # this frame's own pass only: later passes may still be running
         # every frame moves to the next of PYRAMID_SETS pyramid sets (the look-ahead wrote P3..P5 of a hit into exactly that one);
         # a trailing detection pass of the frame that last used the set must be over before a miss recomputes into it
         self._pyramid = (self._pyramid + 1) % PYRAMID_SETS
         if not hit and self._pyramid in self._pyr_reader:
-            torch.cuda.current_stream(self.device).wait_event(self._pyr_reader[self._pyramid])
+            cur.wait_event(self._pyr_reader[self._pyramid])
         coming = [] if next_frame is None else (list(next_frame) if isinstance(next_frame, (list, tuple)) else [next_frame])
-        if still_ahead and not (coming and all(a[0] is c["image"] for a, c in zip(still_ahead, coming)) and len(coming) >= len(still_ahead)):
-            still_ahead = []                       # the hint changed: what was computed ahead is dropped
-        if still_ahead:
-            self._prefetched = still_ahead         # nothing new to start: the next frame's trunk is already there
-            coming = []
-        else:
-            coming = coming[:max(1, int(self.lookahead_frames))]
-        next_frame = coming if coming else None
-        look_ahead = next_frame is not None and self.prefetch_trunk and self.overlap_branches
+        # frames further ahead stay valid only if the caller really passes them next (checked frame by frame)
+        keep = 0
+        while keep < len(ahead) and keep < len(coming) and ahead[keep]["image"] is coming[keep]["image"]:
+            keep += 1
+        for e in ahead[keep:]:
+            cur.wait_event(e["event"])             # dropped: over before their sets are written again
+        ahead = ahead[:keep]
+        self._ahead = ahead
+        depth = max(1, int(self.lookahead_frames)) if self.lookahead_depth is None else max(1, int(self.lookahead_depth))
+        batch = []
+        if self.prefetch_trunk and self.overlap_branches and len(ahead) < min(depth, PYRAMID_SETS - 2):
+            room = PYRAMID_SETS - 2 - len(ahead)
+            batch = coming[len(ahead):len(ahead) + min(max(1, int(self.lookahead_frames)), room)]
+        next_frame = batch if batch else None
+        look_ahead = next_frame is not None
+        first_ahead = len(ahead)
         if look_ahead and self.lookahead_at_start:
             # it may start NOW, beside this frame's memory fusion, tower and proposal decoding (a short latency-bound chain
             # that leaves most of the chip idle); the host enqueues that chain first so that the main stream never starves
             if self._ev_start is None:
                 self._ev_start = torch.cuda.Event()
-            self._ev_start.record(torch.cuda.current_stream(self.device))
+            self._ev_start.record(cur)
         if hit:
-            feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre[1], pre[2], mem_f16, proj, self._pyramid, self._err)
+            feats, views, shapes, off = self.backbone.fuse_memory_and_top(pre["Hp"], pre["Wp"], mem_f16, proj, self._pyramid, self._err)
         else:
             x4, Hp, Wp = ops.preprocess_image(self._device_image(frame), self.pixel_mean, self.pixel_std)
             feats, views, shapes, off = self.backbone.forward(x4, Hp, Wp, mem_f16, proj, self._pyramid, self._err)
         prop_boxes, prop_scores, prop_count = self.proposal_generator.forward(feats, shapes, off)
         if look_ahead and self.lookahead_at_start:
-            self._enqueue_trunk(next_frame, self._ev_start)
+            self._enqueue_trunk(next_frame, self._ev_start, first_ahead)
         update_mem = self.memory_type == "implicit_memory" or self.always_update_memory
         mem_sel = None
         mem_done = False
@@ -490,7 +512,7 @@ class CustomRCNNRecurrent:
             self._ev_props.record(main)
             self._mark("proposals", main)
             if look_ahead and not self.lookahead_at_start:
-                self._enqueue_trunk(next_frame, self._ev_props)
+                self._enqueue_trunk(next_frame, self._ev_props, first_ahead)
             lazy = self.lazy_proposal_masks and update_mem
             # Host enqueue order matters (the GPU runs behind the host here): first the large launches of the main stream, then
             # the side stream's ~45 small ones -- they all execute beside the two mask passes.

@@ -99,6 +99,9 @@ class DeticCascadeROIHeads:
         # the two-launch form (used by the tests as the cross-check)
         self.fuse_mask_tail = True
         self.merge_cls_bb0 = True     # False: the two linear layers as two launches (tests: bitwise the same results)
+        # classifier tail + bbox_pred.2 + apply_deltas of a stage in one launch (`eod_cascade_stage_tail`); False: three launches
+        # (bbox_pred.2 then on the matrix cores: the deltas agree to fp32 summation order, ~1e-7 relative)
+        self.fuse_stage_tail = True
         # True: the next stage's ROIAlign applies the deltas on load (EodBoxRefine: one launch less per stage, bitwise the same
         # results).  Measured in the frame (tools/knob_ab.py, same call): 287.1 frames/s against 288.6 with apply_deltas as its own
         # 5 us launch -- every one of the ROIAlign's 12 544 waves redoes the box arithmetic behind a dependent load: off.
@@ -173,6 +176,19 @@ class DeticCascadeROIHeads:
             else:
                 st["cls"](self.h2, R, 1, 1, m_count=count, m_unit=1, out=feat)
             last = k == self.num_stages - 1
+            if self.fuse_stage_tail and self.merge_cls_bb0 and not self.fold_deltas:
+                # classifier tail + bbox_pred.2 + apply_deltas as ONE launch (two launch boundaries less per stage on the cascade's
+                # chain); the last stage's launch also fuses the cascade's scores (detic_roi_heads.py:164-173)
+                ops.cascade_stage_tail(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp,
+                                       self.hb, st["bb2"], boxes, self.boxes[k + 1], self.cascade_weights[k], not last, float(W), float(H),
+                                       zs_mem=mem_rescore[0] if (k == 0 and mem_rescore is not None) else None,
+                                       prop_scores=prop_scores if (last or (k == 0 and mem_rescore is not None)) else None,
+                                       mem_scores_out=mem_rescore[1] if (k == 0 and mem_rescore is not None) else None,
+                                       final_inv_stages=1.0 / self.num_stages if last else 0.0, deltas_out=self.deltas)
+                if k == 0 and stage0_event is not None:
+                    stage0_event.record(torch.cuda.current_stream(self.device))
+                boxes = self.boxes[k + 1]
+                continue
             # the last stage's launch also fuses the cascade's scores: sqrt(mean_k(prob) * proposal score) (detic_roi_heads.py:164-173)
             ops.zs_classify(feat, st["zs"], self.prob, k > 0, self.featn0 if k == 0 else None, count, R, self.C1, self.norm_temp,
                             zs_mem=mem_rescore[0] if (k == 0 and mem_rescore is not None) else None,

@@ -87,13 +87,12 @@ class ProposalTraining:
         self.last = dict(keep=keep, head=head, shapes=shapes, off=off, saved=saved)                        # for inspection (tests)
         # targets (centernet.py:342-479) and losses (:241-318)
         heat, reg_t, pos, counts = ops.centernet_targets(gt_boxes, shapes, **self.target_cfg)
-        local = counts.cpu().tolist()                                                         # the reference's `.item()` (:264,293)
-        total = reduce_counts(counts).cpu().tolist() if reduce_counts is not None else local
+        # the reference reads the counts back (`.item()`, centernet.py:264,293); here the losses' kernel reads them on the device
+        total = reduce_counts(counts) if reduce_counts is not None else counts
         key = tuple(shapes)
         if key not in self._loss:
             self._loss[key] = ops.CenterNetLoss(off, pg.scales, dev, head_stride=32, **self.loss_cfg)
-        losses_t, d_head = self._loss[key](head, heat, reg_t, pos[:local[0]], max(total[0] / world_size, 1.0),
-                                           max(total[1] / world_size, 1.0))
+        losses_t, d_head = self._loss[key](head, heat, reg_t, pos, counts_local=counts, counts_total=total, world_size=world_size)
         losses = {"loss_centernet_loc": losses_t[0], "loss_centernet_agn_pos": losses_t[1], "loss_centernet_agn_neg": losses_t[2]}
         # ---- backward
         grads: Dict[str, tuple] = {}
@@ -187,8 +186,12 @@ class ProposalTrainer:
             add(f"backbone.map_merge_projection{i + 1}.bias", self.merge_b[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][1])
 
         self.step_fn.bb.merge_weights = self.merge_w
-        # (the gradient of the pooled memory, for which MemoryProjectorBackward keeps W^T convs, is not read by this step)
         self.after.append(lambda: bbm.merge.refresh(self.merge_w, self.merge_b))
+
+        def refresh_merge_backward():                             # the W^T convs of the pooled memory's gradient (read by tests only)
+            if self.step_fn.bb._merge_bw is not None:
+                self.step_fn.bb._merge_bw.refresh(self.merge_w)
+        self.after.append(refresh_merge_backward)
         h = "proposal_generator.centernet_head"
         for i, (conv, gamma, beta) in enumerate(pg.tower):
             w, b = plain_conv(conv, None)
@@ -205,6 +208,7 @@ class ProposalTrainer:
         def sync_out_conv():                                      # the inference path's 5-channel layer is its own object
             pg.out_conv.w.copy_(out32.w[:5])
             pg.out_conv.bias.copy_(out32.bias[:5])
+            pg.out_conv.w_split = None                               # bf16x3 pieces of the old weights, if that arithmetic was in use
         self.after.append(sync_out_conv)
         self.scales = torch.tensor(pg.scales, dtype=torch.float32, device=dev)
         add(f"{h}.scales", self.scales, lambda g: g["scales"])    # five scalar parameters `scales.{l}.scale`, stepped as one tensor
@@ -237,6 +241,7 @@ class ProposalTrainer:
                 for k, st in enumerate(rh.stages):
                     st["bb2"].w.copy_(det.bb2_32[k].w[:4])
                     st["bb2"].bias.copy_(det.bb2_32[k].bias[:4])
+                    st["bb2"].w_split = None
                     st["cls_bb0"].w[:512].copy_(st["cls"].w)
                     st["cls_bb0"].w[512:].copy_(st["bb0"].w)
                     st["cls_bb0"].bias[:512].copy_(st["cls"].bias)
@@ -332,6 +337,11 @@ class DetectorTraining:
         self.beta, self.box_w = float(rb.SMOOTH_L1_BETA), float(rb.BBOX_REG_LOSS_WEIGHT)
         self.C = self.rh.num_classes
         self.last = None
+        # optimistic assumptions about data-dependent sizes instead of host round trips in the middle of the step (see
+        # `label_and_sample`, `losses`): device-side booleans, True = the assumption did NOT hold; `ForwardModelTraining` reads them
+        # once, after the whole step has been enqueued, and repeats the frame on the exact path if one is set
+        self.speculate = False
+        self.checks: List[torch.Tensor] = []
         # bbox_pred.2 (1024 -> 4) in a 32-row tile, the weight-gradient kernel's tile width (as the proposal head's 5-channel output conv)
         self.bb2_32 = []
         for st in self.rh.stages:
@@ -342,16 +352,28 @@ class DetectorTraining:
         self._bw: Dict[int, ops.ConvBackward] = {}
 
     def label_and_sample(self, prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, keys: Optional[torch.Tensor] = None,
-                         generator: Optional[torch.Generator] = None):
-        """detic_roi_heads.py:232 -> (boxes [B,4], classes int32 [B], matched gt boxes [B,4], sampled rows int64 [B])."""
-        boxes = torch.cat([prop_boxes, gt_boxes]).contiguous() if self.append_gt else prop_boxes.contiguous()
-        _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[0], self.C)
+                         generator: Optional[torch.Generator] = None, prop_count: Optional[torch.Tensor] = None):
+        """detic_roi_heads.py:232 -> (boxes [B,4], classes int32 [B], matched gt boxes [B,4], sampled rows int64 [B]).
+
+        `prop_count` (int32 [1] on the device): `prop_boxes` is the decoder's capacity-sized list; the ground truth is appended
+        behind its live rows and the rows beyond are ignored, all on the device (`eod_match_label_proposals`).  With `speculate`
+        the number of sampled rows is not read back either: BATCH_SIZE_PER_IMAGE rows are taken (what the sampling yields whenever
+        there are that many candidates) and the assumption is filed in `self.checks` for the caller to verify after the step."""
+        if prop_count is not None:
+            boxes, cls, gtb = ops.match_label_proposals(prop_boxes, prop_count, gt_boxes, gt_classes, self.ious[0], self.C, self.append_gt)
+        else:
+            boxes = torch.cat([prop_boxes, gt_boxes]).contiguous() if self.append_gt else prop_boxes.contiguous()
+            _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[0], self.C)
         if keys is None:
             keys = torch.rand((boxes.shape[0],), device=self.dev, generator=generator)
         else:
             keys = keys[:boxes.shape[0]].contiguous()              # one key per row; a caller that cannot know R may pass more
         idx, counts = ops.sample_proposals(cls, keys, self.C, self.batch, self.frac)
-        n = int(counts.cpu()[1])                                   # the reference's nonzero() / randperm sizes
+        if self.speculate:
+            n = self.batch
+            self.checks.append(counts[1:2] != n)
+        else:
+            n = int(counts.cpu()[1])                               # the reference's nonzero() / randperm sizes
         rows = idx[:n].long()
         self.last_rows = rows
         return boxes.index_select(0, rows), cls.index_select(0, rows), gtb.index_select(0, rows), rows
@@ -371,12 +393,13 @@ class DetectorTraining:
         return dict(boxes=boxes, pool=pool, h1=h1, h2=h2, feat=feat, featn=featn, hb=hb, deltas=deltas, logits=logits)
 
     def losses(self, P: Sequence[torch.Tensor], prop_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor,
-               image_hw: Tuple[int, int], keys: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
+               image_hw: Tuple[int, int], keys: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+               prop_count: Optional[torch.Tensor] = None):
         """P: the pyramid's P3..P5 as [1,h,w,256] device tensors; prop_boxes [R,4]; gt_boxes [G,4] fp32, gt_classes int32 [G] ->
         {loss_cls_stage{k}, loss_box_reg_stage{k}, loss_mask} (device scalars) and the per-stage records (`self.last`)."""
         H, W = image_hw
         gt_boxes, gt_classes = gt_boxes.contiguous(), gt_classes.to(torch.int32).contiguous()
-        boxes, cls, gtb, _ = self.label_and_sample(prop_boxes, gt_boxes, gt_classes, keys, generator)
+        boxes, cls, gtb, _ = self.label_and_sample(prop_boxes, gt_boxes, gt_classes, keys, generator, prop_count=prop_count)
         out: Dict[str, torch.Tensor] = {}
         stages = []
         for k in range(self.rh.num_stages):
@@ -386,7 +409,11 @@ class DetectorTraining:
                 nxt = torch.empty((B0, 4), dtype=torch.float32, device=self.dev)
                 ops.apply_deltas(prev["deltas"], 4, prev["boxes"], nxt, None, B0, self.rh.cascade_weights[k - 1], True, float(W), float(H))
                 keep = (nxt[:, 2] - nxt[:, 0] > 0) & (nxt[:, 3] - nxt[:, 1] > 0)          # Boxes.nonempty (:317-319)
-                boxes = nxt if bool(keep.all()) else nxt[keep].contiguous()
+                if self.speculate:
+                    boxes = nxt                                                          # refined boxes are practically never empty
+                    self.checks.append((~keep).any().reshape(1))
+                else:
+                    boxes = nxt if bool(keep.all()) else nxt[keep].contiguous()
                 if boxes.shape[0] == 0:
                     raise RuntimeError(f"cascade stage {k}: every refined box is empty")
                 _, _, cls, gtb = ops.match_label(boxes, gt_boxes, gt_classes, self.ious[k], self.C)
@@ -457,6 +484,10 @@ class ForwardModelTraining:
         self.pre, self.post = int(c.PRE_NMS_TOPK_TRAIN), int(c.POST_NMS_TOPK_TRAIN)
         self.nms_train, self.score_thresh = float(c.NMS_TH_TRAIN), float(c.INFERENCE_TH)
         self._dec: Dict[tuple, ops.ProposalDecoder] = {}
+        self._last_props = None
+        self.speculate = True            # see forward_backward
+        self._exact_sizes = set()
+        self.repeated_frames = 0
 
     def decoder(self, shapes, head_stride: int) -> ops.ProposalDecoder:
         """One decoder per pyramid shape; the level scales are trained parameters and are patched into its descriptor after every
@@ -469,26 +500,52 @@ class ForwardModelTraining:
                                                  self.dev, head_stride=head_stride)
         return self._dec[key]
 
-    def train_proposals(self, head: torch.Tensor, shapes) -> torch.Tensor:
-        """`predict_instances` with the training thresholds on the head's raw rows [P, 32] -> proposal boxes [R,4] (detached)."""
+    def train_proposals(self, head: torch.Tensor, shapes):
+        """`predict_instances` with the training thresholds on the head's raw rows [P, 32] -> (proposal boxes [cap,4], count int32 [1]),
+        both on the device (detached; the decoder's own buffers: valid until its next call)."""
         boxes, _, count = self.decoder(shapes, int(head.shape[1]))(head)
-        return boxes[:int(count.cpu()[0])].clone()
+        return boxes, count
+
+    @property
+    def last_proposals(self) -> Optional[torch.Tensor]:
+        """The proposal list of the last `forward_backward` as [R,4] (reads the count back: for tests and reports)."""
+        if self._last_props is None:
+            return None
+        boxes, count = self._last_props
+        return boxes if count is None else boxes[:int(count.cpu()[0])]
 
     def forward_backward(self, image_u8: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, memory=None, proposals=None,
                          keys=None, generator=None, world_size: int = 1, reduce_counts=None):
         """-> (losses: the nine training losses + loss_mask, grads: every layer's (dW, db) / parameter gradient).  `proposals` [R,4]
         replaces the decoded list (tests); `keys` / `generator`: the sampling's random keys."""
         H, W = int(image_u8.shape[1]), int(image_u8.shape[2])
-        self.last_proposals = None
+        self._last_props = None
+        det = self.det
+        # No host round trip inside the step: the proposal count, the number of sampled rows and "no refined box is empty" stay on
+        # the device; the last two are ASSUMED (512 rows; none empty) and verified by ONE read-back after everything has been
+        # enqueued.  A frame on which an assumption fails is repeated on the exact path, and the optimism is switched off for its
+        # image size (small images yield fewer than BATCH_SIZE_PER_IMAGE candidates every time).
+        det.speculate = self.speculate and (H, W) not in self._exact_sizes
+        det.checks = []
 
         def roi_half(P, head, shapes, off):
-            props = proposals if proposals is not None else self.train_proposals(head, shapes)
-            self.last_proposals = props
-            losses = self.det.losses(P[:3], props, gt_boxes, gt_classes, (H, W), keys=keys, generator=generator)
-            grads, dP = self.det.backward(P[:3])
+            if proposals is not None:
+                props, count = proposals, None
+            else:
+                props, count = self.train_proposals(head, shapes)
+            self._last_props = (props.clone(), None if count is None else count.clone())
+            losses = det.losses(P[:3], props, gt_boxes, gt_classes, (H, W), keys=keys, generator=generator, prop_count=count)
+            grads, dP = det.backward(P[:3])
             return losses, grads, dP
-        return self.prop.forward_backward(image_u8, gt_boxes, memory=memory, world_size=world_size, reduce_counts=reduce_counts,
-                                          roi_half=roi_half)
+        out = self.prop.forward_backward(image_u8, gt_boxes, memory=memory, world_size=world_size, reduce_counts=reduce_counts,
+                                         roi_half=roi_half)
+        if det.speculate and det.checks and bool(torch.cat(det.checks).any().cpu()):
+            self._exact_sizes.add((H, W))
+            self.repeated_frames += 1
+            det.speculate, det.checks = False, []
+            out = self.prop.forward_backward(image_u8, gt_boxes, memory=memory, world_size=world_size, reduce_counts=reduce_counts,
+                                             roi_half=roi_half)
+        return out
 
 
 class Trainer(ProposalTrainer):

@@ -429,6 +429,25 @@ def zs_classify(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: i
     check(st, "eod_zs_classify")
 
 
+def cascade_stage_tail(feat, zs, prob_acc, accumulate: bool, featn_out, count, R_cap: int, C1: int, temp: float, hb, bb2: "Conv", boxes_in,
+                       boxes_out, weights, clip: bool, img_w: float, img_h: float, zs_mem=None, prop_scores=None, mem_scores_out=None,
+                       final_inv_stages: float = 0.0, deltas_out=None, batch: int = 1):
+    """`zs_classify` + bbox_pred.2 + apply_deltas of one cascade stage in ONE launch (`eod_cascade_stage_tail`); `bb2` is the stage's
+    1024 -> 4 layer (its packed weight rows and bias are read in place)."""
+    d = _lib.EodStageTailDesc()
+    d.feat, d.zs, d.prob_acc, d.accumulate, d.feat_norm_out, d.count = feat.data_ptr(), zs.data_ptr(), prob_acc.data_ptr(), int(accumulate), _ptr(featn_out), _ptr(count)
+    d.R_cap, d.D, d.C1, d.temp = R_cap, 512, C1, temp
+    d.zs_mem, d.prop_scores, d.mem_scores_out, d.final_inv_stages, d.batch = _ptr(zs_mem), _ptr(prop_scores), _ptr(mem_scores_out), float(final_inv_stages), batch
+    d.hb, d.w2, d.b2, d.hb_dim, d.w2_ld = hb.data_ptr(), bb2.w.data_ptr(), bb2.bias.data_ptr(), bb2.Cin, bb2.Kpad
+    d.boxes_in, d.boxes_out, d.deltas_out = boxes_in.data_ptr(), boxes_out.data_ptr(), _ptr(deltas_out)
+    d.wx, d.wy, d.ww, d.wh = weights
+    d.clip, d.img_w, d.img_h = int(clip), img_w, img_h
+    st = _lib.load().eod_cascade_stage_tail(C.byref(d), _stream())
+    if st == -5:
+        raise _lib.EodError(f"eod_cascade_stage_tail: {C1 - 1} classes exceed the classifier kernel's capacity")
+    check(st, "eod_cascade_stage_tail")
+
+
 def apply_deltas(deltas, ld: int, boxes, out, count, R_cap: int, weights, clip: bool, img_w: float, img_h: float, batch: int = 1):
     wx, wy, ww, wh = weights
     check(_lib.load().eod_apply_deltas(deltas.data_ptr(), ld, boxes.data_ptr(), out.data_ptr(), _ptr(count), R_cap, wx, wy, ww, wh,
@@ -554,7 +573,16 @@ class MemoryProjectorBackward:
         self.convs = [Conv(w.detach().to(torch.float32).reshape(256, 512).t().contiguous().reshape(512, 256, 1, 1), None, device=device,
                            name=f"map_merge_projection{i + 1}^T") for i, w in enumerate(weights)]
 
-    def __call__(self, grads: Sequence[torch.Tensor], pooled_f16: torch.Tensor, H: int, W: int, weight: float):
+    def refresh(self, weights: Sequence[torch.Tensor]) -> None:
+        """After an optimizer step on the projections: the W^T convs of the input gradient follow the stepped weights."""
+        for c, w in zip(self.convs, weights):
+            c.w[:, :256].copy_(w.detach().reshape(256, 512).t())
+            c.w_split = None
+
+    def __call__(self, grads: Sequence[torch.Tensor], pooled_f16: torch.Tensor, H: int, W: int, weight: float,
+                 need_input_grad: bool = True):
+        """`need_input_grad=False`: only dW / db (the training step: the memory table is an input of `forward_model`, loader.py:199-223,
+        nothing reads the gradient below the pooled operand -- three dgrad convs and the pool backward, ~50 MB of writes, stay out)."""
         _need_cuda(pooled_f16, *grads)
         dev = self.device
         rows = [(H >> (3 + l)) * (W >> (3 + l)) for l in range(3)]
@@ -566,6 +594,8 @@ class MemoryProjectorBackward:
                                                            pooled_f16.data_ptr(), H, W, float(weight), dW[0].data_ptr(), db[0].data_ptr(),
                                                            dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), _stream()),
               "eod_memory_project_backward_weights")
+        if not need_input_grad:
+            return dict(dW=dW, db=db)
         dec = [self.convs[l](grads[l].view(1, H >> (3 + l), W >> (3 + l), 256), 1, H >> (3 + l), W >> (3 + l), out_scale=float(weight))
                .view(rows[l], 512) for l in range(3)]
         gE = [torch.empty((rows[l], 512), dtype=torch.float16, device=dev) for l in range(3)]
@@ -713,8 +743,12 @@ class CenterNetLoss:
         self.desc = d
 
     def __call__(self, head_out: torch.Tensor, agn_heatmap: torch.Tensor, reg_targets: torch.Tensor, pos_inds: torch.Tensor,
-                 num_pos_avg: float, reg_norm: float, out: Optional[torch.Tensor] = None):
-        _need_cuda(head_out, agn_heatmap, reg_targets, pos_inds, out)
+                 num_pos_avg: float = 1.0, reg_norm: float = 1.0, out: Optional[torch.Tensor] = None, counts_local: Optional[torch.Tensor] = None,
+                 counts_total: Optional[torch.Tensor] = None, world_size: int = 1):
+        """`counts_local` / `counts_total` (int32 [2] on the device: `centernet_targets`' counts, the second all-reduced over the
+        ranks): the positives' list length and the two normalisers are read on the device -- `pos_inds` is then the capacity-sized
+        list and `num_pos_avg` / `reg_norm` are not used; no host round trip between the target assignment and the losses."""
+        _need_cuda(head_out, agn_heatmap, reg_targets, pos_inds, out, counts_local, counts_total)
         d = self.desc
         assert tuple(head_out.shape) == (d.P, d.head_stride) and head_out.is_contiguous() and pos_inds.dtype == torch.int32
         assert tuple(reg_targets.shape) == (d.P, 4) and reg_targets.is_contiguous() and agn_heatmap.numel() == d.P
@@ -723,6 +757,7 @@ class CenterNetLoss:
         d.head_out, d.agn_heatmap, d.reg_targets = head_out.data_ptr(), agn_heatmap.data_ptr(), reg_targets.data_ptr()
         d.pos_inds, d.n_pos = (pos_inds.data_ptr() if pos_inds.numel() else None), pos_inds.numel()
         d.num_pos_avg, d.reg_norm, d.d_head_out = float(num_pos_avg), float(reg_norm), out.data_ptr()
+        d.counts_local, d.counts_total, d.world_size = _ptr(counts_local), _ptr(counts_total), float(world_size)
         check(self.lib.eod_centernet_loss(C.byref(d), _stream()), "eod_centernet_loss")
         return self.losses, out
 
@@ -764,6 +799,29 @@ def match_label(boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.T
                                       float(iou_thresh), num_classes, midx.data_ptr(), miou.data_ptr(), cls.data_ptr(), gtb.data_ptr(),
                                       _stream()), "eod_match_label")
     return midx, miou, cls, gtb
+
+
+def match_label_proposals(prop_boxes: torch.Tensor, prop_count: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor,
+                          iou_thresh: float, num_classes: int, append_gt: bool = True):
+    """`match_label` on a capacity-sized proposal list whose length is on the device, the ground truth appended behind the live rows
+    (detectron2's add_ground_truth_to_proposals) -> (all_boxes [cap + G, 4], classes int32 [cap + G] with -1 = no row, matched gt
+    boxes): nothing is read back."""
+    _need_cuda(prop_boxes, prop_count, gt_boxes, gt_classes)
+    cap, G = int(prop_boxes.shape[0]), int(gt_boxes.shape[0])
+    assert prop_boxes.is_contiguous() and prop_boxes.dtype == torch.float32 and prop_count.dtype == torch.int32
+    assert gt_boxes.is_contiguous() and gt_boxes.dtype == torch.float32 and gt_classes.dtype == torch.int32 and gt_classes.numel() == G
+    dev = prop_boxes.device
+    R = cap + (G if append_gt else 0)
+    allb = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    midx = torch.empty((R,), dtype=torch.int32, device=dev)
+    miou = torch.empty((R,), dtype=torch.float32, device=dev)
+    cls = torch.empty((R,), dtype=torch.int32, device=dev)
+    gtb = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    check(_lib.load().eod_match_label_proposals(prop_boxes.data_ptr(), prop_count.data_ptr(), cap, gt_boxes.data_ptr() if G else None,
+                                                gt_classes.data_ptr() if G else None, G, int(append_gt), float(iou_thresh), num_classes,
+                                                allb.data_ptr(), midx.data_ptr(), miou.data_ptr(), cls.data_ptr(), gtb.data_ptr(), _stream()),
+          "eod_match_label_proposals")
+    return allb, cls, gtb
 
 
 def sample_proposals(classes: torch.Tensor, keys: torch.Tensor, num_classes: int, batch_size_per_image: int, positive_fraction: float):
@@ -822,6 +880,10 @@ class AdamW:
         self.state = [(torch.zeros_like(g["param"]), torch.zeros_like(g["param"])) for g in groups]
         self.steps = [0] * len(groups)
         self.lib = _lib.load()
+        # all tensors in ceil(n / 24) launches (`eod_adamw_step_multi`); False: one `eod_adamw_step` launch per tensor (the same
+        # arithmetic element for element: tests/test_backward_gpu.py compares the two)
+        self.multi_tensor = True
+        self._descs = (_lib.EodAdamWTensor * max(len(groups), 1))()
 
     def state_dict(self) -> Dict:
         """{parameter name: {'step', 'exp_avg', 'exp_avg_sq'}} on the host -- what DetectionCheckpointer stores for the optimizer
@@ -843,6 +905,24 @@ class AdamW:
 
     def step(self, grads: Sequence[Optional[torch.Tensor]], lr_factor: float = 1.0):
         """`grads[i]`: gradient of group i's tensor (None: no gradient this iteration, the tensor is skipped as torch does)."""
+        if self.multi_tensor:
+            n = 0
+            for i, (g, grad) in enumerate(zip(self.groups, grads)):
+                if grad is None:
+                    continue
+                p = g["param"]
+                _need_cuda(p, grad)
+                assert p.dtype == torch.float32 and grad.dtype == torch.float32 and p.is_contiguous() and grad.is_contiguous()
+                assert grad.shape == p.shape
+                self.steps[i] += 1
+                d = self._descs[n]
+                d.param, d.grad, d.exp_avg, d.exp_avg_sq = p.data_ptr(), grad.data_ptr(), self.state[i][0].data_ptr(), self.state[i][1].data_ptr()
+                d.n, d.lr, d.weight_decay, d.step = p.numel(), g["lr"] * lr_factor, g.get("weight_decay", self.weight_decay), self.steps[i]
+                n += 1
+            if n:
+                check(self.lib.eod_adamw_step_multi(self._descs, n, self.betas[0], self.betas[1], self.eps, self.clip_value, _stream()),
+                      "eod_adamw_step_multi")
+            return
         for i, (g, grad) in enumerate(zip(self.groups, grads)):
             if grad is None:
                 continue

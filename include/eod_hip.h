@@ -211,6 +211,13 @@ typedef struct EodCenterNetLossDesc {
   float pos_weight, neg_weight, reg_weight;                                          /* 0.5, 0.5, 1 in the recurrent yaml */
   float num_pos_avg;          /* max(all-reduced n_pos / world size, 1)  (centernet.py:259-265) */
   float reg_norm;             /* max(all-reduced number of regression rows / world size, 1)  (centernet.py:288-293) */
+  /* Or the counts straight from device memory (no host round trip behind eod_centernet_targets): counts_total != NULL replaces
+   * num_pos_avg / reg_norm by max(counts_total[0] / world_size, 1) and max(counts_total[1] / world_size, 1) -- counts_total =
+   * eod_centernet_targets' `counts`, all-reduced over the ranks -- and n_pos becomes the CAPACITY of pos_inds, of which
+   * counts_local[0] entries are read. */
+  const int32_t* counts_local;
+  const int32_t* counts_total;
+  float world_size;
   float* d_head_out;          /* [P, head_stride] dL/d(head_out) of loss_centernet_loc + _agn_pos + _agn_neg; every column written */
   float* losses;              /* [3]: loss_centernet_loc, loss_centernet_agn_pos, loss_centernet_agn_neg */
   void* workspace;
@@ -259,6 +266,14 @@ int eod_fast_rcnn_loss(const float* scores, int ld, const float* deltas /*[B,4]*
 int eod_match_label(const float* boxes /*[R,4]*/, int R, const float* gt_boxes /*[G,4]*/, const int32_t* gt_classes /*[G]*/, int G,
                     float iou_thresh, int num_classes, int32_t* matched_idx /*[R]*/, float* matched_iou /*[R]*/,
                     int32_t* out_classes /*[R]*/, float* out_gt_boxes /*[R,4]*/, eod_stream_t stream);
+/* The same for a capacity-sized proposal list whose length lives on the device (eod_centernet_proposals' out_count), with
+ * detectron2's add_ground_truth_to_proposals folded in (PROPOSAL_APPEND_GT): of the R = cap + (append_gt ? G : 0) rows, row i is
+ * proposal i for i < min(*prop_count, cap), ground-truth box i - count for the next G rows, and no row beyond (out_classes -1:
+ * eod_sample_proposals ignores it).  all_boxes [R,4] receives the rows' boxes (zeros where there is none). */
+int eod_match_label_proposals(const float* prop_boxes /*[cap,4]*/, const int32_t* prop_count /*[1], device*/, int cap,
+                              const float* gt_boxes /*[G,4]*/, const int32_t* gt_classes /*[G]*/, int G, int append_gt, float iou_thresh,
+                              int num_classes, float* all_boxes, int32_t* matched_idx, float* matched_iou, int32_t* out_classes,
+                              float* out_gt_boxes, eod_stream_t stream);
 /* eod_sample_proposals: detectron2's subsample_labels (through label_and_sample_proposals, detic_roi_heads.py:232) as a selection by
  * random keys: the min(int(batch * positive_fraction), #foreground) foreground rows and the min(batch - that, #background) background
  * rows with the smallest (key, row); classes [R] as eod_match_label writes them (-1 = ignored).  sampled_idx [batch]: foreground rows
@@ -312,6 +327,36 @@ int eod_centernet_proposals(const EodProposalDesc* d, eod_stream_t stream);
  *     (inference_with_proposals, custom_rcnn.py:838-861) -- what eod_memory_scores computes from feat_norm_out;
  *   final_inv_stages > 0 (last cascade stage, with prop_scores): prob_acc = sqrt(prob_acc * final_inv_stages * prop_score)
  *     (detic_roi_heads.py:164-173) -- what eod_cascade_scores does in place. */
+/* eod_zs_classify + the rest of the stage's predictor in the SAME launch: bbox_pred.2 (Linear hb_dim -> 4 on `hb`, the ReLU'd
+ * bbox_pred.0 output; detic_fast_rcnn.py:109-116) and Box2BoxTransform.apply_deltas onto the stage's boxes with the stage's
+ * weights, clipped to the image when `clip` (detic_roi_heads.py:121-122,314): three launches of the cascade's chain become one.
+ * Every field up to `batch` means what the argument of the same name means in eod_zs_classify. */
+typedef struct EodStageTailDesc {
+  const float* feat;
+  const float* zs;
+  float* prob_acc;
+  int32_t accumulate;
+  float* feat_norm_out;
+  const int32_t* count;
+  int32_t R_cap, D, C1;
+  float temp;
+  const float* zs_mem;
+  const float* prop_scores;
+  float* mem_scores_out;
+  float final_inv_stages;
+  int32_t batch;
+  const float* hb;         /* [R, hb_dim] */
+  const float* w2;         /* [4][w2_ld]: bbox_pred.2 weight rows (w2_ld >= hb_dim, the packed conv layout) */
+  const float* b2;         /* [4] */
+  int32_t hb_dim, w2_ld;
+  const float* boxes_in;   /* [R,4] the stage's boxes */
+  float* boxes_out;        /* [R,4] refined boxes */
+  float* deltas_out;       /* [R,4] or NULL */
+  float wx, wy, ww, wh;    /* Box2BoxTransform weights of the stage */
+  int32_t clip;
+  float img_w, img_h;
+} EodStageTailDesc;
+int eod_cascade_stage_tail(const EodStageTailDesc* d, eod_stream_t stream);
 int eod_zs_classify(const float* feat /*[R,512]*/, const float* zs /*[512,C1]*/, float* prob_acc /*[R,C1]*/, int accumulate,
                     float* feat_norm_out /*[R,512] or NULL*/, const int32_t* count, int R_cap, int D, int C1, float temp,
                     const float* zs_mem, const float* prop_scores, float* mem_scores_out, float final_inv_stages, int batch,
@@ -465,6 +510,22 @@ int eod_relu_backward(const float* g, const float* y, float* out, size_t n, eod_
  * 1-based update count of this tensor; exp_avg / exp_avg_sq are its state, zero before the first step.  In place, elementwise. */
 int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, double clip_value, eod_stream_t stream);
+
+/* The same update for `count` parameter tensors in ceil(count / 24) launches (the training step of the recurrent detector has 126):
+ * tensors[i] carries its own lr (BASE_LR x multipliers x the schedule's factor), weight decay and 1-based update count.  Element
+ * for element the arithmetic of eod_adamw_step.  `tensors` is a HOST array, read before the call returns. */
+typedef struct EodAdamWTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  size_t n;
+  double lr;
+  double weight_decay;
+  int32_t step;
+} EodAdamWTensor;
+int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
+                         eod_stream_t stream);
 
 /* a16-a19 write path (custom_rcnn.py:681-760,875-936) */
 typedef struct EodMemWriteDesc {

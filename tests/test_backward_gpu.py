@@ -788,7 +788,7 @@ def test_proposal_trainer_steps_like_torch_and_reduces_the_loss(synthetic_sd):
     dev = torch.device("cuda:0")
     lr = 2e-5
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "SOLVER.BASE_LR", lr])
+                           "SOLVER.BASE_LR", lr, "FP16", False])
     sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
     model = build_model(cfg, sd0)
     trainer = ProposalTrainer(model, sd0)

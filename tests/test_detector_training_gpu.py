@@ -43,6 +43,35 @@ def test_match_label_bit_exact(n_gt, n_rand, thr):
         assert int((rcls < 20).sum()) >= n_gt // 2 and int((rcls == 20).sum()) > 0      # both kinds present
 
 
+@pytest.mark.parametrize("n_gt,cap,count,append", [(24, 2048, 1987, True), (24, 2048, 2048, True), (300, 512, 0, True), (7, 320, 100, False),
+                                                   (0, 256, 200, True)])
+def test_match_label_proposals_with_the_count_on_the_device(n_gt, cap, count, append):
+    """`eod_match_label_proposals`: the decoder's capacity-sized proposal list + its device-side count, ground truth appended behind
+    the live rows (add_ground_truth_to_proposals) -- the rows of cat([proposals[:count], gt]) bit for bit as `eod_match_label` /
+    the oracle label them, every row beyond marked -1 (ignored by the sampling) with a zero box."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + n_gt + cap)
+    gt, props = _boxes(g, n_gt, cap)
+    props = props[:cap].contiguous()
+    gc = torch.randint(0, 20, (n_gt,), generator=g)
+    stale = props.clone()
+    stale[count:] = torch.rand((cap - count, 4), generator=g) * 1e3           # whatever an earlier, longer list left behind
+    allb, cls, gtb = ops.match_label_proposals(stale.to(dev), torch.tensor([count], dtype=torch.int32, device=dev), gt.to(dev), gc.int().to(dev),
+                                               0.6, 20, append_gt=append)
+    live = torch.cat([props[:count], gt]) if append else props[:count]
+    R = cap + (n_gt if append else 0)
+    assert tuple(allb.shape) == (R, 4) and tuple(cls.shape) == (R,)
+    n = live.shape[0]
+    assert torch.equal(allb[:n].cpu(), live) and not bool(allb[n:].any())
+    if n:
+        _, _, rcls, rgtb = OL.match_label(live, gt, gc, 0.6, 20)
+        assert torch.equal(cls[:n].cpu().long(), rcls) and torch.equal(gtb[:n].cpu(), rgtb)
+    assert bool((cls[n:] == -1).all())
+    if append and n_gt:
+        assert bool((cls[count:count + n_gt].cpu().long() == gc).all())          # a ground-truth box matches itself (IoU 1)
+
+
 @pytest.mark.parametrize("R,n_fg,batch,ties", [(2300, 400, 512, False), (2300, 40, 512, True), (300, 10, 512, False), (8192, 3000, 512, True),
                                                (64, 0, 16, False)])
 def test_sample_proposals_matches_oracle(R, n_fg, batch, ties):
@@ -221,7 +250,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     dev = torch.device("cuda:0")
     lr = 2e-5
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "SOLVER.BASE_LR", lr])
+                           "SOLVER.BASE_LR", lr, "FP16", False])
     sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
     model = build_model(cfg, sd0)
     trainer = Trainer(model, sd0)
@@ -240,6 +269,9 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
     fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, generator=torch.Generator(device=dev).manual_seed(1))
     props = fm.last_proposals.cpu()
     assert 16 <= props.shape[0] <= 2000 and bool((props[:, 2] >= props[:, 0]).all())
+    # fewer than BATCH_SIZE_PER_IMAGE candidates on this small image: the optimistic row count failed its check, the frame was
+    # repeated on the exact path and the size is remembered
+    assert fm.repeated_frames == 1 and (H, W) in fm._exact_sizes
     keys = torch.rand((props.shape[0] + gt.shape[0],), generator=g)
     losses, grads = fm.forward_backward(img.to(dev), gt.to(dev), gc.int().to(dev), memory=mem, proposals=props.to(dev), keys=keys.to(dev))
     torch.cuda.synchronize()
@@ -307,13 +339,14 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
     """`forward_model` at 640x640 on the reference's training configuration, each side on its OWN data-dependent choices: the oracle
     decodes its own train-mode proposals from its own head outputs (PRE / POST_NMS_TOPK_TRAIN 4000 / 2000, NMS 0.9:
     centernet.py:214-219,603-745) and draws its own 512-row sample from the shared random keys (detic_roi_heads.py:232); nothing is
-    handed from one side to the other but the image, the memory, the ground truth and the keys.  Asserted: the proposal list (count,
-    order, boxes to 1e-3 px), the sampled rows and their classes bit-exact, the ten losses to 3e-4 relative, probe gradients in L2."""
+    handed from one side to the other but the image, the memory, the ground truth and the keys (a key belongs to a box: where two
+    scores agree to fp32 rounding the two lists hold the same boxes in another order).  Asserted: the proposal set (count, every box
+    to 1e-3 px, one to one), the sampled rows as a set and every stage's classes, the ten losses to 3e-4 relative, probe gradients in L2."""
     from embodied_object_detection_amd import build_model, setup_cfg
     from embodied_object_detection_amd.modeling.training import Trainer
     dev = torch.device("cuda:0")
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "SOLVER.BASE_LR", 2e-5])
+                           "SOLVER.BASE_LR", 2e-5, "FP16", False])
     sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
     model = build_model(cfg, sd0)
     trainer = Trainer(model, sd0)
@@ -342,23 +375,40 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
     agn, reg = M.centernet_head(feats, sd)
     with torch.no_grad():
         oprops, oscores = M.centernet_proposals([a.detach() for a in agn], [r.detach() for r in reg], tcfg)
+    # the same proposal SET: every one of the oracle's >= 2000 boxes is in the HIP list to 1e-3 px, one to one.  The ORDER may differ
+    # where two scores agree to fp32 rounding (the two heads' outputs differ by summation order, ~1e-6 relative): `perm` maps an
+    # oracle row to the HIP row that holds its box
     assert props.shape == oprops.shape and props.shape[0] >= 2000, (props.shape, oprops.shape)
-    assert float((props - oprops).abs().max()) <= 1e-3, float((props - oprops).abs().max())
+    dist = (oprops[:, None, :] - props[None, :, :]).abs().amax(dim=2)
+    near, perm = dist.min(dim=1)
+    assert float(near.max()) <= 1e-3, float(near.max())
+    assert perm.unique().numel() == perm.numel()
+    swapped = int((perm != torch.arange(perm.numel())).sum())
+    assert swapped <= 0.02 * perm.numel(), swapped
+    # the random keys belong to the BOXES: the oracle's row r draws the key the HIP side gave that box (its row perm[r]); the
+    # appended ground truth keeps its place behind the list
+    n = props.shape[0]
+    okeys = keys.clone()
+    okeys[:n] = keys[perm]
     shapes = [(f.shape[2], f.shape[3]) for f in feats]
     pos, reg_t, heat = OL.centernet_targets(gt, shapes)
     ref = OL.centernet_proposal_losses(torch.cat([a.permute(0, 2, 3, 1).reshape(-1) for a in agn]),
                                        torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg]), heat, reg_t, pos)
-    rdet, rstages = OL.cascade_training_losses(feats[:3], oprops, gt, gc, sd, ocfg, (H, W), keys)
+    rdet, rstages = OL.cascade_training_losses(feats[:3], oprops, gt, gc, sd, ocfg, (H, W), okeys)
     ref.update(rdet)
     sum(ref.values()).backward()
-    # the sample: 512 rows of ~2000 + 24, a quarter foreground at most -- really sub-sampled, unlike a 448-row list
+    # the sample: 512 rows of ~2000 + 24, a quarter foreground at most -- really sub-sampled, unlike a 448-row list; the same BOXES on
+    # both sides, bit for bit as sets of rows
     rows = fm.det.last_rows.cpu()
-    assert rows.shape[0] == 512 and torch.equal(rows, rstages[0]["rows"])
+    orows = rstages[0]["rows"]
+    mapped = torch.where(orows < n, perm[orows.clamp(max=n - 1)], orows)
+    assert rows.shape[0] == 512 and torch.equal(rows.sort().values, mapped.sort().values)
+    assert fm.repeated_frames == 0 and fm.det.speculate          # 512 rows sampled, no empty refined box: no host round trip was needed
     n_fg = int((rstages[0]["classes"] != 20).sum())
     assert 24 <= n_fg <= 128, n_fg
     for k in range(3):
         assert fm.det.last[k]["boxes"].shape[0] == rstages[k]["boxes"].shape[0]
-        assert torch.equal(fm.det.last[k]["classes"].cpu().long(), rstages[k]["classes"]), k
+        assert torch.equal(fm.det.last[k]["classes"].cpu().long().sort().values, rstages[k]["classes"].sort().values), k
     assert set(losses) == set(ref) and len(ref) == 10
     for name, v in ref.items():
         assert abs(float(losses[name]) - float(v.detach())) <= 3e-4 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))
@@ -383,8 +433,8 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
         l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
         worst = max(worst, l2)
         assert l2 <= 5e-3, (name, l2)
-    print("640x640 training parity: %d proposals, %d sampled rows (%d foreground), worst probe gradient L2 %.2e" %
-          (props.shape[0], rows.shape[0], n_fg, worst))
+    print("640x640 training parity: %d proposals (%d in another order than the oracle's), %d sampled rows (%d foreground), worst probe "
+          "gradient L2 %.2e" % (props.shape[0], swapped, rows.shape[0], n_fg, worst))
 
 
 def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
@@ -397,7 +447,7 @@ def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
     from embodied_object_detection_amd.structures import Boxes, Instances
     dev = torch.device("cuda:0")
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "SOLVER.BASE_LR", 2e-5])
+                           "SOLVER.BASE_LR", 2e-5, "FP16", False])
     sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
     model = build_model(cfg, sd0)
     model.train()

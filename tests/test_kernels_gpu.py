@@ -541,8 +541,11 @@ def test_centernet_train_proposals_match_oracle(dev, hw, nms, variant, golden_di
     cfg = M.OracleCfg(pre_nms_topk=pre, post_nms_topk=post, nms_th_proposal=nms)
     rb, rs = M.centernet_proposals(agn, [F.relu(r * s) for r, s in zip(reg, scales)], cfg)
     if variant == "golden":
-        np.testing.assert_array_equal(rs.numpy(), gd["scores"])
-        np.testing.assert_array_equal(rb.numpy(), gd["boxes"])
+        # bit for bit on the CPU that wrote the fixture (tests/test_oracle_golden.py); this host's sigmoid / sqrt may differ by an ulp,
+        # which can exchange two neighbours of the list: the same scores, and every box of the fixture in the list
+        np.testing.assert_allclose(rs.numpy(), gd["scores"], rtol=2e-7, atol=0)
+        gb = torch.from_numpy(gd["boxes"])
+        assert float((gb[:, None, :] - rb[None, :, :]).abs().amax(dim=2).min(dim=1).values.max()) <= 1e-4
     head = torch.cat([torch.cat([nhwc(a).reshape(-1, 1), nhwc(r).reshape(-1, 4)], dim=1) for a, r in zip(agn, reg)]).contiguous()
     cap = 4096 if variant == "ties" else post + 48
     dec = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, scales, cfg.inference_th, pre, post, nms, cap=cap, device=dev)
@@ -554,6 +557,9 @@ def test_centernet_train_proposals_match_oracle(dev, hw, nms, variant, golden_di
         # the order among EQUAL scores: position order in both, so the lists still agree entry by entry
         assert n > post + 48
     close(s[:n], rs, rtol=1e-6, atol=1e-6)
+    if variant == "golden":
+        # against the reference's own list, as sets (see above)
+        assert float((gb[:, None, :] - b[:n].cpu()[None, :, :]).abs().amax(dim=2).min(dim=1).values.max()) <= 1e-4
     close(b[:n], rb, rtol=1e-5, atol=1e-4)
     # a second call on the same decoder (workspace reuse) gives the same list
     b2, s2, c2 = dec(head.to(dev))

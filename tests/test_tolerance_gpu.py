@@ -9,7 +9,8 @@ gpurun_out/parity_report_<size>.json so that DESIGN.md quotes numbers, not bound
 
 Memory write (tests/_write_parity.py): (1) fed the HIP frame's OWN pasted masks, features and rows, the oracle's write must
 reproduce the HIP state: cell set bit-exact, every cell to 1e-5 relative; (2) every pasted-mask pixel on which the HIP frame and
-the oracle frame disagree must lie within 1e-5 of the 0.5 threshold in the oracle's own sample; (3) when no pixel differs, the HIP
+the oracle frame disagree must lie closer to the 0.5 threshold (in the oracle's own sample) than the two sides' pasted probabilities
+of that instance differ -- a band MEASURED per instance, itself asserted <= 5e-5 (the 28x28 probabilities: <= 1e-5); (3) when no pixel differs, the HIP
 state must equal the oracle's state (cell set bit-exact, 1e-5 relative).  Together: any difference between the two memories after
 a frame is attributed to counted knife-edge mask decisions, never to the write kernels."""
 import json
@@ -27,7 +28,8 @@ from oracle import ops as OO
 import _write_parity as WP
 
 TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 on box coords/scores"
-CASES = [(128, 160, 24, 3), (480, 640, 60, 2), (640, 640, 200, 2)]
+# (H, W, memory grid side, frames, sequence seed): 640x640 on two sequences, four frames each
+CASES = [(128, 160, 24, 3, 3), (480, 640, 60, 2, 3), (640, 640, 200, 4, 3), (640, 640, 200, 4, 11)]
 
 
 def _cfg():
@@ -56,22 +58,21 @@ def compare(ref, out):
 _RUNS = {}
 
 
-def _run(synthetic_sd, H, W, grid, n_frames):
+def _run(synthetic_sd, H, W, grid, n_frames, seed=3):
     """One pass over the case (HIP teacher-forced + HIP free-running + oracle), shared by the tests of this module.
 
     "On identical frames" includes the recurrent state: before every frame the HIP model's memory is set to the oracle's (teacher
     forcing), so each frame measures ONE pass of the path."""
-    key = (H, W, grid, n_frames)
+    key = (H, W, grid, n_frames, seed)
     if key in _RUNS:
         return _RUNS[key]
     from embodied_object_detection_amd import build_model
     from embodied_object_detection_amd.data.synthetic import SyntheticSequence
-    seq = SyntheticSequence(3, H=H, W=W, n_frames=n_frames, map_w=grid, map_h=grid, cell=0.5 if grid < 200 else 0.2)
+    seq = SyntheticSequence(seed, H=H, W=W, n_frames=n_frames, map_w=grid, map_h=grid, cell=0.5 if grid < 200 else 0.2)
     frames = [seq.frame(i) for i in range(n_frames)]
     model = build_model(_cfg(), synthetic_sd)
     free = build_model(_cfg(), synthetic_sd)
     oracle = OM.RecurrentOracle(synthetic_sd, M.OracleCfg(memory_cls_score_thresh=0.3, map_feature_weight=5.0))
-    free_outs = free([frames])                                 # one episode through the boundary, free running
     n_cells = int(frames[0]["memory"].shape[0])
     report = []
     for i, f in enumerate(frames):
@@ -98,11 +99,13 @@ def _run(synthetic_sd, H, W, grid, n_frames):
         ev = w.pop("evidence")
         r["write_vs_oracle_on_hip_masks"] = w
         r["mask_flips"] = WP.mask_flip_attribution(ev, oracle.last, H, W)
-        r["free_running"] = compare(ref, free_outs[i]["instances"])
+        # the second model runs FREE (its own recurrent state, never re-synchronised), frame by frame through the boundary
+        r["free_running"] = compare(ref, free([[g]])[0]["instances"])
+        r["free_running"]["mask_pixels_differing"] = WP.count_mask_differences(WP.hip_write_inputs(free, H, W), oracle.last)
         report.append(r)
-        print(f"[parity {H}x{W} frame {i}] {r}")
+        print(f"[parity {H}x{W} seq {seed} frame {i}] {r}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"parity_report_{H}x{W}.json"), "w") as fh:
+    with open(os.path.join("gpurun_out", f"parity_report_{H}x{W}_seq{seed}.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     _RUNS[key] = report
     del model, free
@@ -110,27 +113,39 @@ def _run(synthetic_sd, H, W, grid, n_frames):
     return report
 
 
-@pytest.mark.parametrize("H,W,grid,n_frames", CASES)
-def test_absolute_tolerance_through_the_boundary(synthetic_sd, H, W, grid, n_frames):
-    for r in _run(synthetic_sd, H, W, grid, n_frames):
+@pytest.mark.parametrize("H,W,grid,n_frames,seed", CASES)
+def test_absolute_tolerance_through_the_boundary(synthetic_sd, H, W, grid, n_frames, seed):
+    report = _run(synthetic_sd, H, W, grid, n_frames, seed)
+    for r in report:
         assert r["observations_exact"], r
         assert r["matched"] >= 0.98 * r["n_ref"] and abs(r["n_ref"] - r["n_got"]) <= max(3, 0.02 * r["n_ref"]), r
         assert r["max_abs_dscore"] < TOL, r
         assert r["max_abs_dbox_px"] < TOL, r
+    # FREE-RUNNING (no teacher forcing): until a mask pixel has flipped, the HIP model's own state is the oracle's to fp32 rounding
+    # and its detections must stay inside the bound of a frame that starts from its own state (5e-3 px / 1e-4; test_model_gpu.py);
+    # the frame in which the first flip happens is still such a frame (the flip only changes what is WRITTEN)
+    first_flip = next((i for i, r in enumerate(report) if r["free_running"]["mask_pixels_differing"]), len(report) - 1)
+    for r in report[:first_flip + 1]:
+        fr = r["free_running"]
+        assert fr["matched"] >= 0.98 * fr["n_ref"], r
+        assert fr["max_abs_dbox_px"] < 5e-3 and fr["max_abs_dscore"] < 1e-4, r
 
 
-@pytest.mark.parametrize("H,W,grid,n_frames", CASES)
-def test_memory_write_values_and_cell_set_at_full_size(synthetic_sd, H, W, grid, n_frames):
+@pytest.mark.parametrize("H,W,grid,n_frames,seed", CASES)
+def test_memory_write_values_and_cell_set_at_full_size(synthetic_sd, H, W, grid, n_frames, seed):
     """custom_rcnn.py:884-936 at BASELINE sizes: the written VALUES (not only the counters) of every frame."""
-    for r in _run(synthetic_sd, H, W, grid, n_frames):
+    for r in _run(synthetic_sd, H, W, grid, n_frames, seed):
         w, fl = r["write_vs_oracle_on_hip_masks"], r["mask_flips"]
         # (1) the write kernels, on the frame's own instances
         assert w["K"] > 0, r
         assert w["cell_set_exact"], r
         assert w["cells_over_tol"] == 0 and w["max_rel_err"] <= 1e-5, r
         assert w["observations_exact"], r
-        # (2) every mask pixel decided differently is a knife-edge of the 0.5 threshold
-        assert fl["flips_outside_band"] == 0, r
+        # (2) every mask pixel decided differently is a knife-edge of the 0.5 threshold: closer to it than the two sides' pasted
+        # probabilities of that instance differ (per instance and, sharper, at the pixel itself); and that measured difference is
+        # itself small -- both sides start every frame of this run from one state
+        assert fl["flips_outside_band"] == 0 and fl["flips_outside_pixel_band"] == 0, r
+        assert fl["max_band"] <= WP.BAND_CAP_IDENTICAL_STATE and fl["max_m28_diff"] <= WP.MASK28_DIFF_CAP, r
         # (3) no flip and the same instances -> the same memory
         if fl["masks_identical"]:
             assert r["written_cells_identical"], r

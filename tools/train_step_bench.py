@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args()
     H, W = a.size
     dev = torch.device("cuda:0")
-    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5])
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False])
     sd = synthetic_state_dict(0)
     model = build_model(cfg, sd)
     trainer = Trainer(model, sd) if a.roi_heads else ProposalTrainer(model, sd)

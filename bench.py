@@ -101,11 +101,14 @@ def available_cores() -> int:
 
 
 def _profile_json(name):
-    """The newest committed summary of that name (profiles/r03_*.json, else r02_*.json)."""
-    for rnd in ("r03", "r02"):
+    """The newest committed summary of that name (profiles/r04_*.json, else r03_*, r02_*), with the file it came from."""
+    for rnd in ("r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as fh:
-                return json.load(fh)
+                d = json.load(fh)
+            if isinstance(d, dict):
+                d.setdefault("_file", f"profiles/{rnd}_{name}.json")
+            return d
         except (OSError, ValueError):
             continue
     return None
@@ -113,7 +116,7 @@ def _profile_json(name):
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate passes: profiles/r03_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
+    WRITE_SIZE, separate passes: profiles/r04_dominant_kernel_traffic.json).  PMC counters cannot be read live from here."""
     d = _profile_json("dominant_kernel_traffic")
     try:
         return round(float(d["traffic_bytes_per_launch"]), 1)
@@ -550,7 +553,10 @@ def main():
     headline_math = ops.get_conv_math()          # "fp32" unless EOD_CONV_MATH=bf16x3 is exported
     # one frame more than is processed: in the enqueue-only variant the model starts the NEXT frame's memory-independent
     # bottom-up pass during a step, so the last timed step needs a next frame for the region to hold exactly `steps` trunks
-    n_frames = args.steps + args.warmup + 1
+    # (the look-ahead window reaches up to four frames beyond the current one: with four spare frames its fill is the same at
+    # both ends of the timed region, which then holds the trunks of exactly `steps` frames)
+    n_proc = args.steps + args.warmup
+    n_frames = n_proc + 4
     seq = SyntheticSequence(rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell,
                             projector=None)
     host_frames = [seq.frame(i) for i in range(n_frames)]
@@ -587,7 +593,7 @@ def main():
             if fr[i]["memory_reset"]:
                 model.reset_memory(seq.n_cells)      # custom_rcnn.py:470-479
             model.inference_frame(fr[i], refresh_memory_snapshot=True, materialize=False,
-                                  next_frame=fr[i + 1] if i + 1 < n_frames else None)
+                                  next_frame=fr[i + 1:i + 5] or None)          # the look-ahead window sees the frames that follow
         return hi - lo
 
     def timed_pass(run, fr, what):
@@ -663,7 +669,7 @@ def main():
         for conv in model.roi_heads.mask_convs:
             conv.event_log = ev_excl
         model.stats_log = []
-        run_enqueue(frames, args.warmup, min(n_frames - 1, args.warmup + 8))
+        run_enqueue(frames, args.warmup, min(n_proc, args.warmup + 8))
         torch.cuda.synchronize()
         excl_counts = model.stats_log
         model.stats_log = None
@@ -702,6 +708,37 @@ def main():
                                                                   "head's work exactly as the reference issues it; outputs bitwise identical")
         model.lazy_proposal_masks = True
         model.dedup_detection_masks = True
+
+        # the same frame with the two mask passes one after the other (the detection pass may start only when the proposal masks
+        # are done): the dominant kernel's launches then share the chip with the look-ahead trunk only -- what its in-frame
+        # fraction is when the schedule does not overlap it with itself
+        if not args.no_kernel_events:
+            ev3, mark3 = [], []
+            for conv in model.roi_heads.mask_convs:
+                conv.event_log = ev3
+            model.detection_pass_after = "proposal_masks"
+
+            def run_seq(fr, lo, hi):
+                if lo == args.warmup:
+                    mark3.append(len(ev3))
+                return run_boundary(fr, lo, hi)
+
+            tv = timed_pass(run_seq, frames, "mask passes one after the other")
+            model.detection_pass_after = "cascade"
+            for conv in model.roi_heads.mask_convs:
+                conv.event_log = None
+            ev3 = ev3[mark3[0]:] if mark3 else ev3
+            v = as_variant(tv, "detection_pass_after = 'proposal_masks': the detection mask pass waits for the proposal-mask pass instead of "
+                               "running beside it; bitwise the same results (tests/test_model_gpu.py)")
+            if ev3:
+                order3 = {f: i for i, f in enumerate(sorted({t[1] for (_s, _e, t) in ev3}))}
+                fl3 = [2.0 * int(counts[min(order3[t[1]], len(counts) - 1)][4 if t[0] == "det" else 3].item()) * 196 * 256 * 2304
+                       for (_s, _e, t) in ev3]
+                d3 = [s_.elapsed_time(e_) for (s_, e_, _c) in ev3]
+                a3 = sum(fl3) / (sum(d3) * 1e-3) / 1e12
+                v["mask_conv"] = {"achieved_tflops": round(a3, 3), "frac_of_fp32_mfma_peak": round(a3 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "avg_launch_ms": round(sum(d3) / len(d3), 4), "launches": len(d3)}
+            variants["mask_passes_one_after_the_other"] = v
 
         # worst-case memory write path: MEMORY_CLS_SCORE_THRESH 0.0 keeps up to 100 memory instances per frame
         thr0 = model.cls_score_thresh
@@ -759,11 +796,11 @@ def main():
             try:
                 for nb, key in ((2, "two_sequences_in_lockstep"), (4, "four_sequences_in_lockstep")):
                     group = LockstepScenes(cfg, nb, sd)
-                    eps = [frames[:n_frames - 1]]
+                    eps = [frames[:n_proc]]
                     for extra in range(1, nb):
-                        seq2 = SyntheticSequence(1000 * extra + rank, H=H, W=W, n_frames=n_frames, map_w=map_w, map_h=map_h, cell=args.cell)
+                        seq2 = SyntheticSequence(1000 * extra + rank, H=H, W=W, n_frames=n_proc, map_w=map_w, map_h=map_h, cell=args.cell)
                         fr2 = []
-                        for i in range(n_frames - 1):
+                        for i in range(n_proc):
                             f = seq2.frame(i)
                             f["image"] = f["image"].to(dev)
                             f["proj_indices"] = torch.from_numpy(f["proj_indices"][..., 0]).to(dev)
@@ -816,7 +853,7 @@ def main():
 
     # ---- detection records -> one all-reduce -> AP50 (the eval collective of the north star) --------------------
     rec = RecordBuffer(max_rows=4 * 108)
-    for j, i in enumerate(range(args.warmup, n_frames - 1)):
+    for j, i in enumerate(range(args.warmup, n_proc)):
         if j % max(1, args.steps // 4) == 0 and j // max(1, args.steps // 4) < 4:
             inst = model.inference_frame(frames[i], refresh_memory_snapshot=True, materialize=True)["instances"]
             n = min(len(inst), 100)
@@ -875,7 +912,7 @@ def main():
                 # this run's mean FLOPs per launch of each pass over the committed trace's mean kernel duration of that launch shape
                 fl_ = sum((sum(mean_flop[s_["workgroups"]]) / max(1, len(mean_flop[s_["workgroups"]]))) * s_["launches"] for s_ in sel)
                 us_ = sum(s_["avg_us"] * s_["launches"] for s_ in sel)
-                roofline["rocprof"] = {"file": "profiles/r03_dominant_kernel_rocprof.json",
+                roofline["rocprof"] = {"file": prof.get("_file"),
                                        "avg_launch_ms": round(us_ / n_ * 1e-3, 4),
                                        "achieved": round(fl_ / (us_ * 1e-6) / 1e12, 3), "frac": round(fl_ / (us_ * 1e-6) / 1e12 / peak, 4),
                                        "by_workgroups": {str(s_["workgroups"]): {"launches": s_["launches"], "avg_us": s_["avg_us"],

@@ -25,6 +25,7 @@
 #include "../../include/eod_hip.h"
 #include <hip/hip_fp16.h>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -298,6 +299,117 @@ __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs 
   }
 }
 
+// The same contraction with a 64 (co) x 64 (ci) register block per wave (round 4).  The 32 x 32 form above issues one MFMA per pair
+// of operand loads and redoes the position arithmetic (two divisions, the tap's bounds test) for every load: 35 TFLOP/s, bound by
+// instruction issue and by the L1 operand path, not by the matrix cores.  Here a k-step loads G for two 32-channel blocks and X for
+// two, with ONE position computation, and feeds four MFMAs: half the loads and a quarter of the address arithmetic per FLOP.  The
+// four waves of a workgroup still split the range's positions and are added in wave order through LDS; a layer with 32 channels on
+// one side (the 5-channel head padded to 32, bbox_pred.2) runs with the second block switched off.
+__global__ __launch_bounds__(256) void conv_backward_weights_rb_kernel(ConvBwdArgs a) {
+  const int ci_tiles = (a.Cin + 63) >> 6;
+  const int tile = blockIdx.x;                       // (co tile, ci tile) of 64 x 64
+  const int co0 = (tile / ci_tiles) * 64, ci0 = (tile % ci_tiles) * 64;
+  const bool co2 = co0 + 32 < a.Cout, ci2 = ci0 + 32 < a.Cin;     // workgroup-uniform
+  const int tap = blockIdx.y;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int P = a.N * a.OH * a.OW;
+  const int steps = (P + 7) / 8;
+  const int sps = (steps + a.splits - 1) / a.splits;
+  const int z_begin = blockIdx.z * sps;
+  const int z_end = min(z_begin + sps, steps);
+  const int spw = (sps + 3) / 4;
+  const int s_begin = z_begin + wave * spw;
+  int s_end = s_begin + spw;
+  if (s_end > z_end) s_end = z_end;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    float g0[4], g1[4], x0[4], x1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = s * 8 + 2 * t + kh;            // instruction t contracts positions 8 s + 2 t and 8 s + 2 t + 1
+      float ga = 0.f, gb = 0.f, xa = 0.f, xb = 0.f;
+      if (pos < P) {
+        const float* gp = a.g + (size_t)pos * a.Cout + co0 + col;
+        ga = gp[0];
+        if (co2) gb = gp[32];
+        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * OH + oy
+        const int ox = pos - row * a.OW;
+        const int n = (int)fdiv((unsigned)row, a.div_h);
+        const int oy = row - n * a.OH;
+        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+          const float* xp = a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + col;
+          xa = xp[0];
+          if (ci2) xb = xp[32];
+        }
+      }
+      g0[t] = ga; g1[t] = gb; x0[t] = xa; x1[t] = xb;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[t], x0[t], acc[0][0], 0, 0, 0);
+      if (ci2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[t], x1[t], acc[0][1], 0, 0, 0);
+      if (co2) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[t], x0[t], acc[1][0], 0, 0, 0);
+      if (co2 && ci2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[t], x1[t], acc[1][1], 0, 0, 0);
+      bsum0 += g0[t];
+      bsum1 += g1[t];
+    }
+  }
+  // waves 1..3 hand their 64 x 64 block to wave 0 through LDS, one 32 x 32 quarter at a time (12 KB), added in wave order
+  __shared__ float red[3 * 16 * 64];
+  __shared__ float bred[2][4 * 64];
+  bred[0][wave * 64 + lane] = bsum0;
+  bred[1][wave * 64 + lane] = bsum1;
+  const int Ktot = a.KH * a.KW * a.Cin;
+  float* dw = a.splits > 1 ? a.part + (size_t)blockIdx.z * a.Cout * Ktot : a.dw;
+  float* db = a.splits > 1 ? a.bpart + (size_t)blockIdx.z * a.Cout : a.db;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if ((i && !co2) || (j && !ci2)) continue;      // workgroup-uniform
+      __syncthreads();                               // the previous quarter has been consumed
+      if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+        f32x16 v = acc[i][j];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += red[((w - 1) * 16 + r) * 64 + lane];
+        // C/D layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          dw[(size_t)co * Ktot + (size_t)tap * a.Cin + ci0 + 32 * j + col] = v[r];
+        }
+      }
+    }
+  }
+  if (a.db && tap == 0 && (tile % ci_tiles) == 0 && wave == 0 && lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i && !co2) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += bred[i][w * 64 + lane] + bred[i][w * 64 + 32 + lane];    // even + odd positions, wave order
+      db[co0 + 32 * i + lane] = v;
+    }
+  }
+}
+
 // dW / db = the partial results of the position ranges added in range order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dw,
                                                            float* __restrict__ db, size_t n, int Cout, int splits) {
@@ -564,11 +676,22 @@ static int conv_bwd_args(ConvBwdArgs& a, int N, int H, int W, int Cin, int Cout,
 }
 
 // position ranges of a weight-gradient launch: enough workgroups for the chip, ranges of at least 16 steps (128 positions)
+// EOD_WGRAD_RB=0 selects the 32 x 32 kernel of round 3 (same-box A/B of the two; read once)
+static bool wgrad_register_blocked() {
+  static const bool on = [] {
+    const char* e = getenv("EOD_WGRAD_RB");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   const long P = (long)N * OH * OW;
   const bool tap4_scalar = Cin == 4 && KW > 8;                    // wider kernel rows than a 32-column tile: the scalar kernel
-  const long wgs = Cin == 4 ? (tap4_scalar ? (long)KH * KW * (Cout >> 4) : (long)(Cout >> 5) * KH) : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
+  const long wgs = Cin == 4 ? (tap4_scalar ? (long)KH * KW * (Cout >> 4) : (long)(Cout >> 5) * KH)
+                   : wgrad_register_blocked() ? (long)((Cout + 63) >> 6) * ((Cin + 63) >> 6) * KH * KW        // 64 x 64 register blocks
+                                              : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
   long s = tap4_scalar ? 16 : (768 + wgs - 1) / wgs;
   const long cap = tap4_scalar ? P / 2048 : (P + 7) / 8 / 16;
   if (s > cap) s = cap;
@@ -605,6 +728,9 @@ static int conv2d_backward_weights_impl(const float* x, const float* g, int N, i
     hipLaunchKernelGGL(conv_backward_weights_tap4_mfma_kernel, dim3((Cout >> 5) * KH, 1, a.splits), dim3(256), 0, (hipStream_t)stream, a);
   else if (Cin == 4)
     hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4, a.splits), dim3(1024), 0, (hipStream_t)stream, a);
+  else if (wgrad_register_blocked())
+    hipLaunchKernelGGL(conv_backward_weights_rb_kernel, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
+                       (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv_backward_weights_kernel, dim3((Cout >> 5) * (Cin >> 5), KH * KW, a.splits), dim3(256), 0, (hipStream_t)stream, a);
   if (a.splits > 1) {

@@ -534,32 +534,100 @@ struct SampleArgs {
   int* sampled; int* counts;
 };
 
+// exclusive scan of one int per thread over the 1024 threads of the workgroup (wave shuffles + one LDS pass); *total = the sum
+__device__ __forceinline__ int sample_block_scan(int v, int* wsum, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();                                   // wsum may still be read from the previous scan
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int c = wsum[w];
+    if (w < wave) before += c;
+    all += c;
+  }
+  *total = all;
+  return before + inc - v;
+}
+
+// Ranks by counting are O(R^2) in one workgroup (0.55 ms at R = 2072: the training step's 4 000 / 2 000 proposal lists).  Uniform
+// keys in [0, 1) bucket well: rows are dealt into 1024 value buckets per kind (counting sort in LDS), a row's rank among its kind =
+// rows in smaller buckets + rows of its own bucket with a smaller (key, row) -- two or three candidates on average, the whole bucket
+// when many keys are equal (still exact: the comparison is the full (key, row) order).  The sampled rows' slots are a block scan.
 __global__ __launch_bounds__(1024) void sample_proposals_kernel(SampleArgs a) {
+  constexpr int NB = 1024;
   __shared__ float key[SAMPLE_MAX_R];
   __shared__ unsigned char kind[SAMPLE_MAX_R];      // 0: ignored (-1), 1: foreground, 2: background; bit 2: sampled
+  __shared__ unsigned short list[SAMPLE_MAX_R];     // rows grouped by (kind, bucket)
+  __shared__ int start[2][NB + 1];                  // first list slot of a (kind, bucket); then the running fill position
+  __shared__ int wsum[16];
   __shared__ int tot[2];
   const int tid = threadIdx.x;
   if (tid < 2) tot[tid] = 0;
+  for (int b = tid; b < 2 * (NB + 1); b += 1024) (&start[0][0])[b] = 0;
   __syncthreads();
+  auto bucket_of = [](float k) {
+    int b = (int)(k * (float)NB);
+    return b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+  };
   for (int i = tid; i < a.R; i += 1024) {
     const int c = a.cls[i];
     const unsigned char k = c == a.C ? 2 : (c != -1 ? 1 : 0);            // subsample_labels: (labels != -1) & (labels != bg) / labels == bg
-    key[i] = a.keys[i];
+    const float kv = a.keys[i];
+    key[i] = kv;
     kind[i] = k;
-    if (k) atomicAdd(&tot[k - 1], 1);
+    if (k) {
+      atomicAdd(&tot[k - 1], 1);
+      atomicAdd(&start[k - 1][bucket_of(kv) + 1], 1);                    // counts, shifted by one for the exclusive prefix
+    }
+  }
+  __syncthreads();
+  // exclusive prefix over the buckets of each kind (thread t owns bucket t); the background lists follow the foreground ones
+  {
+    int total = 0;
+    const int c0 = start[0][tid + 1];
+    const int e0 = sample_block_scan(c0, wsum, &total);
+    const int n_fg = total;
+    const int c1 = start[1][tid + 1];
+    const int e1 = sample_block_scan(c1, wsum, &total);
+    __syncthreads();
+    start[0][tid] = e0;
+    start[1][tid] = n_fg + e1;
+    if (tid == 0) { start[0][NB] = n_fg; start[1][NB] = n_fg + total; }
+  }
+  __syncthreads();
+  // fill the lists: `fillp` = a second copy of the bucket starts, advanced atomically (the order inside a bucket does not matter)
+  __shared__ int fillp[2][NB];
+  fillp[0][tid] = start[0][tid];
+  fillp[1][tid] = start[1][tid];
+  __syncthreads();
+  for (int i = tid; i < a.R; i += 1024) {
+    const unsigned char k = kind[i];
+    if (k) list[atomicAdd(&fillp[k - 1][bucket_of(key[i])], 1)] = (unsigned short)i;
   }
   __syncthreads();
   const int n_pos = tot[0] < a.max_pos ? tot[0] : a.max_pos;
   const int n_neg = tot[1] < a.batch - n_pos ? tot[1] : a.batch - n_pos;
+  const int base1 = start[0][NB];                                         // first background slot
   unsigned keep = 0;                                                      // bit q: row tid + 1024 q is sampled
   for (int i = tid, q = 0; i < a.R; i += 1024, ++q) {
     const unsigned char k = kind[i];
     if (!k) continue;
     const float ki = key[i];
-    int rank = 0;
-    for (int j = 0; j < a.R; ++j) {
+    const int b = bucket_of(ki);
+    const int lo = start[k - 1][b], hi = start[k - 1][b + 1];
+    int rank = lo - (k == 2 ? base1 : 0);                                 // rows of this kind in smaller buckets
+    for (int p = lo; p < hi; ++p) {
+      const int j = list[p];
       const float kj = key[j];
-      rank += (kind[j] == k && (kj < ki || (kj == ki && j < i))) ? 1 : 0;
+      rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
     }
     if (rank < (k == 1 ? n_pos : n_neg)) keep |= 1u << q;
   }
@@ -567,12 +635,21 @@ __global__ __launch_bounds__(1024) void sample_proposals_kernel(SampleArgs a) {
   for (int i = tid, q = 0; i < a.R; i += 1024, ++q)
     if (keep >> q & 1u) kind[i] |= 4;
   __syncthreads();
-  for (int i = tid, q = 0; i < a.R; i += 1024, ++q) {
-    if (!(keep >> q & 1u)) continue;
-    const unsigned char k = kind[i];
-    int slot = 0;
-    for (int j = 0; j < i; ++j) slot += kind[j] == k ? 1 : 0;
-    a.sampled[((k & 3) == 1 ? 0 : n_pos) + slot] = i;
+  // slots: foreground rows first, each kind in ascending row order = exclusive scans over the rows.  Thread t scans a CONTIGUOUS
+  // run of rows so that the order of the scan is the row order
+  const int per = (a.R + 1023) / 1024;
+  const int r0 = tid * per, r1 = min(r0 + per, a.R);
+  int cf = 0, cb = 0;
+  for (int i = r0; i < r1; ++i) {
+    cf += kind[i] == 5 ? 1 : 0;
+    cb += kind[i] == 6 ? 1 : 0;
+  }
+  int total = 0;
+  int sf = sample_block_scan(cf, wsum, &total);
+  int sb = sample_block_scan(cb, wsum, &total) + n_pos;
+  for (int i = r0; i < r1; ++i) {
+    if (kind[i] == 5) a.sampled[sf++] = i;
+    else if (kind[i] == 6) a.sampled[sb++] = i;
   }
   if (tid == 0) { a.counts[0] = n_pos; a.counts[1] = n_pos + n_neg; }
 }

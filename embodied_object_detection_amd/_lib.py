@@ -101,7 +101,8 @@ class EodStageTailDesc(C.Structure):
 
 class EodAdamWTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t),
-                ("lr", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32)]
+                ("lr", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("folded_out", C.c_void_p), ("row_scale", C.c_void_p),
+                ("cols", C.c_int32), ("ld_out", C.c_int32)]
 
 
 class EodMemWriteDesc(C.Structure):
@@ -196,6 +197,7 @@ SIGNATURES = {
     "eod_relu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "eod_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, C.c_int, C.c_double, C.c_void_p]),
+    "eod_conv_rotate_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "eod_adamw_step_multi": (C.c_int, [C.POINTER(EodAdamWTensor), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, 
 // microseconds each were 4 % of the iteration's kernel time and 126 launch boundaries).  The tensors' constants travel in the
 // kernel arguments; a workgroup finds its tensor by the prefix of the tensors' workgroup counts.  Element for element the
 // arithmetic of adamw_step_kernel.
-#define ADAMW_MULTI 24
+#define ADAMW_MULTI 20
 struct AdamWMulti {
   float* p[ADAMW_MULTI];
   const float* g[ADAMW_MULTI];
@@ -170,6 +170,11 @@ struct AdamWMulti {
   unsigned long long n[ADAMW_MULTI];
   float decay[ADAMW_MULTI], step_size[ADAMW_MULTI], bc2_sqrt[ADAMW_MULTI];
   unsigned block_end[ADAMW_MULTI];     // exclusive end of tensor t's workgroups
+  // optional: the stepped value times a per-row factor, written to a second matrix (a trunk conv's raw master -> the layer's weights
+  // with its FrozenBatchNorm folded in: timm.py:277-299 keeps weight / bias of the norm as buffers, not parameters)
+  float* folded[ADAMW_MULTI];
+  const float* row_scale[ADAMW_MULTI];
+  unsigned cols[ADAMW_MULTI], ld_out[ADAMW_MULTI];
   int count;
   float one_minus_b1, b2, one_minus_b2, eps, clip;
 };
@@ -185,6 +190,9 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWMulti a) {
   float* __restrict__ v = a.v[t];
   const size_t n = a.n[t];
   const float decay = a.decay[t], step_size = a.step_size[t], bc2_sqrt = a.bc2_sqrt[t];
+  float* __restrict__ folded = a.folded[t];
+  const float* __restrict__ rs = a.row_scale[t];
+  const unsigned cols = a.cols[t], ldo = a.ld_out[t];
   for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
     float gi = g[i];
     if (a.clip > 0.f) gi = fminf(fmaxf(gi, -a.clip), a.clip);
@@ -197,6 +205,10 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWMulti a) {
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
+    if (folded) {
+      const unsigned r = (unsigned)(i / cols), c = (unsigned)(i - (size_t)r * cols);
+      folded[(size_t)r * ldo + c] = pi * rs[r];
+    }
   }
 }
 
@@ -810,6 +822,34 @@ extern "C" int eod_adamw_step(float* param, const float* grad, float* exp_avg, f
   return eod_launch_status();
 }
 
+// The weights of a layer's input-gradient convolution (dX = conv of dY with the 180-degree rotated, in/out-transposed kernel), from the
+// layer's packed forward weights: out[ci][(ky', kx', co)] = w[co][(KH-1-ky', KW-1-kx', ci)].  One launch per layer after an optimizer
+// step (torch's flip + permute + copy were three).
+__global__ __launch_bounds__(256) void rotate_weights_kernel(const float* __restrict__ w, int Cout, int KH, int KW, int Cin, int ld_in,
+                                                              float* __restrict__ out, int ld_out) {
+  const size_t n = (size_t)Cin * KH * KW * Cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    size_t r = i / Cout;
+    const int kx = (int)(r % KW);
+    r /= KW;
+    const int ky = (int)(r % KH);
+    const int ci = (int)(r / KH);
+    out[(size_t)ci * ld_out + ((size_t)ky * KW + kx) * Cout + co] =
+        w[(size_t)co * ld_in + ((size_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * Cin + ci];
+  }
+}
+
+extern "C" int eod_conv_rotate_weights(const float* w, int Cout, int KH, int KW, int Cin, int ld_in, float* out, int ld_out,
+                                       eod_stream_t stream) {
+  if (!w || !out) return EOD_ERR_NULL;
+  if (Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || ld_in < KH * KW * Cin || ld_out < KH * KW * Cout) return EOD_ERR_BAD_DIMS;
+  size_t blocks = ((size_t)Cin * KH * KW * Cout + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rotate_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, KH, KW, Cin, ld_in, out, ld_out);
+  return eod_launch_status();
+}
+
 extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
                                     eod_stream_t stream) {
   if (!tensors) return EOD_ERR_NULL;
@@ -818,6 +858,7 @@ extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, do
     const EodAdamWTensor& t = tensors[i];
     if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return EOD_ERR_NULL;
     if (t.n == 0 || t.step < 1 || !(t.lr >= 0.0)) return EOD_ERR_BAD_DIMS;
+    if (t.folded_out && (!t.row_scale || t.cols <= 0 || t.ld_out < t.cols || t.n % (size_t)t.cols != 0)) return EOD_ERR_BAD_DIMS;
   }
   for (int i0 = 0; i0 < count; i0 += ADAMW_MULTI) {
     AdamWMulti a{};
@@ -829,6 +870,7 @@ extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, do
       const EodAdamWTensor& t = tensors[i0 + k];
       const double bc1 = 1.0 - pow(beta1, (double)t.step), bc2 = 1.0 - pow(beta2, (double)t.step);
       a.p[k] = t.param; a.g[k] = t.grad; a.m[k] = t.exp_avg; a.v[k] = t.exp_avg_sq; a.n[k] = t.n;
+      a.folded[k] = t.folded_out; a.row_scale[k] = t.row_scale; a.cols[k] = (unsigned)t.cols; a.ld_out[k] = (unsigned)t.ld_out;
       a.decay[k] = (float)(1.0 - t.lr * t.weight_decay);
       a.step_size[k] = (float)(t.lr / bc1);
       a.bc2_sqrt[k] = (float)sqrt(bc2);

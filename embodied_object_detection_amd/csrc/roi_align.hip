@@ -354,6 +354,88 @@ extern "C" int eod_roi_align(const float* p3, const float* p4, const float* p5, 
   return eod_launch_status();
 }
 
+// Gather form (round 4): one wave per CELL of a level's gradient.  The footprint kernel above still issues one atomic per (ROI,
+// footprint cell, channel) -- 512 sampled rows with ~200-cell footprints are ~3 x 10^7 fp32 atomics per launch (0.56 ms; 1.7 ms of a
+// training iteration), and their order is not fixed.  Here a cell's wave finds the ROIs whose footprint holds the cell (every lane
+// tests R / 64 boxes: level, row range, column range), walks them in ROW ORDER, accumulates weight x dY in registers (lane = 4
+// channels) and adds the sum to the cell once: no atomics, and the result does not depend on the schedule.  C <= 256, S <= 64.
+static __global__ __launch_bounds__(256) void roi_align_backward_gather_kernel(RoiArgs p, float* d3, float* d4, float* d5, const float* __restrict__ g) {
+  int R = p.R_cap;
+  if (p.count) {
+    const int c = *p.count;
+    R = c < R ? c : R;
+  }
+  const int lane = threadIdx.x & 63;
+  const int S = p.S;
+  const int n0 = p.h[0] * p.w[0], n1 = p.h[1] * p.w[1], n2 = p.h[2] * p.w[2];
+  const int cell_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (cell_id >= n0 + n1 + n2) return;                               // wave-uniform
+  const int l = cell_id < n0 ? 0 : (cell_id < n0 + n1 ? 1 : 2);
+  const int local = cell_id - (l == 0 ? 0 : (l == 1 ? n0 : n0 + n1));
+  const int H = p.h[l], W = p.w[l];
+  const int cy = local / W, cx = local - cy * W;
+  const float sc = p.scale[l];
+  float* dfeat = l == 0 ? d3 : (l == 1 ? d4 : d5);
+  const int c0 = lane * 4;
+  const bool on = c0 < p.C;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < R; base += 64) {
+    // does ROI base + lane reach this cell?  (its level; the rows / columns its samples' taps can touch)
+    bool hit = false;
+    const int rr = base + lane;
+    if (rr < R) {
+      const float bx1 = p.boxes[rr * 4 + 0], by1 = p.boxes[rr * 4 + 1], bx2 = p.boxes[rr * 4 + 2], by2 = p.boxes[rr * 4 + 3];
+      const float area = (bx2 - bx1) * (by2 - by1);
+      float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
+      lv = fminf(fmaxf(lv, 3.0f), 5.0f);
+      if ((int)lv - 3 == l) {
+        const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f, x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+        const int cy_lo = min(max((int)floorf(fmaxf(y1, -2.0f)), 0), H - 1), cy_hi = min(max((int)floorf(fminf(y2, (float)H + 1.0f)) + 1, 0), H - 1);
+        const int cx_lo = min(max((int)floorf(fmaxf(x1, -2.0f)), 0), W - 1), cx_hi = min(max((int)floorf(fminf(x2, (float)W + 1.0f)) + 1, 0), W - 1);
+        hit = cy >= cy_lo && cy <= cy_hi && cx >= cx_lo && cx <= cx_hi;
+      }
+    }
+    for (unsigned long long m = __ballot(hit); m; m &= m - 1) {
+      const int r = base + __builtin_ctzll(m);                       // wave-uniform
+      const float bx1 = p.boxes[r * 4 + 0], by1 = p.boxes[r * 4 + 1], bx2 = p.boxes[r * 4 + 2], by2 = p.boxes[r * 4 + 3];
+      const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f, x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+      const float roi_w = x2 - x1, roi_h = y2 - y1;
+      const float bin_h = roi_h / (float)S, bin_w = roi_w / (float)S;
+      const float ghf = ceilf(roi_h / (float)S), gwf = ceilf(roi_w / (float)S);
+      const bool sane = (ghf == ghf) && (gwf == gwf) && ghf < 1.0e6f && gwf < 1.0e6f && ghf >= 1.0f && gwf >= 1.0f;
+      if (!sane) continue;
+      const int gh = (int)ghf, gw = (int)gwf;
+      const float inv_cnt = 1.0f / ((float)gh * (float)gw);
+      const float ay = lane < S ? roi_axis_weight(y1, bin_h, gh, lane, H, cy) : 0.f;
+      const unsigned long long my = __ballot(ay != 0.f);
+      if (!my) continue;
+      const float ax = lane < S ? roi_axis_weight(x1, bin_w, gw, lane, W, cx) : 0.f;
+      const unsigned long long mx = __ballot(ax != 0.f);
+      if (!mx) continue;
+      f32x4 part = {0.f, 0.f, 0.f, 0.f};
+      for (unsigned long long m1 = my; m1; m1 &= m1 - 1) {
+        const int ph = __builtin_ctzll(m1);
+        const float wy = __shfl(ay, ph);
+        for (unsigned long long m2 = mx; m2; m2 &= m2 - 1) {
+          const int pw = __builtin_ctzll(m2);
+          const float wgt = wy * __shfl(ax, pw);
+          if (on) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (((size_t)r * S + ph) * S + pw) * p.C + c0);
+            part.x += wgt * gv.x; part.y += wgt * gv.y; part.z += wgt * gv.z; part.w += wgt * gv.w;
+          }
+        }
+      }
+      acc.x += part.x * inv_cnt; acc.y += part.y * inv_cnt; acc.z += part.z * inv_cnt; acc.w += part.w * inv_cnt;
+    }
+  }
+  if (on && (acc.x != 0.f || acc.y != 0.f || acc.z != 0.f || acc.w != 0.f)) {
+    f32x4* dst = reinterpret_cast<f32x4*>(dfeat + (size_t)local * p.C + c0);
+    f32x4 v = *dst;
+    v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+    *dst = v;
+  }
+}
+
 extern "C" int eod_roi_align_backward(float* dp3, float* dp4, float* dp5, int h3, int w3, int C, const float* boxes, const int32_t* count,
                                       int R_cap, int out_size, const float* g, eod_stream_t stream) {
   if (!dp3 || !dp4 || !dp5 || !boxes || !g) return EOD_ERR_NULL;
@@ -368,6 +450,13 @@ extern "C" int eod_roi_align_backward(float* dp3, float* dp4, float* dp5, int h3
   a.div_bins = eod_make_fastdiv((unsigned)(out_size * out_size));
   a.div_s = eod_make_fastdiv((unsigned)out_size);
   static const bool by_samples = getenv("EOD_ROI_BWD_SAMPLES") != nullptr;     // the sample-tap form, for A/B runs (tools/)
+  static const bool by_rows = getenv("EOD_ROI_BWD_ROWS") != nullptr;           // the footprint form with atomics (round 3), for A/B runs
+  if (out_size <= 64 && C <= 256 && !by_samples && !by_rows && eod_aligned16(dp3) && eod_aligned16(dp4) && eod_aligned16(dp5)) {
+    const long cells = (long)h3 * w3 + (long)(h3 / 2) * (w3 / 2) + (long)(h3 / 4) * (w3 / 4);
+    hipLaunchKernelGGL(roi_align_backward_gather_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, dp3, dp4,
+                       dp5, g);
+    return eod_launch_status();
+  }
   if (out_size <= 64 && !by_samples) {
     const int rows_max = h3 + 1;                                             // the tallest footprint: a level-3 ROI over the whole height
     const long waves = (long)R_cap * rows_max;

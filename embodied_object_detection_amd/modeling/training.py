@@ -142,6 +142,7 @@ class ProposalTrainer:
         bbm, pg = model.backbone, model.proposal_generator
         self.entries = []          # (reference parameter name, tensor stepped by AdamW, gradient getter)
         self.after = []            # callables run after every optimizer step
+        self.folds = {}            # parameter name -> (layer weights, per-row FrozenBatchNorm scale): re-folded by the optimizer's launch
         base = "backbone.bottom_up.base"
 
         def add(name, tensor, getter):
@@ -154,7 +155,8 @@ class ProposalTrainer:
             master = master[:, :K].contiguous().to(dev)
             scale = (sd[f"{bnp}.weight"].float() / torch.sqrt(sd[f"{bnp}.running_var"].float() + 1e-5)).to(dev).view(-1, 1)
             add(wname, master, lambda g, n=conv.name, s=scale: (g[n][0] * s).contiguous())
-            self.after.append(lambda c=conv, m=master, s=scale, K=K: c.w[:, :K].copy_(m * s))
+            # the optimizer's launch writes the re-folded weights (master x scale) straight into the layer (`AdamW` group key "fold")
+            self.folds[wname] = (conv.w, scale.view(-1).contiguous())
 
         trunk_conv(bbm.bottom_up.stem, f"{base}.conv1.weight", f"{base}.bn1", cin_pad=4)
         for (li, c1, c2, c3, ds) in bbm.bottom_up.blocks:
@@ -270,6 +272,9 @@ class ProposalTrainer:
             frozen = [n for n, _, _ in self.entries if not any(k in n for k in keys)]
         self.groups = solver.param_groups_from_cfg(cfg, [(n, t) for n, t, _ in self.entries])
         self.groups = [g for g in self.groups if g["name"] not in frozen]
+        for g in self.groups:
+            if g["name"] in self.folds:
+                g["fold"] = self.folds[g["name"]]
         self.getters = {n: f for n, _, f in self.entries}
         clip = s.CLIP_GRADIENTS
         if bool(clip.ENABLED) and str(clip.CLIP_TYPE) != "value":

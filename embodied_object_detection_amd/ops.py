@@ -640,9 +640,9 @@ class ConvBackward:
                 wt = w.flip(1, 2).permute(3, 0, 1, 2).contiguous()                 # [ci, co, ky', kx'] = OIHW of the transposed conv
                 self._flipped = Conv(wt.cpu(), None, stride=1, pad=c.pad, device=c.w.device, name=c.name + "^T")
             else:
-                # the weights were stepped: refresh the packed rows [ci][(ky', kx', co)] on the device (no host round trip)
-                K2 = c.KH * c.KW * c.Cout
-                self._flipped.w[:, :K2].copy_(w.flip(1, 2).permute(3, 1, 2, 0).reshape(c.Cin, K2))
+                # the weights were stepped: refresh the packed rows [ci][(ky', kx', co)] on the device, one launch
+                check(self.lib.eod_conv_rotate_weights(c.w.data_ptr(), c.Cout, c.KH, c.KW, c.Cin, c.Kpad, self._flipped.w.data_ptr(),
+                                                       self._flipped.Kpad, _stream()), "eod_conv_rotate_weights")
                 self._flipped.w_split = None
             self._flipped_of = key
         return self._flipped
@@ -880,7 +880,7 @@ class AdamW:
         self.state = [(torch.zeros_like(g["param"]), torch.zeros_like(g["param"])) for g in groups]
         self.steps = [0] * len(groups)
         self.lib = _lib.load()
-        # all tensors in ceil(n / 24) launches (`eod_adamw_step_multi`); False: one `eod_adamw_step` launch per tensor (the same
+        # all tensors in ceil(n / 20) launches (`eod_adamw_step_multi`); False: one `eod_adamw_step` launch per tensor (the same
         # arithmetic element for element: tests/test_backward_gpu.py compares the two)
         self.multi_tensor = True
         self._descs = (_lib.EodAdamWTensor * max(len(groups), 1))()
@@ -918,6 +918,11 @@ class AdamW:
                 d = self._descs[n]
                 d.param, d.grad, d.exp_avg, d.exp_avg_sq = p.data_ptr(), grad.data_ptr(), self.state[i][0].data_ptr(), self.state[i][1].data_ptr()
                 d.n, d.lr, d.weight_decay, d.step = p.numel(), g["lr"] * lr_factor, g.get("weight_decay", self.weight_decay), self.steps[i]
+                fold = g.get("fold")              # (folded weights [rows, ld], per-row scale [rows]): written by the same launch
+                if fold is not None:
+                    d.folded_out, d.row_scale, d.cols, d.ld_out = fold[0].data_ptr(), fold[1].data_ptr(), p.shape[1], fold[0].stride(0)
+                else:
+                    d.folded_out, d.row_scale, d.cols, d.ld_out = None, None, 0, 0
                 n += 1
             if n:
                 check(self.lib.eod_adamw_step_multi(self._descs, n, self.betas[0], self.betas[1], self.eps, self.clip_value, _stream()),
@@ -935,6 +940,8 @@ class AdamW:
             check(self.lib.eod_adamw_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), g["lr"] * lr_factor,
                                           self.betas[0], self.betas[1], self.eps, g.get("weight_decay", self.weight_decay), self.steps[i],
                                           self.clip_value, _stream()), "eod_adamw_step")
+            if g.get("fold") is not None:
+                g["fold"][0][:, :p.shape[1]].copy_(p * g["fold"][1].view(-1, 1))
 
 
 class MemoryWriter:

@@ -511,7 +511,12 @@ int eod_relu_backward(const float* g, const float* y, float* out, size_t n, eod_
 int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, double clip_value, eod_stream_t stream);
 
-/* The same update for `count` parameter tensors in ceil(count / 24) launches (the training step of the recurrent detector has 126):
+/* Weights of a layer's input-gradient convolution from its packed forward weights w [Cout][ld_in] (k = (ky, kx, ci)):
+ * out [Cin][ld_out] with k' = (ky', kx', co) and out[ci][k'] = w[co][(KH-1-ky', KW-1-kx', ci)] -- the 180-degree rotated, in/out-transposed
+ * kernel that `eod_conv2d` convolves dY with (autograd of every conv of timm.py:118-136,277-299, centernet_head.py:141-161). */
+int eod_conv_rotate_weights(const float* w, int Cout, int KH, int KW, int Cin, int ld_in, float* out, int ld_out, eod_stream_t stream);
+
+/* The same update for `count` parameter tensors in ceil(count / 20) launches (the training step of the recurrent detector has 126):
  * tensors[i] carries its own lr (BASE_LR x multipliers x the schedule's factor), weight decay and 1-based update count.  Element
  * for element the arithmetic of eod_adamw_step.  `tensors` is a HOST array, read before the call returns. */
 typedef struct EodAdamWTensor {
@@ -523,6 +528,11 @@ typedef struct EodAdamWTensor {
   double lr;
   double weight_decay;
   int32_t step;
+  /* optional (NULL = off): the stepped tensor read as [n / cols, cols] rows, times row_scale[row], written to folded_out with row
+   * pitch ld_out -- a trunk conv's raw master weight -> the layer's packed weights with its FrozenBatchNorm folded in */
+  float* folded_out;
+  const float* row_scale;
+  int32_t cols, ld_out;
 } EodAdamWTensor;
 int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
                          eod_stream_t stream);

@@ -95,7 +95,7 @@ def test_adamw_step_matches_the_reference_optimizer(golden):
 
 @pytest.mark.gpu
 def test_multi_tensor_adamw_equals_the_single_tensor_launches():
-    """`eod_adamw_step_multi` (all parameter tensors of the training step in ceil(n / 24) launches) against one `eod_adamw_step`
+    """`eod_adamw_step_multi` (all parameter tensors of the training step in ceil(n / 20) launches) against one `eod_adamw_step`
     launch per tensor: bitwise the same parameters and moments after three steps, on 61 tensors of 1 .. 3 M elements with their own
     learning rates, a skipped tensor (no gradient) and clip by value."""
     from embodied_object_detection_amd import ops
@@ -104,14 +104,23 @@ def test_multi_tensor_adamw_equals_the_single_tensor_launches():
     sizes = [1, 3, 5, 64, 255, 256, 257, 1023, 1024, 1025, 4097, 70001, 3_000_001] + [int(torch.randint(1, 50000, (1,), generator=g)) for _ in range(48)]
     base = [torch.randn((n,), generator=g) for n in sizes]
 
+    folded = {}
+
     def run(multi):
         params = [b.clone().to(dev) for b in base]
         groups = [{"name": f"t{i}", "param": p, "lr": 1e-3 * (1 + i % 3)} for i, p in enumerate(params)]
+        # a trunk conv's raw master [64, 196] whose stepped value x the per-row FrozenBatchNorm scale lands in the layer's padded
+        # weights [64, 224] in the same launch (the multi-tensor form) / by a torch expression (the per-tensor form)
+        master = torch.linspace(-1, 1, 64 * 196).reshape(64, 196).to(dev)
+        layer_w = torch.zeros((64, 224), device=dev)
+        scale = (torch.arange(64, dtype=torch.float32) * 0.01 + 0.5).to(dev)
+        groups.append({"name": "conv1", "param": master, "lr": 2e-3, "fold": (layer_w, scale)})
+        folded[multi] = (master, layer_w, scale)
         opt = ops.AdamW(groups, weight_decay=1e-2, clip_value=1.0)
         opt.multi_tensor = multi
         gg = torch.Generator().manual_seed(9)
         for step in range(3):
-            grads = [(torch.randn((n,), generator=gg) * 3).to(dev) for n in sizes]
+            grads = [(torch.randn((n,), generator=gg) * 3).to(dev) for n in sizes] + [(torch.randn((64, 196), generator=gg)).to(dev)]
             if step == 1:
                 grads[7] = None                                  # a tensor without a gradient this iteration keeps its step count
             opt.step(grads, lr_factor=0.5 + 0.25 * step)
@@ -124,8 +133,13 @@ def test_multi_tensor_adamw_equals_the_single_tensor_launches():
         assert torch.equal(pa[i], pb[i]), i
         assert torch.equal(oa.state[i][0], ob.state[i][0]) and torch.equal(oa.state[i][1], ob.state[i][1]), i
     assert not torch.equal(pa[12].cpu(), base[12])
+    for multi in (True, False):
+        master, layer_w, scale = folded[multi]
+        assert torch.equal(layer_w[:, :196], master * scale.view(-1, 1)) and not bool(layer_w[:, 196:].any())
+    assert torch.equal(folded[True][0], folded[False][0]) and torch.equal(folded[True][1], folded[False][1])
     # the state dict round trip the checkpoint uses
     sd = oa.state_dict()
-    oc = ops.AdamW([{"name": f"t{i}", "param": p.clone(), "lr": 1e-3} for i, p in enumerate(pa)])
+    oc = ops.AdamW([{"name": f"t{i}", "param": p.clone(), "lr": 1e-3} for i, p in enumerate(pa)] +
+                   [{"name": "conv1", "param": folded[True][0].clone(), "lr": 1e-3}])
     oc.load_state_dict(sd)
     assert oc.steps == oa.steps and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(oc.state, oa.state))

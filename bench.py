@@ -479,7 +479,8 @@ def train_step_variant(sd) -> dict:
     wh = torch.rand((24, 2), generator=g) * torch.tensor([W * 0.35, H * 0.35]) + 8
     gt = torch.cat([xy, xy + wh], dim=1).to(dev)
     kw = dict(gt_classes=torch.randint(0, 20, (24,), generator=g).int().to(dev), generator=torch.Generator(device=dev).manual_seed(0))
-    warm, steps = 3, 8
+    torch.cuda.empty_cache()
+    warm, steps = 4, 10
     first = None
     for _ in range(warm):
         out = trainer.step(img, gt, memory=(mem16, proj), **kw)
@@ -491,6 +492,12 @@ def train_step_variant(sd) -> dict:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     last = sum(float(v) for v in out.values())
+    per_iter = []
+    for _ in range(4):                                          # diagnostics: one iteration at a time, synchronised
+        t1 = time.perf_counter()
+        trainer.step(img, gt, memory=(mem16, proj), **kw)
+        torch.cuda.synchronize()
+        per_iter.append(round((time.perf_counter() - t1) * 1e3, 2))
     rows = [int(r["boxes"].shape[0]) for r in trainer.fm.det.last]
     fr = frame_roofline(H, W, float(np.mean(rows)), 0.0, 1.0, "fp32", n_mask_rois=0.0)["by_stage_gflop"]
     fwd = sum(fr.values())
@@ -498,7 +505,7 @@ def train_step_variant(sd) -> dict:
            "dtype": "f32", "proposals": int(trainer.fm.last_proposals.shape[0]), "proposal_list_sizes": [trainer.fm.pre, trainer.fm.post],
            "roi_rows_per_stage": rows, "gt_boxes": 24, "forward_gflop": round(fwd, 1), "algorithmic_gflop_per_iteration": round(3 * fwd, 1),
            "achieved_tflops": round(3 * fwd / dt / 1e3, 2), "frac_of_fp32_mfma_peak": round(3 * fwd / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
-           "total_loss_first_last": [round(first, 4), round(last, 4)],
+           "total_loss_first_last": [round(first, 4), round(last, 4)], "synchronised_iterations_ms": per_iter,
            "note": "Trainer.step: forward_model forward + backward + AdamW over 126 tensors on one 640x640 frame, parameters stepped in the "
                    "layers the inference path runs; FP16: False (the yaml's autocast / GradScaler path is refused, not emulated)"}
     del trainer, model

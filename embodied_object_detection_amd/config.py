@@ -153,7 +153,8 @@ def get_cfg() -> CfgNode:
         "INPUT": {"FORMAT": "BGR", "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333, "CUSTOM_AUG": "", "TEST_SIZE": 640,
                   "NOT_CLAMP_BOX": False},
         "DATASETS": {"TRAIN": (), "TEST": ()},
-        "DATALOADER": {"NUM_WORKERS": 4, "SAMPLER_TRAIN": "TrainingSampler"},
+        # NUM_WORKERS_TRAIN_MP3D: the MP3D training DataLoader's worker processes (hard-coded 2 in train_mp3d.py:566; 0 = in-process)
+        "DATALOADER": {"NUM_WORKERS": 4, "SAMPLER_TRAIN": "TrainingSampler", "NUM_WORKERS_TRAIN_MP3D": 2},
         "TEST": {"DETECTIONS_PER_IMAGE": 100, "EVAL_PERIOD": 0},
         # detectron2's SOLVER defaults + Detic's additions (detic/config.py:153-157): read by solver.py / modeling/training.py
         "SOLVER": {

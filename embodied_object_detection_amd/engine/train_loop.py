@@ -14,8 +14,8 @@ rhythm (`tests/golden/mp3d_train_driver.json`).  Three things the reference's lo
   * a resumed run starts at stored iteration + 1 (:524-525) and the body adds one again: the iteration numbered stored + 1 never
     runs -- a run resumed from `model_final` written at max_iter - 1 does nothing;
   * the schedule is built from SOLVER.MAX_ITER (`build_lr_scheduler`, :519) even when SOLVER.TRAIN_ITER caps the loop (:529).
-What is not here: the AMP GradScaler (`Trainer` refuses FP16: True), DataLoader worker processes, TensorBoard / JSON writers (a `log`
-callable takes their rows at the writers' rhythm, :647-650).
+What is not here: the AMP GradScaler (`Trainer` refuses FP16: True), TensorBoard / JSON writers (a `log` callable takes their rows at
+the writers' rhythm, :647-650).  The loader's worker processes (:563-572) are `training_batches(..., workers=2)`.
 """
 from __future__ import annotations
 
@@ -36,11 +36,31 @@ def training_sampler(size: int, seed: int = 0, shuffle: bool = True) -> Iterator
         yield from order
 
 
-def training_batches(dataset, ims_per_batch: int, seed: int = 0, shuffle: bool = True, collate: Optional[Callable] = None) -> Iterator[List]:
+class _TrainingSampler(torch.utils.data.Sampler):
+    """`training_sampler` as a torch Sampler object (what `DataLoader(sampler=TrainingSampler(len(t_loader)))` is handed, :552)."""
+
+    def __init__(self, size: int, seed: int = 0, shuffle: bool = True):
+        self.size, self.seed, self.shuffle = size, seed, shuffle
+
+    def __iter__(self):
+        return training_sampler(self.size, self.seed, self.shuffle)
+
+
+def training_batches(dataset, ims_per_batch: int, seed: int = 0, shuffle: bool = True, collate: Optional[Callable] = None,
+                     workers: int = 0) -> Iterator[List]:
     """The DataLoader of `train_mp3d.py:563-572`: `ims_per_batch` episodes per iteration drawn by `training_sampler`, collated by
-    `collate_smnet` (a list of episodes; an episode is the loader's list of frame records)."""
+    `collate_smnet` (a list of episodes; an episode is the loader's list of frame records).  `workers` > 0: the reference's own
+    arrangement -- a torch DataLoader with that many forked worker PROCESSES reading and decoding episodes ahead (`num_workers=2`,
+    `multiprocessing_context='fork'`, `drop_last`, :563-572); the batches and their order are those of `workers = 0` (the workers
+    touch files and host memory only, never the GPU)."""
     if ims_per_batch < 1 or len(dataset) < 1:
         raise ValueError("training needs at least one episode per batch and a non-empty dataset")
+    if workers > 0:
+        dl = torch.utils.data.DataLoader(dataset, batch_size=ims_per_batch, num_workers=int(workers), drop_last=True,
+                                         sampler=_TrainingSampler(len(dataset), seed, shuffle), multiprocessing_context="fork",
+                                         collate_fn=collate if collate is not None else (lambda b: list(b)), pin_memory=False)
+        yield from dl
+        return
     it = training_sampler(len(dataset), seed, shuffle)
     while True:
         batch = [dataset[next(it)] for _ in range(ims_per_batch)]

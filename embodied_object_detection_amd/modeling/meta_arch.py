@@ -484,6 +484,13 @@ class CustomRCNNRecurrent:
         if self.prefetch_trunk and self.overlap_branches and len(ahead) < min(depth, PYRAMID_SETS - 2):
             room = PYRAMID_SETS - 2 - len(ahead)
             batch = coming[len(ahead):len(ahead) + min(max(1, int(self.lookahead_frames)), room)]
+            # one pass = one image size (the N = 2 pass stacks the images); a frame of another size starts its own pass later
+            n_same = 0
+            for f in batch:
+                if tuple(f["image"].shape) != tuple(batch[0]["image"].shape):
+                    break
+                n_same += 1
+            batch = batch[:n_same]
         next_frame = batch if batch else None
         look_ahead = next_frame is not None
         first_ahead = len(ahead)

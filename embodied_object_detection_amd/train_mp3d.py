@@ -120,7 +120,9 @@ def do_train(cfg, args, rank: int, world: int):
         clip_path = cfg.MODEL.ROI_BOX_HEAD.ZEROSHOT_WEIGHT_PATH if cfg.MODEL.MEMORY_TYPE in ("semantic_gt", "map_gt") else None
         loader = SMNetDetectionLoader(data_path=data_root, clip_path=clip_path, memory_type=cfg.MODEL.MEMORY_TYPE,
                                       semmap_path=str(cfg.MODEL.SEMMAP_PATH))
-        batches, map_batch = train_loop.training_batches(loader, ims, seed=0, collate=collate_smnet), map_mp3d_batch_to_coco
+        # the reference's DataLoader: two forked worker processes read and decode the episodes ahead (train_mp3d.py:563-572)
+        batches = train_loop.training_batches(loader, ims, seed=0, collate=collate_smnet, workers=int(cfg.DATALOADER.NUM_WORKERS_TRAIN_MP3D))
+        map_batch = map_mp3d_batch_to_coco
     else:
         from .data.synthetic import SyntheticTrainingEpisodes
         H, W = args.synthetic_size

@@ -455,6 +455,21 @@ def test_roi_align_backward_matches_autograd():
     ops.roi_align_backward(d2[0], d2[1], d2[2], shapes[0][0], shapes[0][1], Cc, boxes.to(dev), torch.zeros_like(count), R, 7,
                            Gs[7].permute(0, 2, 3, 1).contiguous().to(dev))
     assert all(float(t.abs().max()) == 0.0 for t in d2)
+    # the gather form has no atomics: a crowd of overlapping ROIs (the training step's 512 sampled rows pile up on the objects) gives
+    # bitwise the same gradient on every run, and the same numbers as the footprint / sample forms up to summation order
+    gg = torch.Generator().manual_seed(72)
+    R2, C2 = 512, 256
+    ctr = torch.tensor([[200.0, 180.0], [420.0, 300.0], [90.0, 400.0]])[torch.randint(0, 3, (R2,), generator=gg)] + torch.randn((R2, 2), generator=gg) * 25
+    half = torch.exp(torch.rand((R2, 2), generator=gg) * 2.2 + 2.2)                 # 9 .. 80 px half extents: levels 3 and 4
+    crowd = torch.cat([ctr - half, ctr + half], dim=1).contiguous().to(dev)
+    G7 = torch.randn((R2, 7, 7, C2), generator=gg).to(dev)
+    cnt2 = torch.tensor([R2], dtype=torch.int32, device=dev)
+    runs = []
+    for _ in range(2):
+        dd = [torch.zeros((h, w, C2), device=dev) for h, w in shapes]
+        ops.roi_align_backward(dd[0], dd[1], dd[2], shapes[0][0], shapes[0][1], C2, crowd, cnt2, R2, 7, G7)
+        runs.append(dd)
+    assert all(torch.equal(a, b) for a, b in zip(*runs)) and float(runs[0][0].abs().max()) > 0 and float(runs[0][1].abs().max()) > 0
 
 
 def _raw_from_reg(reg_pred, scales, off, g):

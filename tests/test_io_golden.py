@@ -249,3 +249,24 @@ def test_do_train_matches_the_reference_loop(golden_dir, root):
         assert tests == want["do_test_after_rows"], name
         assert logged == want["writer_after_rows"], name
         assert model.training == want["training"], name
+
+
+def test_training_loader_worker_processes_give_the_same_batches(root):
+    """`training_batches(..., workers=2)`: the reference's DataLoader arrangement (two forked worker processes, drop_last, collate_smnet,
+    TrainingSampler; train_mp3d.py:552-572) yields the batches of the in-process iterator, in the same order."""
+    from embodied_object_detection_amd.data.mp3d import SMNetDetectionLoader, collate_smnet
+    from embodied_object_detection_amd.engine import train_loop
+    loader = SMNetDetectionLoader(data_path=root, memory_type="implicit_memory", semmap_path="")
+    a = train_loop.training_batches(loader, 2, seed=7, collate=collate_smnet)
+    b = train_loop.training_batches(loader, 2, seed=7, collate=collate_smnet, workers=2)
+    for _ in range(4):
+        x, y = next(a), next(b)
+        assert len(x) == len(y) == 2
+        for ex, ey in zip(x, y):
+            assert len(ex) == len(ey)
+            for fx, fy in zip(ex, ey):
+                assert fx["sequence_name"] == fy["sequence_name"] and fx["file_name"] == fy["file_name"]
+                assert bool(fx["memory_reset"]) == bool(fy["memory_reset"])
+                assert crc(np.asarray(fx["image"])) == crc(np.asarray(fy["image"]))
+                assert crc(np.asarray(fx["proj_indices"])) == crc(np.asarray(fy["proj_indices"]))
+    del b

@@ -566,6 +566,34 @@ def test_centernet_train_proposals_match_oracle(dev, hw, nms, variant, golden_di
     assert int(c2.item()) == n and torch.equal(b2[:n], b[:n])
 
 
+def test_centernet_train_proposals_batch_of_two_equals_single_scenes(dev):
+    """The wide path with `batch` = 2 (every buffer = two single-scene buffers back to back, the head rows level major over the
+    scenes): each scene's list is bitwise the list of its own single-scene call."""
+    from embodied_object_detection_amd import ops
+    level_hw = _pyramid_hw(384, 512)
+    scales = [0.9, 1.0, 1.1, 1.2, 0.8]
+    pre, post, cap = 4000, 2000, 2048
+    heads, singles = [], []
+    for b in range(2):
+        agn, reg = _head_case(level_hw, seed=40 + b)
+        head = torch.cat([torch.cat([nhwc(a).reshape(-1, 1), nhwc(r).reshape(-1, 4)], dim=1) for a, r in zip(agn, reg)]).contiguous()
+        heads.append(head)
+        dec = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, scales, 1e-4, pre, post, 0.9, cap=cap, device=dev)
+        bx, sc, c = dec(head.to(dev))
+        n = int(c.item())
+        singles.append((bx[:n].clone(), sc[:n].clone(), n))
+    off = [0]
+    for (h, w) in level_hw:
+        off.append(off[-1] + h * w)
+    both = torch.cat([torch.cat([heads[b][off[l]:off[l + 1]] for b in range(2)]) for l in range(5)]).contiguous()
+    dec2 = ops.ProposalDecoder(level_hw, M.FPN_STRIDES, scales, 1e-4, pre, post, 0.9, cap=cap, device=dev, batch=2)
+    bx, sc, c = dec2(both.to(dev))
+    for b in range(2):
+        n = int(c[b].item())
+        assert n == singles[b][2] and n >= post
+        assert torch.equal(bx[b * cap:b * cap + n], singles[b][0]) and torch.equal(sc[b * cap:b * cap + n], singles[b][1])
+
+
 def test_centernet_proposals_keep_ties(dev):
     from embodied_object_detection_amd import ops
     level_hw = [(12, 12), (6, 6), (3, 3), (2, 2), (1, 1)]

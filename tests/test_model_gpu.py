@@ -547,6 +547,24 @@ def test_deep_trunk_lookahead_gives_identical_results(synthetic_sd):
             assert torch.equal(x.pred_masks, y.pred_masks), (batch, depth)
 
 
+def test_lookahead_over_frames_of_two_sizes(synthetic_sd):
+    """An episode list whose frames change size (a look-ahead pass stacks images: one pass = one size): the list call equals the
+    frame-by-frame calls, bit for bit."""
+    from embodied_object_detection_amd import build_model
+    a_frames, _ = _frames(128, 160, 3, 24, 24)
+    b_frames, _ = _frames(96, 128, 3, 24, 24, seed=5)
+    frames = a_frames + b_frames
+    ref = build_model(_cfg(), synthetic_sd)
+    ref.prefetch_trunk = False
+    ra = [ref([[f]])[0]["instances"] for f in frames]
+    m = build_model(_cfg(), synthetic_sd)
+    rb = [o["instances"] for o in m([frames])]
+    assert torch.equal(ref.implicit_memory, m.implicit_memory) and torch.equal(ref.observations, m.observations)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor) and torch.equal(x.scores, y.scores)
+        assert torch.equal(x.pred_masks, y.pred_masks)
+
+
 def test_detection_pass_position_and_snapshot_mode_change_nothing(setup):
     """Where the deferred detection pass may start (behind the cascade / the proposal masks / the memory write) and how the fp16
     snapshot is kept current (write-through rows or a normalise launch at the next frame) are scheduling choices: an episode gives

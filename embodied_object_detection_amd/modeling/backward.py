@@ -20,9 +20,11 @@ from .backbone import CustomRecurrentFPN
 
 
 class BackboneBackward:
-    def __init__(self, backbone: CustomRecurrentFPN, merge_weights: Optional[List[torch.Tensor]] = None):
+    def __init__(self, backbone: CustomRecurrentFPN, merge_weights: Optional[List[torch.Tensor]] = None, side_stream: bool = False):
         """`merge_weights`: the three `backbone.map_merge_projection{1,2,3}.weight` tensors ([256,512,1,1] fp32 masters), needed
-        only when the forward runs with a memory."""
+        only when the forward runs with a memory.  `side_stream`: the layers' weight-gradient launches go to a second stream
+        (`ops.ConvBackward`); the caller joins it (`ops.ConvBackward.join`) before it reads a dW / db."""
+        self.side = bool(side_stream)
         if backbone.feat_fusion not in ("sum", "image_only"):
             raise ValueError("the backbone's backward covers MAP_FEAT_FUSION sum / image_only (mem_only has no image gradient)")
         self.bb = backbone
@@ -33,7 +35,7 @@ class BackboneBackward:
 
     def _b(self, conv: ops.Conv) -> ops.ConvBackward:
         if id(conv) not in self._bw:
-            self._bw[id(conv)] = ops.ConvBackward(conv)
+            self._bw[id(conv)] = ops.ConvBackward(conv, side_stream=self.side)
         return self._bw[id(conv)]
 
     # ---- forward that keeps its activations -------------------------------------------------------------------------------

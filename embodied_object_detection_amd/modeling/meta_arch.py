@@ -155,7 +155,7 @@ class CustomRCNNRecurrent:
         # waits for them: the look-ahead is a second critical chain.  A deeper window decouples it: a pass is started while frames
         # are still ahead and has several frame periods to finish (only its throughput matters, and N = 2 passes cost 24 % less per
         # image).  None = lookahead_frames (the round-3 schedule).  Measured at 640x640 (tools/knob_ab.py, one call): batch 1 /
-        # window 1 287 frames/s, 1 / 2 287, 2 / 3 301, 2 / 4 299.
+        # window 1 287 frames/s, 1 / 2 287, 2 / 3 301, 2 / 4 300, 3 / 5 297, 4 / 6 295 (the last two with eight pyramid sets).
         self.lookahead_depth: Optional[int] = 3
         self._ahead: List[dict] = []        # frames computed (or being computed) ahead, in order: image, Hp, Wp, event
         self.front_event: Optional[torch.cuda.Event] = None      # one-stream schedule only: recorded after the box cascade

@@ -17,9 +17,14 @@ from .backward import BackboneBackward
 
 
 class ProposalTraining:
-    def __init__(self, model, sd: Dict[str, torch.Tensor]):
-        """`model`: the built `CustomRCNNRecurrent`; `sd`: its state dict (fp32 masters of the parameters the step differentiates)."""
+    def __init__(self, model, sd: Dict[str, torch.Tensor], side_stream: bool = False):
+        """`model`: the built `CustomRCNNRecurrent`; `sd`: its state dict (fp32 masters of the parameters the step differentiates).
+        `side_stream`: the weight-gradient launches run on a second stream beside the dgrad chain (`ops.ConvBackward`); joined at
+        the end of `forward_backward`.  Measured at 640x640 (tools/train_step_bench.py, same call): the whole step 15.6 ms either
+        way, the proposal half 14.0 against 10.9 ms -- two events and four `record_stream` calls per layer cost the host more than
+        the overlap gives a step whose kernels already fill the chip: off."""
         self.model = model
+        self.side = bool(side_stream)
         self.dev = model.device
         self.pg = model.proposal_generator
         c = model.cfg.MODEL.CENTERNET
@@ -30,7 +35,7 @@ class ProposalTraining:
             raise NotImplementedError("proposal losses: LOC_LOSS_TYPE giou, NOT_NORM_REG, no MORE_POS / NO_REDUCE (the recurrent yaml)")
         self.target_cfg = dict(strides=list(c.FPN_STRIDES), sizes_of_interest=[tuple(x) for x in c.SOI],
                                hm_min_overlap=float(c.HM_MIN_OVERLAP), min_radius=float(c.MIN_RADIUS))
-        self.bb = BackboneBackward(model.backbone, [sd[f"backbone.map_merge_projection{i}.weight"] for i in (1, 2, 3)])
+        self.bb = BackboneBackward(model.backbone, [sd[f"backbone.map_merge_projection{i}.weight"] for i in (1, 2, 3)], side_stream=self.side)
         h = "proposal_generator.centernet_head"
         w = torch.zeros((32, 256, 3, 3))
         b = torch.zeros((32,))
@@ -45,14 +50,15 @@ class ProposalTraining:
     def _conv_bwd(self, conv: ops.Conv, xin: torch.Tensor, gout: torch.Tensor, shapes, off):
         """Backward of a level-shared conv over the pyramid row list: per level on that level's grid, dW / db summed over the levels."""
         if id(conv) not in self._bw:
-            self._bw[id(conv)] = ops.ConvBackward(conv)
+            self._bw[id(conv)] = ops.ConvBackward(conv, side_stream=self.side)
         bwd = self._bw[id(conv)]
         dw = db = None
         dxs = []
         for l, (h, w) in enumerate(shapes):
             o = bwd(xin[off[l]:off[l + 1]].view(1, h, w, conv.Cin), None, gout[off[l]:off[l + 1]].view(1, h, w, conv.Cout))
-            dw = o["dw"] if dw is None else dw.add_(o["dw"])
-            db = o["db"] if db is None else db.add_(o["db"])
+            with ops.ConvBackward.on_side(self.dev, self.side):      # the sums over the levels follow the launches they read
+                dw = o["dw"] if dw is None else dw.add_(o["dw"])
+                db = o["db"] if db is None else db.add_(o["db"])
             dxs.append(o["dx"].reshape(-1, conv.Cin))
         return torch.cat(dxs), dw, db
 
@@ -105,7 +111,7 @@ class ProposalTraining:
         prod = (d_head[:, 1:5] * head[:, 1:5]).sum(dim=1)
         grads["scales"] = torch.stack([prod[off[l]:off[l + 1]].sum() / pg.scales[l] for l in range(len(shapes))])
         gx, dw, db = self._conv_bwd(self.out32, x, d_head, shapes, off)
-        grads["agn_hm"] = (dw[0:1], db[0:1])
+        grads["agn_hm"] = (dw[0:1], db[0:1])                          # views: no device work
         grads["bbox_pred"] = (dw[1:5], db[1:5])
         for i in reversed(range(len(pg.tower))):
             conv, gamma, beta = pg.tower[i]
@@ -120,6 +126,8 @@ class ProposalTraining:
                 dP[l] = (dP[l] + d.view(dP[l].shape)).contiguous()
         bgrads, _ = self.bb.backward(saved, dP)
         grads.update(bgrads)
+        if self.side:
+            ops.ConvBackward.join(self.dev)                           # the weight gradients ran on their own stream (ops.ConvBackward)
         return losses, grads
 
 
@@ -325,9 +333,10 @@ class DetectorTraining:
     loss gradients w.r.t. the predictor outputs (d scores, d deltas) and keeps the activations a backward pass needs.  The
     proposals are an input (`ForwardModelTraining.train_proposals` decodes them with PRE / POST_NMS_TOPK_TRAIN 4000 / 2000)."""
 
-    def __init__(self, model):
+    def __init__(self, model, side_stream: bool = False):
         cfg = model.cfg
         self.model, self.dev, self.rh = model, model.device, model.roi_heads
+        self.side = bool(side_stream)                  # weight gradients on a second stream (`ops.ConvBackward`), joined in `backward`
         rhc, rb = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
         self.ious = tuple(float(v) for v in cfg.MODEL.ROI_BOX_CASCADE_HEAD.IOUS)
         if len(self.ious) != self.rh.num_stages or self.ious[0] != float(rhc.IOU_THRESHOLDS[0]):
@@ -435,11 +444,13 @@ class DetectorTraining:
 
     def _conv_bw(self, conv: ops.Conv) -> ops.ConvBackward:
         if id(conv) not in self._bw:
-            self._bw[id(conv)] = ops.ConvBackward(conv)
+            self._bw[id(conv)] = ops.ConvBackward(conv, side_stream=self.side)
         return self._bw[id(conv)]
 
-    def backward(self, P: Sequence[torch.Tensor]):
-        """Gradients of the sum of the stage losses of the last `losses()` call -> ({layer name: (dW packed [Cout, K], db)} for the
+    def backward(self, P: Sequence[torch.Tensor], join: bool = True):
+        """`join=False` (inside `ForwardModelTraining`): the caller joins the weight gradients' stream at the end of the whole backward.
+
+        Gradients of the sum of the stage losses of the last `losses()` call -> ({layer name: (dW packed [Cout, K], db)} for the
         five linear layers of every stage, [dP3, dP4, dP5] as [h,w,256]).  Per stage: d logits -> normalize / class matrix
         (`eod_zs_logits_backward`) -> cls_score.linear; d deltas -> bbox_pred.2 -> ReLU -> bbox_pred.0; both into fc2 -> fc1 -> the
         pooled features x 1 / num_stages (`_ScaleGradient`, detic_roi_heads.py:334) -> ROIAlign backward, added over the stages.  The
@@ -457,7 +468,8 @@ class DetectorTraining:
             g32 = torch.zeros((B, 1, 1, 32), dtype=torch.float32, device=self.dev)
             g32[:, 0, 0, :4] = rec["d_deltas"] * self.box_w
             o = self._conv_bw(self.bb2_32[k])(rec["hb"], None, g32)
-            grads[st["bb2"].name] = (o["dw"][:4].contiguous(), o["db"][:4].contiguous())
+            with ops.ConvBackward.on_side(self.dev, self.side):
+                grads[st["bb2"].name] = (o["dw"][:4].contiguous(), o["db"][:4].contiguous())
             o = self._conv_bw(st["bb0"])(rec["h2"], rec["hb"], o["dx"], relu=True)
             grads[st["bb0"].name] = (o["dw"], o["db"])
             d_h2 = d_h2 + o["dx"]
@@ -467,6 +479,8 @@ class DetectorTraining:
             grads[st["fc1"].name] = (o["dw"], o["db"])
             d_pool = (o["dx"].view(B, 7, 7, 256) * (1.0 / rh.num_stages)).contiguous()
             ops.roi_align_backward(dP[0], dP[1], dP[2], h3, w3, 256, rec["boxes"], None, B, 7, d_pool)
+        if join and self.side:
+            ops.ConvBackward.join(self.dev)
         return grads, dP
 
 
@@ -540,7 +554,7 @@ class ForwardModelTraining:
                 props, count = self.train_proposals(head, shapes)
             self._last_props = (props.clone(), None if count is None else count.clone())
             losses = det.losses(P[:3], props, gt_boxes, gt_classes, (H, W), keys=keys, generator=generator, prop_count=count)
-            grads, dP = det.backward(P[:3])
+            grads, dP = det.backward(P[:3], join=False)
             return losses, grads, dP
         out = self.prop.forward_backward(image_u8, gt_boxes, memory=memory, world_size=world_size, reduce_counts=reduce_counts,
                                          roi_half=roi_half)

@@ -614,10 +614,49 @@ class ConvBackward:
     weights; dw / db = `eod_conv2d_backward_weights`."""
 
     _workspace: Dict = {}      # per device: partial sums of the position-split weight gradient (stream-ordered reuse)
+    # The weight gradients are side outputs of the backward chain (only the optimizer reads them), the input gradients ARE the chain:
+    # with `side_stream` every dW / db launch goes to a second stream behind an event of the main one and runs beside the next
+    # layers' dgrad convs (the training step is one stream of ~30 us kernels otherwise).  Whoever reads a dW on the main stream calls
+    # `join(device)` first -- or does its own small ops inside `on_side(device)`.  Per instance (`ConvBackward(conv, side_stream=True)`):
+    # off by default, `modeling.training` switches it on for the layers of its steps.
+    _side: Dict = {}           # per device: [stream, event recorded behind the last side launch]
 
-    def __init__(self, conv: "Conv"):
+    @classmethod
+    def _side_state(cls, dev):
+        key = torch.device(dev).index or 0
+        st = cls._side.get(key)
+        if st is None:
+            st = cls._side[key] = [torch.cuda.Stream(device=dev), None]
+        return st
+
+    @classmethod
+    def join(cls, dev) -> None:
+        """The current stream waits for every weight-gradient launch (and `on_side` op) issued so far."""
+        st = cls._side.get(torch.device(dev).index or 0)
+        if st is not None and st[1] is not None:
+            torch.cuda.current_stream(dev).wait_event(st[1])
+
+    @classmethod
+    def on_side(cls, dev, enabled: bool = True):
+        """Context: torch ops on weight gradients (slices, level sums) ordered on the side stream, behind what is there already."""
+        import contextlib
+        if not enabled:
+            return contextlib.nullcontext()
+        st = cls._side_state(dev)
+
+        @contextlib.contextmanager
+        def ctx():
+            with torch.cuda.stream(st[0]):
+                yield
+                ev = torch.cuda.Event()
+                ev.record(st[0])
+                st[1] = ev
+        return ctx()
+
+    def __init__(self, conv: "Conv", side_stream: bool = False):
         if conv.out_mode != 0:
             raise ValueError("ConvBackward covers plain convolutions (no deconv)")
+        self.side_stream = bool(side_stream)
         # stride-1 'same' layers: dX on the matrix cores (eod_conv2d with rotated weights); anything else: the gather kernel
         self.same = conv.stride == 1 and conv.KH == conv.KW and conv.pad * 2 == conv.KH - 1
         # strided 'same'-padded layers (3x3 s2 p1: P6 / P7 and the trunk's conv2; 1x1 s2: its downsample convs): the gradient is
@@ -660,15 +699,36 @@ class ConvBackward:
             g = torch.empty_like(g_out)
             check(self.lib.eod_relu_backward(g_out.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "eod_relu_backward")
         K = c.KH * c.KW * c.Cin
-        dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
-        db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
         need = self.lib.eod_conv2d_backward_weights_workspace_bytes(N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride)
-        ws = ConvBackward._workspace.get(x.device)
-        if need and (ws is None or ws.numel() * 4 < need):
-            ws = ConvBackward._workspace[x.device] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=x.device)
-        check(self.lib.eod_conv2d_backward_weights_ws(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
-                                                      dw.data_ptr(), db.data_ptr(), ws.data_ptr() if need else None, ws.numel() * 4 if need else 0,
-                                                      _stream()), "eod_conv2d_backward_weights_ws")
+
+        def wgrad():
+            dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
+            db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
+            ws = ConvBackward._workspace.get(x.device)
+            if need and (ws is None or ws.numel() * 4 < need):
+                ws = ConvBackward._workspace[x.device] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=x.device)
+            check(self.lib.eod_conv2d_backward_weights_ws(x.data_ptr(), g.data_ptr(), N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
+                                                          dw.data_ptr(), db.data_ptr(), ws.data_ptr() if need else None,
+                                                          ws.numel() * 4 if need else 0, _stream()), "eod_conv2d_backward_weights_ws")
+            return dw, db
+
+        if self.side_stream:
+            main = torch.cuda.current_stream(x.device)
+            st = ConvBackward._side_state(x.device)
+            ready = torch.cuda.Event()
+            ready.record(main)                           # x and g (the ReLU-masked gradient included) are complete in main's order here
+            st[0].wait_event(ready)
+            with torch.cuda.stream(st[0]):
+                dw, db = wgrad()
+                done = torch.cuda.Event()
+                done.record(st[0])
+                st[1] = done
+            for t in (x, g):
+                t.record_stream(st[0])                   # the caching allocator must not hand their memory out before the side launch ran
+            dw.record_stream(main)
+            db.record_stream(main)
+        else:
+            dw, db = wgrad()
         dx = None
         if need_dx and self.same:
             dx = self._dgrad_conv()(g, N, H, W)

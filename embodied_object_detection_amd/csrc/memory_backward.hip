@@ -422,6 +422,99 @@ __global__ __launch_bounds__(256) void conv_backward_weights_rb_kernel(ConvBwdAr
   }
 }
 
+// LDS-tiled form (round 4, second step): the contraction index of dW = G^T . X is the POSITION, the slow index of both operands, so
+// the register-blocked kernel above still fetches one dword per lane and MFMA and computes an address per operand pair.  Here a
+// workgroup (2 x 2 waves, 64 co x 64 ci of one tap) walks its position range in chunks of 32: the chunk's G rows [32][64] and the
+// tap-shifted, border-masked X rows [32][64] are fetched with two 16-byte loads per thread each (ONE position computation per load)
+// into registers, staged in LDS as they lie ([position][channel]: conflict-free stores), and every MFMA operand is one ds_read_b32
+// (lane = channel, half wave = position parity).  The next chunk's global loads are in flight under the 16 MFMAs of the current one.
+__global__ __launch_bounds__(256) void conv_backward_weights_lds_kernel(ConvBwdArgs a) {
+  constexpr int PK = 32, TC = 64;
+  __shared__ __attribute__((aligned(16))) float As[PK][TC];
+  __shared__ __attribute__((aligned(16))) float Bs[PK][TC];
+  __shared__ float bred[16][TC];
+  const int ci_tiles = (a.Cin + 63) >> 6;
+  const int tile = blockIdx.x;
+  const int co0 = (tile / ci_tiles) * 64, ci0 = (tile % ci_tiles) * 64;
+  const int tap = blockIdx.y;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, kh = lane >> 5;
+  const int P = a.N * a.OH * a.OW;
+  const int chunks = (P + PK - 1) / PK;
+  const int cps = (chunks + a.splits - 1) / a.splits;
+  const int c_begin = blockIdx.z * cps;
+  const int c_end = min(c_begin + cps, chunks);
+  // loader role: thread -> (position row lp + 16 i, four channels c4 .. c4 + 3)
+  const int lp = tid >> 4, c4 = (tid & 15) * 4;
+  const bool g_ok = co0 + c4 < a.Cout, x_ok = ci0 + c4 < a.Cin;          // Cout, Cin are multiples of 32 (and of 4)
+  f32x4 gr[2], xr[2];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pos = c * PK + lp + 16 * i;
+      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      if (pos < P) {
+        if (g_ok) gv = *reinterpret_cast<const f32x4*>(a.g + (size_t)pos * a.Cout + co0 + c4);
+        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * OH + oy
+        const int ox = pos - row * a.OW;
+        const int n = (int)fdiv((unsigned)row, a.div_h);
+        const int oy = row - n * a.OH;
+        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+        if (x_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          xv = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c4);
+      }
+      gr[i] = gv;
+      xr[i] = xv;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  if (c_begin < c_end) load_chunk(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&As[lp + 16 * i][c4]) = gr[i];
+      *reinterpret_cast<f32x4*>(&Bs[lp + 16 * i][c4]) = xr[i];
+      bsum += gr[i];
+    }
+    __syncthreads();
+    if (c + 1 < c_end) load_chunk(c + 1);
+    const float* ap = &As[kh][wm * 32 + r];
+    const float* bp = &Bs[kh][wn * 32 + r];
+#pragma unroll
+    for (int kk = 0; kk < PK / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * 2 * TC], bp[kk * 2 * TC], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // C/D layout: column (ci) = lane & 31, row (co) = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+  const int Ktot = a.KH * a.KW * a.Cin;
+  float* dw = a.splits > 1 ? a.part + (size_t)blockIdx.z * a.Cout * Ktot : a.dw;
+  float* db = a.splits > 1 ? a.bpart + (size_t)blockIdx.z * a.Cout : a.db;
+  const int ci = ci0 + wn * 32 + r;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      if (co < a.Cout) dw[(size_t)co * Ktot + (size_t)tap * a.Cin + ci] = acc[q];
+    }
+  }
+  if (a.db && tap == 0 && (tile % ci_tiles) == 0) {
+    // db[co] = sum over the positions: the 16 loader rows' sums, added in row order
+    bred[lp][c4 + 0] = bsum.x; bred[lp][c4 + 1] = bsum.y; bred[lp][c4 + 2] = bsum.z; bred[lp][c4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < TC && co0 + tid < a.Cout) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += bred[q][tid];
+      db[co0 + tid] = v;
+    }
+  }
+}
+
 // dW / db = the partial results of the position ranges added in range order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dw,
                                                            float* __restrict__ db, size_t n, int Cout, int splits) {
@@ -697,6 +790,15 @@ static bool wgrad_register_blocked() {
   return on;
 }
 
+// EOD_WGRAD_LDS=0 falls back to the register-blocked kernel (same-box A/B; read once)
+static bool wgrad_lds() {
+  static const bool on = [] {
+    const char* e = getenv("EOD_WGRAD_LDS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   const long P = (long)N * OH * OW;
@@ -705,7 +807,7 @@ static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, 
                    : wgrad_register_blocked() ? (long)((Cout + 63) >> 6) * ((Cin + 63) >> 6) * KH * KW        // 64 x 64 register blocks
                                               : (long)(Cout >> 5) * (Cin >> 5) * KH * KW;
   long s = tap4_scalar ? 16 : (768 + wgs - 1) / wgs;
-  const long cap = tap4_scalar ? P / 2048 : (P + 7) / 8 / 16;
+  const long cap = tap4_scalar ? P / 2048 : (Cin != 4 && wgrad_lds() ? (P + 31) / 32 / 4 : (P + 7) / 8 / 16);
   if (s > cap) s = cap;
   if (s > 64) s = 64;
   return s < 1 ? 1 : (int)s;
@@ -740,6 +842,9 @@ static int conv2d_backward_weights_impl(const float* x, const float* g, int N, i
     hipLaunchKernelGGL(conv_backward_weights_tap4_mfma_kernel, dim3((Cout >> 5) * KH, 1, a.splits), dim3(256), 0, (hipStream_t)stream, a);
   else if (Cin == 4)
     hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4, a.splits), dim3(1024), 0, (hipStream_t)stream, a);
+  else if (wgrad_lds())
+    hipLaunchKernelGGL(conv_backward_weights_lds_kernel, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
+                       (hipStream_t)stream, a);
   else if (wgrad_register_blocked())
     hipLaunchKernelGGL(conv_backward_weights_rb_kernel, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
                        (hipStream_t)stream, a);

@@ -39,7 +39,7 @@ class EodConvDesc(C.Structure):
         ("out_scale", C.c_float), ("levels", C.c_int32), ("level_off", C.c_int32 * (MAX_LEVELS + 1)), ("level_h", C.c_int32 * MAX_LEVELS),
         ("level_w", C.c_int32 * MAX_LEVELS), ("fuse_w", C.c_void_p), ("out_units", C.c_void_p), ("fuse_b", C.c_float), ("w_split", C.c_void_p),
         ("plan_rows", C.c_int32), ("lds_reserve", C.c_int32), ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
-        ("y2", C.c_void_p), ("split_n", C.c_int32), ("prefetch2", C.c_int32),
+        ("y2", C.c_void_p), ("split_n", C.c_int32), ("prefetch2", C.c_int32), ("gate", C.c_void_p),
     ]
 
 
@@ -102,7 +102,12 @@ class EodStageTailDesc(C.Structure):
 class EodAdamWTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t),
                 ("lr", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("folded_out", C.c_void_p), ("row_scale", C.c_void_p),
-                ("cols", C.c_int32), ("ld_out", C.c_int32)]
+                ("cols", C.c_int32), ("ld_out", C.c_int32), ("grad_of_folded", C.c_int32)]
+
+
+class EodRotateTensor(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("Cin", C.c_int32),
+                ("ld_in", C.c_int32), ("ld_out", C.c_int32)]
 
 
 class EodMemWriteDesc(C.Structure):
@@ -198,6 +203,7 @@ SIGNATURES = {
     "eod_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, C.c_int, C.c_double, C.c_void_p]),
     "eod_conv_rotate_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "eod_conv_rotate_weights_multi": (C.c_int, [C.POINTER(EodRotateTensor), C.c_int, C.c_void_p]),
     "eod_adamw_step_multi": (C.c_int, [C.POINTER(EodAdamWTensor), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "eod_memory_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),

@@ -13,6 +13,7 @@ struct ConvArgs {
   const float* w;
   const float* bias;
   const float* res;
+  const float* gate;        // optional [M][Cout]: the stored value is 0 where gate <= 0 (EodConvDesc.gate: backward of a ReLU)
   float* y;
   float* partial;
   const int* m_count;
@@ -104,6 +105,7 @@ __device__ __forceinline__ float epilogue_store(const ConvArgs& p, float v, int 
     return v;
   }
   if (p.relu) v = fmaxf(v, 0.0f);
+  if (p.gate && !(p.gate[oidx] > 0.0f)) v = 0.0f;
   p.y[oidx] = v;
   return v;
 }

@@ -311,6 +311,7 @@ int check_desc(const EodConvDesc* d) {
       return EOD_ERR_BAD_DIMS;
     if (((long)(d->N / d->m_segments) * d->OH * d->OW) % d->m_unit != 0) return EOD_ERR_BAD_DIMS;
   }
+  if (d->gate && (d->out_mode != 0 || d->split_n != 0 || d->gn_partial)) return EOD_ERR_BAD_DIMS;
   if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;
   if (d->split_n != 0) {
     if (!d->y2) return EOD_ERR_NULL;
@@ -399,6 +400,7 @@ extern "C" int eod_conv2d(const EodConvDesc* d, eod_stream_t stream) {
   }
   if (a.nlv) a.lv_off[a.nlv] = d->level_off[a.nlv];
   a.relu = d->relu; a.res_mode = d->res_mode; a.in_relu = d->in_relu; a.out_mode = d->out_mode;
+  a.gate = d->gate;
   a.out_scale = d->out_scale;
   a.gn_partial = d->gn_partial;
   a.gn_groups = d->gn_groups;

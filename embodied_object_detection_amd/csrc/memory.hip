@@ -358,6 +358,28 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_cover_kernel(const float* boxes
   if (bad && err) atomicOr(err, EOD_FLAG_BAD_CELL_INDEX);
 }
 
+// Entry `key` of the frame's tables: key >= 0 is weight-table entry wtab[key] (= cell * K_cap + instance), key <= -2 the sample
+// count of cell -key - 2.
+#define MW_AGG 512
+__device__ __forceinline__ void mw_table_add(int key, unsigned long long v, long long* wtab, int* cell_cnt) {
+  if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(wtab + key), v);
+  else atomicAdd(cell_cnt + (-key - 2), (int)v);
+}
+// ... summed in the workgroup's LDS table first (open addressing, 8 probes; a crowded table sends the share straight to memory)
+__device__ __forceinline__ void mw_agg_add(int* key_s, unsigned long long* val_s, int key, unsigned long long v, long long* wtab,
+                                           int* cell_cnt) {
+  unsigned h = ((unsigned)key * 2654435761u) >> (32 - 9);
+  for (int probe = 0; probe < 8; ++probe) {
+    const int old = atomicCAS(&key_s[h], -1, key);
+    if (old == -1 || old == key) {
+      atomicAdd(&val_s[h], v);
+      return;
+    }
+    h = (h + 1) & (MW_AGG - 1);
+  }
+  mw_table_add(key, v, wtab, cell_cnt);
+}
+
 // Launch 2.  The per-cell mean of the per-pixel means (custom_rcnn.py:884-936) is linear in the instance features:
 //   mean_cell = (1 / n_cell) * sum_k W[cell][k] * f_k,   W[cell][k] = sum over the cell's sampled pixels covered by k of 1 / cover(p)
 // so a sampled pixel contributes ONE scalar per covering instance (2^-32 fixed point, integer atomics: order independent,
@@ -402,6 +424,15 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* box
   // against ~40 candidates were a serial chain on one lane in eight), the hit sets are OR-ed over the eight lanes.
   __shared__ int samp_s[SCAN_ELEMS / 8];
   __shared__ int nsamp_s;
+  // The block's shares are summed in LDS first, keyed by their table entry: its <= 128 sampled pixels lie on one or two image rows
+  // and neighbours fall into the same cell, so the ~250 shares of a block are a few dozen distinct entries -- and the scatter pass
+  // is bound by its integer atomics on ~800 cells' rows in memory.  Integer sums: the order does not matter, bitwise as before.
+  __shared__ int key_s[MW_AGG];
+  __shared__ unsigned long long val_s[MW_AGG];
+  for (int i = threadIdx.x; i < MW_AGG; i += blockDim.x) {
+    key_s[i] = -1;
+    val_s[i] = 0ull;
+  }
   if (threadIdx.x == 0) nsamp_s = 0;
   __syncthreads();
   {
@@ -414,7 +445,7 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* box
   }
   __syncthreads();
   const int slot = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  if (slot >= nsamp_s) return;              // uniform over the 8 lanes of a slot; no barrier follows
+  if (slot < nsamp_s) {                     // uniform over the 8 lanes of a slot
   const int sp = samp_s[slot];
   const int y = sp / W, x = sp - y * W;
   const float fxp = (float)x + 0.5f, fyp = (float)y + 0.5f;
@@ -439,18 +470,23 @@ __global__ __launch_bounds__(SCAN_ELEMS) void mw_scatter_kernel(const float* box
   }
   const int ncov = __popcll(hit0) + __popcll(hit1);          // >= 1: the pixel is observed
   const unsigned long long share = (unsigned long long)llrint(4294967296.0 / (double)ncov);
-  long long* dst = wtab + (size_t)cell * K_cap;
-  if (sub == 0) atomicAdd(cell_cnt + cell, 1);
+  if (sub == 0) mw_agg_add(key_s, val_s, -(cell + 2), 1ull, wtab, cell_cnt);
   unsigned long long m0 = mine0, m1 = mine1;
   while (m0) {
     const int i = (int)__ffsll((long long)m0) - 1;
     m0 &= m0 - 1;
-    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[i]), share);
+    mw_agg_add(key_s, val_s, cell * K_cap + cand_s[i], share, wtab, cell_cnt);
   }
   while (m1) {
     const int i = (int)__ffsll((long long)m1) - 1;
     m1 &= m1 - 1;
-    atomicAdd(reinterpret_cast<unsigned long long*>(dst + cand_s[64 + i]), share);
+    mw_agg_add(key_s, val_s, cell * K_cap + cand_s[64 + i], share, wtab, cell_cnt);
+  }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < MW_AGG; i += blockDim.x) {
+    const int k = key_s[i];
+    if (k != -1) mw_table_add(k, val_s[i], wtab, cell_cnt);
   }
 }
 
@@ -604,6 +640,7 @@ extern "C" int eod_memory_write_init(void* workspace, size_t workspace_bytes, in
   // (workspace_bytes >= B x the single-scene size) is initialised scene by scene.
   if (!workspace) return EOD_ERR_NULL;
   if (K_cap <= 0 || K_cap > MW_MAX_K || R_cap <= 0 || R_cap > MW_MAX_R) return EOD_ERR_BAD_DIMS;
+  if (n_cells <= 0 || (long long)n_cells * K_cap >= (1ll << 31)) return EOD_ERR_BAD_DIMS;      // weight-table entries are int keys
   const size_t one = mw_carve(nullptr, H, W, D, n_cells, R_cap, K_cap).bytes;
   if (workspace_bytes < one) return EOD_ERR_CAPACITY;
   for (size_t b = 0; (b + 1) * one <= workspace_bytes && b < EOD_MAX_BATCH; ++b) {

@@ -175,6 +175,7 @@ struct AdamWMulti {
   float* folded[ADAMW_MULTI];
   const float* row_scale[ADAMW_MULTI];
   unsigned cols[ADAMW_MULTI], ld_out[ADAMW_MULTI];
+  unsigned grad_of_folded;             // bit t: g is the gradient of the FOLDED weights (x row_scale = the master's, chain rule)
   int count;
   float one_minus_b1, b2, one_minus_b2, eps, clip;
 };
@@ -193,8 +194,10 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWMulti a) {
   float* __restrict__ folded = a.folded[t];
   const float* __restrict__ rs = a.row_scale[t];
   const unsigned cols = a.cols[t], ldo = a.ld_out[t];
+  const bool gscale = (a.grad_of_folded >> t) & 1u;
   for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
     float gi = g[i];
+    if (gscale) gi *= rs[(unsigned)(i / cols)];
     if (a.clip > 0.f) gi = fminf(fmaxf(gi, -a.clip), a.clip);
     float pi = p[i] * decay;
     float mi = m[i];
@@ -955,6 +958,71 @@ extern "C" int eod_conv_rotate_weights(const float* w, int Cout, int KH, int KW,
   return eod_launch_status();
 }
 
+// The rotation for up to ROTATE_MULTI layers in one launch: after an optimizer step every layer with an input-gradient convolution
+// needs it (74 layers of the recurrent detector: 74 launches of ~9 us were 4 % of the iteration).
+#define ROTATE_MULTI 24
+struct RotateMulti {
+  const float* w[ROTATE_MULTI];
+  float* out[ROTATE_MULTI];
+  int Cout[ROTATE_MULTI], KH[ROTATE_MULTI], KW[ROTATE_MULTI], Cin[ROTATE_MULTI], ld_in[ROTATE_MULTI], ld_out[ROTATE_MULTI];
+  unsigned block_end[ROTATE_MULTI];
+  int count;
+};
+
+// Per tap the rotation is a (co, ci) -> (ci, co) transpose: a workgroup moves one 32 x 32 tile of one tap through LDS, reading rows of
+// w along ci and writing rows of out along co (both coalesced; the element-per-thread form reads with a stride of a weight row).
+__global__ __launch_bounds__(256) void rotate_weights_multi_kernel(RotateMulti a) {
+  __shared__ float tile[32][33];
+  int t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.block_end[t]) ++t;
+  const unsigned b = blockIdx.x - (t ? a.block_end[t - 1] : 0u);
+  const float* __restrict__ w = a.w[t];
+  float* __restrict__ out = a.out[t];
+  const int Cout = a.Cout[t], KH = a.KH[t], KW = a.KW[t], Cin = a.Cin[t], ld_in = a.ld_in[t], ld_out = a.ld_out[t];
+  const unsigned tiles_ci = (unsigned)(Cin + 31) >> 5, tiles_co = (unsigned)(Cout + 31) >> 5;
+  const unsigned tap = b / (tiles_co * tiles_ci), rem = b - tap * tiles_co * tiles_ci;
+  const int co0 = (int)(rem / tiles_ci) * 32, ci0 = (int)(rem % tiles_ci) * 32;
+  const int ky = (int)tap / KW, kx = (int)tap - ky * KW;
+  const int src_tap = (KH - 1 - ky) * KW + (KW - 1 - kx);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+    tile[ty + 8 * j][tx] = (co < Cout && ci < Cin) ? w[(size_t)co * ld_in + (size_t)src_tap * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+    if (ci < Cin && co < Cout) out[(size_t)ci * ld_out + (size_t)tap * Cout + co] = tile[tx][ty + 8 * j];
+  }
+}
+
+extern "C" int eod_conv_rotate_weights_multi(const EodRotateTensor* tensors, int count, eod_stream_t stream) {
+  if (!tensors) return EOD_ERR_NULL;
+  if (count < 1) return EOD_ERR_BAD_DIMS;
+  for (int i = 0; i < count; ++i) {
+    const EodRotateTensor& t = tensors[i];
+    if (!t.w || !t.out) return EOD_ERR_NULL;
+    if (t.Cout <= 0 || t.KH <= 0 || t.KW <= 0 || t.Cin <= 0 || t.ld_in < t.KH * t.KW * t.Cin || t.ld_out < t.KH * t.KW * t.Cout)
+      return EOD_ERR_BAD_DIMS;
+  }
+  for (int i0 = 0; i0 < count; i0 += ROTATE_MULTI) {
+    RotateMulti a{};
+    a.count = std::min(ROTATE_MULTI, count - i0);
+    unsigned blocks = 0;
+    for (int k = 0; k < a.count; ++k) {
+      const EodRotateTensor& t = tensors[i0 + k];
+      a.w[k] = t.w; a.out[k] = t.out;
+      a.Cout[k] = t.Cout; a.KH[k] = t.KH; a.KW[k] = t.KW; a.Cin[k] = t.Cin; a.ld_in[k] = t.ld_in; a.ld_out[k] = t.ld_out;
+      blocks += (unsigned)((size_t)t.KH * t.KW * ((t.Cout + 31) >> 5) * ((t.Cin + 31) >> 5));     // one 32 x 32 tile each
+      a.block_end[k] = blocks;
+    }
+    hipLaunchKernelGGL(rotate_weights_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return eod_launch_status();
+}
+
 extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
                                     eod_stream_t stream) {
   if (!tensors) return EOD_ERR_NULL;
@@ -964,6 +1032,7 @@ extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, do
     if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return EOD_ERR_NULL;
     if (t.n == 0 || t.step < 1 || !(t.lr >= 0.0)) return EOD_ERR_BAD_DIMS;
     if (t.folded_out && (!t.row_scale || t.cols <= 0 || t.ld_out < t.cols || t.n % (size_t)t.cols != 0)) return EOD_ERR_BAD_DIMS;
+    if (t.grad_of_folded && (!t.row_scale || t.cols <= 0 || t.n % (size_t)t.cols != 0)) return EOD_ERR_BAD_DIMS;
   }
   for (int i0 = 0; i0 < count; i0 += ADAMW_MULTI) {
     AdamWMulti a{};
@@ -976,6 +1045,7 @@ extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, do
       const double bc1 = 1.0 - pow(beta1, (double)t.step), bc2 = 1.0 - pow(beta2, (double)t.step);
       a.p[k] = t.param; a.g[k] = t.grad; a.m[k] = t.exp_avg; a.v[k] = t.exp_avg_sq; a.n[k] = t.n;
       a.folded[k] = t.folded_out; a.row_scale[k] = t.row_scale; a.cols[k] = (unsigned)t.cols; a.ld_out[k] = (unsigned)t.ld_out;
+      if (t.grad_of_folded) a.grad_of_folded |= 1u << k;
       a.decay[k] = (float)(1.0 - t.lr * t.weight_decay);
       a.step_size[k] = (float)(t.lr / bc1);
       a.bc2_sqrt[k] = (float)sqrt(bc2);

@@ -101,9 +101,9 @@ class BackboneBackward:
         r = self._b(bb.p7)(x7, None, dP[4].contiguous())
         put(bb.p7, r)
         g6 = dP[3] + self._relu_bw(r["dx"], p6)
-        r = self._b(bb.p6)(P[2].contiguous(), None, g6.contiguous())
+        r = self._b(bb.p6)(P[2].contiguous(), None, g6.contiguous(), dx_res=dP[2].contiguous())    # P5 also feeds P6: both gradients
         put(bb.p6, r)
-        g_out = [dP[0].contiguous(), dP[1].contiguous(), (dP[2] + r["dx"]).contiguous()]      # sum fusion: identity to the image branch
+        g_out = [dP[0].contiguous(), dP[1].contiguous(), r["dx"]]      # sum fusion: identity to the image branch
         if saved["pooled"] is not None:
             # the memory branch of the fusion: dW / db of the map_merge projections (timm.py:170-178)
             if self._merge_bw is None:
@@ -129,32 +129,41 @@ class BackboneBackward:
         self._up_bw(g_lat4, g_lat5, N, h5, w5)
         gc = {}
         for l, cx, gl in ((3, c3, g_lat3), (4, c4, g_lat4), (5, c5, g_lat5)):
-            r = self._b(bb.lateral[l])(cx, None, gl)
+            # c5 feeds its lateral only: the ReLU it came out of is crossed on the way out of that layer's input-gradient launch
+            r = self._b(bb.lateral[l])(cx, None, gl, dx_gate=cx if l == 5 else None)
             put(bb.lateral[l], r)
             gc[l] = r["dx"]
         # trunk, last block first; the exposed stage outputs ('layer3', 'layer4', 'layer5') collect their lateral's gradient
         blocks = bb.bottom_up.blocks
         kept = saved["blocks"]
-        g = gc[5]
+        # gp: gradient of a block's (conv3 + shortcut), i.e. behind its final ReLU.  Inside a block every ReLU's backward and the
+        # shortcut's add ride on the epilogue of the input-gradient convolution that produces the gradient (`dx_gate`, `dx_res`):
+        # three launches per layer pair instead of five, and conv1's launch hands the block below its gated gradient directly.
+        gp = gc[5]
         for bi in range(len(blocks) - 1, -1, -1):
             li, c1, c2, c3b, ds = blocks[bi]
             x_in, o1, o2, y, h, w, h2, w2 = kept[bi]
-            gp = self._relu_bw(g, y)                          # through the block's final ReLU: gradient of (conv3 + shortcut)
-            r = self._b(c3b)(o2, None, gp)
+            r = self._b(c3b)(o2, None, gp, dx_gate=o2)        # gradient of conv2's pre-activation
             put(c3b, r)
-            r2 = self._b(c2)(o1, o2, r["dx"], relu=True)
+            r2 = self._b(c2)(o1, None, r["dx"], dx_gate=o1)   # ... of conv1's
             put(c2, r2)
-            r1 = self._b(c1)(x_in, o1, r2["dx"], relu=True)
-            put(c1, r1)
+            shortcut = gp
             if ds is not None:
                 rd = self._b(ds)(x_in, None, gp)
                 put(ds, rd)
-                g = r1["dx"] + rd["dx"]
-            else:
-                g = r1["dx"] + gp
-            # first block of stage li: its input is stage li-1's output, which the FPN reads as 'layer{li}' (timm.py:379,404)
-            if bi > 0 and blocks[bi - 1][0] != li and li in gc:
+                shortcut = rd["dx"]
+            # first block of stage li: its input is stage li-1's output, which the FPN reads as 'layer{li}' (timm.py:379,404) and
+            # whose gradient therefore has a third term before the ReLU below it is crossed
+            boundary = bi > 0 and blocks[bi - 1][0] != li and li in gc
+            fuse_gate = bi > 0 and not boundary               # x_in is the block below's ReLU output
+            r1 = self._b(c1)(x_in, None, r2["dx"], dx_res=shortcut, dx_gate=x_in if fuse_gate else None)
+            put(c1, r1)
+            g = r1["dx"]
+            if boundary:
                 g = g + gc[li]
+                gp = self._relu_bw(g, x_in)
+            else:
+                gp = g
         g_stem = None
         if need_stem_grad:
             stem_out, hs, ws, pooled, hp, wp = saved["stem"]

@@ -151,6 +151,7 @@ class ProposalTrainer:
         self.entries = []          # (reference parameter name, tensor stepped by AdamW, gradient getter)
         self.after = []            # callables run after every optimizer step
         self.folds = {}            # parameter name -> (layer weights, per-row FrozenBatchNorm scale): re-folded by the optimizer's launch
+        self.raw_getters = {}      # parameter name -> gradient of the FOLDED weights (what the optimizer's launch takes for those)
         base = "backbone.bottom_up.base"
 
         def add(name, tensor, getter):
@@ -164,7 +165,9 @@ class ProposalTrainer:
             scale = (sd[f"{bnp}.weight"].float() / torch.sqrt(sd[f"{bnp}.running_var"].float() + 1e-5)).to(dev).view(-1, 1)
             add(wname, master, lambda g, n=conv.name, s=scale: (g[n][0] * s).contiguous())
             # the optimizer's launch writes the re-folded weights (master x scale) straight into the layer (`AdamW` group key "fold")
+            # and takes the gradient of the folded weights as it comes out of the backward pass (key "grad_of_folded": x scale inside)
             self.folds[wname] = (conv.w, scale.view(-1).contiguous())
+            self.raw_getters[wname] = lambda g, n=conv.name: g[n][0]
 
         trunk_conv(bbm.bottom_up.stem, f"{base}.conv1.weight", f"{base}.bn1", cin_pad=4)
         for (li, c1, c2, c3, ds) in bbm.bottom_up.blocks:
@@ -261,8 +264,9 @@ class ProposalTrainer:
 
         def stale_caches():
             extra = list(self.fm.det._bw.values()) if self.fm is not None else []
-            for bw in list(self.step_fn._bw.values()) + list(self.step_fn.bb._bw.values()) + extra:
-                bw._flipped_of = None                            # rotated weights of the dgrad convs
+            bws = list(self.step_fn._bw.values()) + list(self.step_fn.bb._bw.values()) + extra
+            ops.ConvBackward.refresh_all(bws)                    # rotated weights of the dgrad convs: all layers in 4 launches
+            for bw in bws:
                 bw.conv.w_split = None                           # bf16x3 pieces, if that arithmetic was in use
         self.after.append(stale_caches)
         s = cfg.SOLVER
@@ -283,7 +287,9 @@ class ProposalTrainer:
         for g in self.groups:
             if g["name"] in self.folds:
                 g["fold"] = self.folds[g["name"]]
-        self.getters = {n: f for n, _, f in self.entries}
+                g["grad_of_folded"] = True
+        self.getters = {n: f for n, _, f in self.entries}        # gradient of every stepped tensor (of the raw master for a trunk conv)
+        self.step_getters = {**self.getters, **self.raw_getters}   # what `opt.step` is handed
         clip = s.CLIP_GRADIENTS
         if bool(clip.ENABLED) and str(clip.CLIP_TYPE) != "value":
             raise NotImplementedError("gradient clipping: CLIP_TYPE value (detectron2's default)")
@@ -314,7 +320,7 @@ class ProposalTrainer:
                                                      generator=generator)
         else:
             losses, grads = self.step_fn.forward_backward(image_u8, gt_boxes, memory=memory)
-        self.opt.step([self.getters[g["name"]](grads) for g in self.groups], lr_factor=lr_factor)
+        self.opt.step([self.step_getters[g["name"]](grads) for g in self.groups], lr_factor=lr_factor)
         for f in self.after:
             f()
         self.iteration += 1
@@ -610,7 +616,7 @@ class Trainer(ProposalTrainer):
                     memory = (ops.memory_normalize_f16(mem, obs), proj)
                 losses, grads = self.fm.forward_backward(img, gt_boxes.to(dev).contiguous(), gt_classes.to(dev), memory=memory,
                                                          generator=generator)
-                gl = [self.getters[g["name"]](grads) for g in self.groups]
+                gl = [self.step_getters[g["name"]](grads) for g in self.groups]
                 acc = [t.clone() for t in gl] if acc is None else [a.add_(t) for a, t in zip(acc, gl)]
                 for k, v in losses.items():
                     total[k] = v.clone() if k not in total else total[k] + v

@@ -140,16 +140,18 @@ class Conv:
                  levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None,
                  fuse: Optional[Tuple[torch.Tensor, float, Optional[torch.Tensor]]] = None, presplit: bool = True,
                  plan_rows: int = 0, gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 32,
-                 split: Optional[Tuple[int, torch.Tensor]] = None, m_segments: int = 0) -> torch.Tensor:
+                 split: Optional[Tuple[int, torch.Tensor]] = None, m_segments: int = 0,
+                 gate: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`levels=(row_offsets, [(h, w), ...])` runs the layer once over a whole feature pyramid stored as one row list.
         `split=(n0, out2)`: the layer is two stacked linear layers; columns [0, n0) go to `out` [rows, n0] without the ReLU, columns
         [n0, Cout) to `out2` [rows, Cout - n0] with it (EodConvDesc.split_n).
         `m_segments` = B: the N images are B unit lists back to back, `m_count` holds B counts (EodConvDesc.m_segments).
         `gn_stats` (pyramid mode; the workspace of the `groupnorm_relu` call that follows): when the layer's plan reduces split-K
         slabs, that reduce also writes GroupNorm's partial sums into it and `self.gn_fused` is set (pass it as `partial_ready`).
+        `gate` [N,OH,OW,Cout]: the output is zeroed where gate <= 0 (EodConvDesc.gate: a ReLU's backward on the way out).
         `fuse=(pred_w [Cout/4], pred_b, out_units or None)` (deconv layers only): ConvTranspose + ReLU + 1x1 predictor + sigmoid
         in one launch, `out` = [units, 2H, 2W] probabilities (out_mode 2 of include/eod_hip.h)."""
-        _need_cuda(x, res, out)
+        _need_cuda(x, res, out, gate)
         if fuse is not None:
             if self.out_mode != 1 or out is None:
                 raise ValueError("fuse= needs a deconv layer and an explicit probability buffer `out`")
@@ -165,6 +167,7 @@ class Conv:
         d = self.desc
         d.x, d.w, d.bias, d.res, d.y = x.data_ptr(), self.w.data_ptr(), _ptr(self.bias), _ptr(res), out.data_ptr()
         d.m_count, d.m_unit, d.m_segments = _ptr(m_count), m_unit, int(m_segments)
+        d.gate = _ptr(gate)
         d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, self.Cin, OH, OW, self.Cout
         d.KH, d.KW, d.stride, d.pad, d.Kpad = self.KH, self.KW, self.stride, self.pad, self.Kpad
         d.relu, d.res_mode, d.in_relu, d.out_mode, d.tap4 = int(relu), res_mode, int(in_relu), self.out_mode, self.tap4
@@ -686,7 +689,27 @@ class ConvBackward:
             self._flipped_of = key
         return self._flipped
 
-    def __call__(self, x: torch.Tensor, y: Optional[torch.Tensor], g_out: torch.Tensor, relu: bool = False, need_dx: bool = True):
+    @staticmethod
+    def refresh_all(bws: Sequence["ConvBackward"]) -> None:
+        """After an optimizer step: the rotated weights of every layer in `bws` that has an input-gradient convolution, in
+        ceil(n / 24) launches (`eod_conv_rotate_weights_multi`) instead of one launch per layer at its next backward."""
+        todo = [bw for bw in bws if bw._flipped is not None]
+        for bw in bws:
+            bw._flipped_of = None
+        if not todo:
+            return
+        descs = (_lib.EodRotateTensor * len(todo))()
+        for d, bw in zip(descs, todo):
+            c = bw.conv
+            d.w, d.out = c.w.data_ptr(), bw._flipped.w.data_ptr()
+            d.Cout, d.KH, d.KW, d.Cin, d.ld_in, d.ld_out = c.Cout, c.KH, c.KW, c.Cin, c.Kpad, bw._flipped.Kpad
+        check(_lib.load().eod_conv_rotate_weights_multi(descs, len(todo), _stream()), "eod_conv_rotate_weights_multi")
+        for bw in todo:
+            bw._flipped.w_split = None
+            bw._flipped_of = (bw.conv.w.data_ptr(), bw.conv.w._version)
+
+    def __call__(self, x: torch.Tensor, y: Optional[torch.Tensor], g_out: torch.Tensor, relu: bool = False, need_dx: bool = True,
+                 dx_res: Optional[torch.Tensor] = None, dx_gate: Optional[torch.Tensor] = None):
         c = self.conv
         _need_cuda(x, y, g_out)
         if c.tap4 and need_dx:
@@ -729,17 +752,26 @@ class ConvBackward:
             db.record_stream(main)
         else:
             dw, db = wgrad()
+        # `dx_res` (a second gradient of x: the skip connection's) and `dx_gate` (the ReLU output x came out of: its backward) ride
+        # on the input-gradient convolution's epilogue: dx = relu'(dx_gate) * (conv(g) + dx_res) in one launch
         dx = None
+        tail = dict(res=dx_res, res_mode=1 if dx_res is not None else 0, gate=dx_gate)
         if need_dx and self.same:
-            dx = self._dgrad_conv()(g, N, H, W)
+            dx = self._dgrad_conv()(g, N, H, W, **tail)
         elif need_dx and self.zero_insert:
             up = torch.zeros((N, H, W, c.Cout), dtype=torch.float32, device=x.device)
             up[:, ::c.stride, ::c.stride] = g
-            dx = self._dgrad_conv()(up, N, H, W)
+            dx = self._dgrad_conv()(up, N, H, W, **tail)
         elif need_dx:
             dx = torch.empty_like(x)
             check(self.lib.eod_conv2d_backward_input(g.data_ptr(), c.w.data_ptr(), c.Kpad, N, H, W, c.Cin, c.Cout, c.KH, c.KW, c.pad, c.stride,
                                                      dx.data_ptr(), _stream()), "eod_conv2d_backward_input")
+            if dx_res is not None:
+                dx = dx + dx_res
+            if dx_gate is not None:
+                gated = torch.empty_like(dx)
+                check(self.lib.eod_relu_backward(dx.data_ptr(), dx_gate.data_ptr(), gated.data_ptr(), dx.numel(), _stream()), "eod_relu_backward")
+                dx = gated
         return dict(dx=dx, dw=dw, db=db)
 
 
@@ -981,8 +1013,10 @@ class AdamW:
                 fold = g.get("fold")              # (folded weights [rows, ld], per-row scale [rows]): written by the same launch
                 if fold is not None:
                     d.folded_out, d.row_scale, d.cols, d.ld_out = fold[0].data_ptr(), fold[1].data_ptr(), p.shape[1], fold[0].stride(0)
+                    # `grads[i]` is the gradient of the folded weights: x scale inside the launch (group key "grad_of_folded")
+                    d.grad_of_folded = 1 if g.get("grad_of_folded") else 0
                 else:
-                    d.folded_out, d.row_scale, d.cols, d.ld_out = None, None, 0, 0
+                    d.folded_out, d.row_scale, d.cols, d.ld_out, d.grad_of_folded = None, None, 0, 0, 0
                 n += 1
             if n:
                 check(self.lib.eod_adamw_step_multi(self._descs, n, self.betas[0], self.betas[1], self.eps, self.clip_value, _stream()),
@@ -997,6 +1031,8 @@ class AdamW:
             assert grad.shape == p.shape
             self.steps[i] += 1
             m, v = self.state[i]
+            if g.get("fold") is not None and g.get("grad_of_folded"):
+                grad = grad * g["fold"][1].view(-1, 1)
             check(self.lib.eod_adamw_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), g["lr"] * lr_factor,
                                           self.betas[0], self.betas[1], self.eps, g.get("weight_decay", self.weight_decay), self.steps[i],
                                           self.clip_value, _stream()), "eod_adamw_step")

@@ -117,6 +117,11 @@ typedef struct EodConvDesc {
    * barriers per chunk (default); 1 = two chunks of operands in flight (one more set of prefetch registers); 2 = the operand
    * tiles double buffered in LDS, one barrier per chunk (36 KB per workgroup). */
   int32_t prefetch2;
+  /* optional [N,OH,OW,Cout] (out_mode 0, no split_n / gn_partial): after everything else the output is 0 where gate <= 0 -- the
+   * backward of a ReLU whose output is `gate`, applied by the input-gradient convolution that produces the gradient (with res_mode 1
+   * = the skip connection's gradient: y = relu'(gate) * (conv(x) + res), a bottleneck block's timm.py:277-299 backward in one
+   * launch instead of conv, add, mask). */
+  const float* gate;
 } EodConvDesc;
 int eod_conv2d(const EodConvDesc* d, eod_stream_t stream);
 int eod_conv2d_gn_fused(const EodConvDesc* d); /* 1 when this layer can carry gn_partial (its plan has a slab reduce), else 0 */
@@ -484,7 +489,7 @@ int eod_memory_pool_backward(const float* dec3, const float* dec4, const float* 
 int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                                 int stride, float* dw, float* db, eod_stream_t stream);
 /* The same with a workspace (>= eod_conv2d_backward_weights_workspace_bytes(...) for the same arguments; 0 bytes: not needed): layers
- * with few 32 x 32 channel tiles and many positions (the trunk's first stages) cut the positions into up to 64 ranges, one grid slice
+ * with few channel tiles and many positions (the trunk's first stages) cut the positions into up to 64 ranges, one grid slice
  * each, whose partial results are added in range order by a second launch. */
 size_t eod_conv2d_backward_weights_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride);
 int eod_conv2d_backward_weights_ws(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
@@ -516,6 +521,15 @@ int eod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * kernel that `eod_conv2d` convolves dY with (autograd of every conv of timm.py:118-136,277-299, centernet_head.py:141-161). */
 int eod_conv_rotate_weights(const float* w, int Cout, int KH, int KW, int Cin, int ld_in, float* out, int ld_out, eod_stream_t stream);
 
+/* eod_conv_rotate_weights for `count` layers in ceil(count / 24) launches (after an optimizer step every layer with an input-gradient
+ * convolution needs it).  `tensors` is a HOST array, read before the call returns. */
+typedef struct EodRotateTensor {
+  const float* w;
+  float* out;
+  int32_t Cout, KH, KW, Cin, ld_in, ld_out;
+} EodRotateTensor;
+int eod_conv_rotate_weights_multi(const EodRotateTensor* tensors, int count, eod_stream_t stream);
+
 /* The same update for `count` parameter tensors in ceil(count / 20) launches (the training step of the recurrent detector has 126):
  * tensors[i] carries its own lr (BASE_LR x multipliers x the schedule's factor), weight decay and 1-based update count.  Element
  * for element the arithmetic of eod_adamw_step.  `tensors` is a HOST array, read before the call returns. */
@@ -533,6 +547,9 @@ typedef struct EodAdamWTensor {
   float* folded_out;
   const float* row_scale;
   int32_t cols, ld_out;
+  /* 1: `grad` is the gradient of the FOLDED weights; the master's = grad x row_scale[row] (chain rule of the fold), applied before the
+   * clipping.  Needs row_scale and cols. */
+  int32_t grad_of_folded;
 } EodAdamWTensor;
 int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, double beta1, double beta2, double eps, double clip_value,
                          eod_stream_t stream);

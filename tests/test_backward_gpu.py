@@ -934,3 +934,100 @@ def test_weight_gradients_on_a_side_stream_give_the_same_gradients(synthetic_sd)
             assert torch.equal(a, b), k
         else:
             assert all(torch.equal(x, y) for x, y in zip(a, b)), k
+
+
+@pytest.mark.gpu
+def test_weight_gradients_through_one_shared_workspace_repeat_bitwise():
+    """The LDS-tiled weight-gradient kernel cuts the positions into ranges (blockIdx.z) whose partial tiles a second launch adds in
+    range order.  Three layer shapes share ONE workspace, called in turn three times: every call gives bitwise the same dW / db
+    (no atomics, a fixed order of summation) and they match autograd."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(33)
+    cases = [(1, 80, 80, 64, 64, 3), (2, 40, 56, 128, 96, 1), (1, 33, 47, 32, 160, 3)]
+    layers = []
+    for (N, H, W, Cin, Cout, k) in cases:
+        w = (torch.randn((Cout, Cin, k, k), generator=g) * (0.5 / (Cin * k * k) ** 0.5)).requires_grad_()
+        b = torch.zeros((Cout,)).requires_grad_()
+        x = torch.randn((N, Cin, H, W), generator=g)
+        go = torch.randn((N, Cout, H, W), generator=g)
+        (F.conv2d(x, w, b, padding=k // 2) * go).sum().backward()
+        conv = ops.Conv(w.detach(), b.detach(), stride=1, pad=k // 2, device=dev)
+        assert ops._lib.load().eod_conv2d_backward_weights_workspace_bytes(N, H, W, Cin, Cout, k, k, k // 2, 1) > 0, \
+            "the case is meant to run with several position ranges"
+        layers.append((ops.ConvBackward(conv), x.permute(0, 2, 3, 1).contiguous().to(dev), go.permute(0, 2, 3, 1).contiguous().to(dev),
+                       w.grad.permute(0, 2, 3, 1).reshape(Cout, -1), b.grad))
+    first = {}
+    for rep in range(3):
+        for i, (bw, xd, gd, ref_dw, ref_db) in enumerate(layers):
+            out = bw(xd, None, gd, need_dx=False)
+            dw, db = out["dw"].cpu(), out["db"].cpu()
+            if rep == 0:
+                first[i] = (dw, db)
+                for name, got, ref in (("dW", dw, ref_dw), ("db", db, ref_db)):
+                    assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()), (i, name)
+            else:
+                assert torch.equal(dw, first[i][0]) and torch.equal(db, first[i][1]), (rep, i)
+
+
+@pytest.mark.gpu
+def test_rotated_weights_of_many_layers_in_one_launch():
+    """`ConvBackward.refresh_all` (`eod_conv_rotate_weights_multi`: the input-gradient convolutions' weights of all layers after an
+    optimizer step) against the per-layer construction from the new weights; 30 layers = two launches."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    shapes = [(64, 32, 3), (32, 64, 1), (96, 64, 3), (256, 256, 3), (64, 160, 5)] * 6
+    bws = []
+    for (Cout, Cin, k) in shapes:
+        conv = ops.Conv(torch.randn((Cout, Cin, k, k), generator=g), torch.zeros((Cout,)), stride=1, pad=k // 2, device=dev)
+        bw = ops.ConvBackward(conv)
+        bw._dgrad_conv()
+        bws.append(bw)
+    never_built = ops.ConvBackward(ops.Conv(torch.randn((32, 32, 3, 3), generator=g), torch.zeros((32,)), stride=1, pad=1, device=dev))
+    new_w = []
+    for bw in bws:
+        c = bw.conv
+        w = torch.randn((c.Cout, c.Cin, c.KH, c.KW), generator=g)
+        new_w.append(w)
+        packed, _ = ops.pack_conv_weight(w)
+        assert c.w.shape == packed.shape
+        c.w.copy_(packed.to(dev))                               # the stepped weights, written in place
+    ops.ConvBackward.refresh_all(bws + [never_built])
+    assert never_built._flipped is None
+    for bw, w in zip(bws, new_w):
+        c = bw.conv
+        fresh = ops.ConvBackward(ops.Conv(w, torch.zeros((c.Cout,)), stride=1, pad=c.pad, device=dev))._dgrad_conv()
+        assert bw._flipped_of == (c.w.data_ptr(), c.w._version)
+        assert torch.equal(bw._dgrad_conv().w, fresh.w), (c.Cout, c.Cin, c.KH)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride", [(1, 20, 28, 256, 64, 1, 1), (2, 14, 14, 64, 64, 3, 1), (1, 20, 20, 128, 256, 3, 2),
+                                                     (1, 16, 16, 64, 128, 1, 2), (1, 40, 40, 64, 256, 1, 1)])
+def test_relu_backward_and_shortcut_add_ride_on_the_input_gradient_launch(N, H, W, Cin, Cout, k, stride):
+    """`ConvBackward(..., dx_res=, dx_gate=)`: dx = relu'(gate) * (dX + res) out of the input-gradient convolution's epilogue
+    (EodConvDesc.gate + res_mode 1) is bitwise the three-launch form conv -> torch add -> eod_relu_backward, for stride-1 layers, the
+    zero-inserted stride-2 layers and a layer whose plan splits K; dW / db are untouched by the two arguments."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    conv = ops.Conv(torch.randn((Cout, Cin, k, k), generator=g) * (0.5 / (Cin * k * k) ** 0.5), torch.randn((Cout,), generator=g),
+                    stride=stride, pad=k // 2, device=dev)
+    OH, OW = conv.out_hw(H, W)
+    x = torch.randn((N, H, W, Cin), generator=g).to(dev)
+    go = torch.randn((N, OH, OW, Cout), generator=g).to(dev)
+    res = torch.randn((N, H, W, Cin), generator=g).to(dev)
+    gate = torch.relu(torch.randn((N, H, W, Cin), generator=g)).to(dev)           # a ReLU output: zeros and positives
+    bw = ops.ConvBackward(conv)
+    plain = bw(x, None, go)
+    want = torch.empty_like(plain["dx"])
+    summed = plain["dx"] + res
+    ops.check(ops._lib.load().eod_relu_backward(summed.data_ptr(), gate.data_ptr(), want.data_ptr(), summed.numel(), ops._stream()), "relu_backward")
+    fused = bw(x, None, go, dx_res=res, dx_gate=gate)
+    assert torch.equal(fused["dx"], want)
+    assert bool((fused["dx"] == 0).any()) and bool((fused["dx"] != 0).any())
+    assert torch.equal(fused["dw"], plain["dw"]) and torch.equal(fused["db"], plain["db"])
+    only_gate = bw(x, None, go, dx_gate=gate)["dx"]
+    assert torch.equal(only_gate, torch.where(gate > 0, plain["dx"], torch.zeros_like(plain["dx"])))
+    assert torch.equal(bw(x, None, go, dx_res=res)["dx"], summed)

@@ -490,7 +490,7 @@ def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
             assert torch.equal(mem16.cpu(), rm.half())
             l, gr = trainer.fm.forward_backward(f["image"].to(dev), gtb.to(dev), gtc.to(dev),
                                                 memory=(mem16, torch.from_numpy(f["proj_indices"]).to(dev).reshape(H, W).int()))
-            gl = [trainer.getters[g_["name"]](gr).clone() for g_ in trainer.groups]
+            gl = [trainer.step_getters[g_["name"]](gr).clone() for g_ in trainer.groups]     # what the optimizer is handed
             want_grads = gl if want_grads is None else [a + b for a, b in zip(want_grads, gl)]
             for k, v in l.items():
                 want_losses[k] = want_losses.get(k, 0.0) + float(v)

@@ -115,12 +115,17 @@ def test_multi_tensor_adamw_equals_the_single_tensor_launches():
         layer_w = torch.zeros((64, 224), device=dev)
         scale = (torch.arange(64, dtype=torch.float32) * 0.01 + 0.5).to(dev)
         groups.append({"name": "conv1", "param": master, "lr": 2e-3, "fold": (layer_w, scale)})
-        folded[multi] = (master, layer_w, scale)
+        # the same with the gradient of the FOLDED weights handed over (x scale inside the launch: key "grad_of_folded")
+        master2 = torch.linspace(1, -1, 64 * 196).reshape(64, 196).to(dev)
+        layer_w2 = torch.zeros((64, 224), device=dev)
+        groups.append({"name": "conv2", "param": master2, "lr": 2e-3, "fold": (layer_w2, scale), "grad_of_folded": True})
+        folded[multi] = (master, layer_w, scale, master2, layer_w2)
         opt = ops.AdamW(groups, weight_decay=1e-2, clip_value=1.0)
         opt.multi_tensor = multi
         gg = torch.Generator().manual_seed(9)
         for step in range(3):
             grads = [(torch.randn((n,), generator=gg) * 3).to(dev) for n in sizes] + [(torch.randn((64, 196), generator=gg)).to(dev)]
+            grads.append((grads[-1] / scale.view(-1, 1)) * 0.5)  # conv2: gradient of the folded weights
             if step == 1:
                 grads[7] = None                                  # a tensor without a gradient this iteration keeps its step count
             opt.step(grads, lr_factor=0.5 + 0.25 * step)
@@ -134,12 +139,16 @@ def test_multi_tensor_adamw_equals_the_single_tensor_launches():
         assert torch.equal(oa.state[i][0], ob.state[i][0]) and torch.equal(oa.state[i][1], ob.state[i][1]), i
     assert not torch.equal(pa[12].cpu(), base[12])
     for multi in (True, False):
-        master, layer_w, scale = folded[multi]
+        master, layer_w, scale, master2, layer_w2 = folded[multi]
         assert torch.equal(layer_w[:, :196], master * scale.view(-1, 1)) and not bool(layer_w[:, 196:].any())
-    assert torch.equal(folded[True][0], folded[False][0]) and torch.equal(folded[True][1], folded[False][1])
+        assert torch.equal(layer_w2[:, :196], master2 * scale.view(-1, 1)) and not bool(layer_w2[:, 196:].any())
+    for k in range(5):
+        if k != 2:
+            assert torch.equal(folded[True][k], folded[False][k]), k
+    assert not torch.equal(folded[True][3].cpu(), torch.linspace(1, -1, 64 * 196).reshape(64, 196))
     # the state dict round trip the checkpoint uses
     sd = oa.state_dict()
     oc = ops.AdamW([{"name": f"t{i}", "param": p.clone(), "lr": 1e-3} for i, p in enumerate(pa)] +
-                   [{"name": "conv1", "param": folded[True][0].clone(), "lr": 1e-3}])
+                   [{"name": "conv1", "param": folded[True][0].clone(), "lr": 1e-3}, {"name": "conv2", "param": folded[True][3].clone(), "lr": 1e-3}])
     oc.load_state_dict(sd)
     assert oc.steps == oa.steps and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(oc.state, oa.state))

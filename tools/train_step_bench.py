@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roi-heads", action="store_true", help="the whole forward_model: both halves, all 126 parameter tensors")
+    ap.add_argument("--no-scale-sync", action="store_true",
+                    help="experiment: skip the per-step read-back of the five Scale parameters (the one host synchronisation of a step)")
     a = ap.parse_args()
     H, W = a.size
     dev = torch.device("cuda:0")
@@ -34,6 +36,8 @@ def main():
     sd = synthetic_state_dict(0)
     model = build_model(cfg, sd)
     trainer = Trainer(model, sd) if a.roi_heads else ProposalTrainer(model, sd)
+    if a.no_scale_sync:
+        trainer.after = [f for f in trainer.after if getattr(f, "__name__", "") != "sync_scales"]
     g = torch.Generator().manual_seed(0)
     n_cells = 200 * 200
     img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)

@@ -159,6 +159,35 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float* __restr
 // first reduces that level's chunk partials to (mean, rstd) for every group -- one wave per group, lanes striding over the chunks,
 // the same fixed-shape shuffle tree and the same double arithmetic as gn_finalize_kernel, hence the same bits -- into LDS, then
 // normalises its rows.  The redundant reductions are 32 groups x <= 200 partial pairs per workgroup out of L2.
+// mean / rstd of every group of one level image from the chunks' partial sums (double): eight lanes per group take every eighth
+// chunk in chunk order and are added by a three-step butterfly -- a fixed order, all groups at once (the one-wave-per-group form
+// walked 8 groups one after the other: ~20 us of prologue in every workgroup of the apply passes).
+__device__ __forceinline__ void gn_level_stats(const double* __restrict__ fwd_partial, int first_chunk, int nch, int rows, int C,
+                                               int groups, float eps, float (*s_stats)[2]) {
+  const int sub = threadIdx.x & 7;
+  for (int g = threadIdx.x >> 3; g < groups; g += (int)(blockDim.x >> 3)) {
+    double s = 0.0, q = 0.0;
+    for (int c = sub; c < nch; c += 8) {
+      s += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
+      q += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    if (sub == 0) {
+      const double n = (double)rows * (C / groups);
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stats[g][0] = (float)mean;
+      s_stats[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void gn_finalize_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                       LevelOff lo, int C, int groups, float eps,
@@ -175,27 +204,7 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_relu_kernel(const float
   }
   const int rows = lo.off[level + 1] - lo.off[level];
   const int nch = (rows + GN_ROWS - 1) / GN_ROWS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int g = wave; g < groups; g += 4) {
-    double s = 0.0, q = 0.0;
-    for (int c = lane; c < nch; c += 64) {
-      s += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
-      q += partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      s += __shfl_xor(s, off, 64);
-      q += __shfl_xor(q, off, 64);
-    }
-    if (lane == 0) {
-      const double n = (double)rows * (C / groups);
-      const double mean = s / n;
-      double var = q / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_stats[g][0] = (float)mean;
-      s_stats[g][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
+  gn_level_stats(partial, first_chunk, nch, rows, C, groups, eps, s_stats);
   const int r0 = lo.off[level] + ((int)blockIdx.x - first_chunk) * GN_ROWS;
   const int r1 = min(r0 + GN_ROWS, lo.off[level + 1]);
   const int c4 = C >> 2;
@@ -294,34 +303,6 @@ extern "C" int eod_maxpool3x3s2(const float* x, float* y, int N, int H, int W, i
 //   a_c / b_c = the level's sums of dyr / dyr * xhat for channel c.
 // Three launches: per 32-row chunk the per-channel sums (double, row order); one workgroup adds them per level in chunk order and
 // over the levels in level order (deterministic); the apply pass.  mean / rstd are recomputed from the forward's own partial sums.
-struct GnStats {
-  float mean, rstd;
-};
-__device__ __forceinline__ void gn_level_stats(const double* __restrict__ fwd_partial, int first_chunk, int nch, int rows, int C,
-                                               int groups, float eps, float (*s_stats)[2]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int g = wave; g < groups; g += 4) {
-    double s = 0.0, q = 0.0;
-    for (int c = lane; c < nch; c += 64) {
-      s += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 0];
-      q += fwd_partial[((size_t)(first_chunk + c) * groups + g) * 2 + 1];
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      s += __shfl_xor(s, off, 64);
-      q += __shfl_xor(q, off, 64);
-    }
-    if (lane == 0) {
-      const double n = (double)rows * (C / groups);
-      const double mean = s / n;
-      double var = q / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_stats[g][0] = (float)mean;
-      s_stats[g][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-}
-
 __device__ __forceinline__ void gn_chunk_of_block(const LevelOff& lo, int& level, int& first_chunk) {
   level = 0;
   first_chunk = 0;
@@ -360,24 +341,44 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// one workgroup: per level the chunk sums in chunk order -> level totals [levels][C][2]; over the levels -> dgamma, dbeta
+// per level the chunk sums -> level totals [levels][C][2]; over the levels -> dgamma, dbeta.  A workgroup owns 32 channels; its eight
+// sub-lanes per channel take every eighth chunk of a level (in chunk order) and are added in sub-lane order through LDS: a fixed
+// order of summation, and 8 x C / 32 times the one-workgroup form's parallelism (66 -> ~10 us for the tower's 267 chunks).
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const double* __restrict__ part, LevelOff lo, int C, double* __restrict__ level_tot,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double ga = 0.0, gb = 0.0;
-    int chunk = 0;
-    for (int l = 0; l < lo.levels; ++l) {
-      const int nch = (lo.off[l + 1] - lo.off[l] + GN_ROWS - 1) / GN_ROWS;
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < nch; ++k, ++chunk) {
-        a += part[((size_t)chunk * C + c) * 2 + 0];
-        b += part[((size_t)chunk * C + c) * 2 + 1];
+  __shared__ double s_part[8][32][2];
+  const int cl = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double ga = 0.0, gb = 0.0;
+  int chunk0 = 0;
+  for (int l = 0; l < lo.levels; ++l) {
+    const int nch = (lo.off[l + 1] - lo.off[l] + GN_ROWS - 1) / GN_ROWS;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+      for (int k = sub; k < nch; k += 8) {
+        a += part[((size_t)(chunk0 + k) * C + c) * 2 + 0];
+        b += part[((size_t)(chunk0 + k) * C + c) * 2 + 1];
+      }
+    }
+    s_part[sub][cl][0] = a;
+    s_part[sub][cl][1] = b;
+    __syncthreads();
+    if (sub == 0 && c < C) {
+      a = 0.0; b = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a += s_part[j][cl][0];
+        b += s_part[j][cl][1];
       }
       level_tot[((size_t)l * C + c) * 2 + 0] = a;
       level_tot[((size_t)l * C + c) * 2 + 1] = b;
       ga += a;
       gb += b;
     }
+    __syncthreads();
+    chunk0 += nch;
+  }
+  if (sub == 0 && c < C) {
     dbeta[c] = (float)ga;
     dgamma[c] = (float)gb;
   }
@@ -449,7 +450,7 @@ extern "C" int eod_groupnorm_relu_backward(const float* x, const float* y, const
   double* level_tot = part + (size_t)chunks * C * 2;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks), dim3(256), 0, s, x, y, dy, lo, C, groups, eps, fwd_partial, part);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(1), dim3(256), 0, s, part, lo, C, level_tot, dgamma, dbeta);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, s, part, lo, C, level_tot, dgamma, dbeta);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, s, x, y, dy, gamma, lo, C, groups, eps, fwd_partial, level_tot, dx);
   return eod_launch_status();
 }

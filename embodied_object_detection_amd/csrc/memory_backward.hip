@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWMulti a) {
 // channels of one position per half wave (coalesced as the NHWC rows lie in memory); a workgroup owns one 32 (co) x 32 (ci) tile of
 // one tap, its four waves take a quarter of the positions each and are added in wave order (deterministic).  The gradient with
 // respect to the input is a convolution of G with the 180-degree rotated, in/out-transposed weights: eod_conv2d (ops.ConvBackward).
+#define WGRAD_MAX_LEVELS 8
 struct ConvBwdArgs {
   const float* x;   // [N,H,W,Cin]
   const float* g;   // [N,H,W,Cout]
@@ -236,6 +237,10 @@ struct ConvBwdArgs {
   int splits;
   float* part;
   float* bpart;
+  // pyramid mode of the LDS-tiled kernel (nlv > 0; stride 1, 'same' padding): x / g are row lists, rows [lv_off[l], lv_off[l+1])
+  // are an lv_h[l] x lv_w[l] image, the weights are shared by the levels and dW / db are summed over all of them
+  int nlv;
+  int lv_off[WGRAD_MAX_LEVELS + 1], lv_h[WGRAD_MAX_LEVELS], lv_w[WGRAD_MAX_LEVELS];
 };
 
 __global__ __launch_bounds__(256) void conv_backward_weights_kernel(ConvBwdArgs a) {
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(256) void conv_backward_weights_rb_kernel(ConvBwdAr
 // tap-shifted, border-masked X rows [32][64] are fetched with two 16-byte loads per thread each (ONE position computation per load)
 // into registers, staged in LDS as they lie ([position][channel]: conflict-free stores), and every MFMA operand is one ds_read_b32
 // (lane = channel, half wave = position parity).  The next chunk's global loads are in flight under the 16 MFMAs of the current one.
+template <bool LEVELS>
 __global__ __launch_bounds__(256) void conv_backward_weights_lds_kernel(ConvBwdArgs a) {
   constexpr int PK = 32, TC = 64;
   __shared__ __attribute__((aligned(16))) float As[PK][TC];
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void conv_backward_weights_lds_kernel(ConvBwdA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, kh = lane >> 5;
-  const int P = a.N * a.OH * a.OW;
+  const int P = LEVELS ? a.lv_off[a.nlv] : a.N * a.OH * a.OW;
   const int chunks = (P + PK - 1) / PK;
   const int cps = (chunks + a.splits - 1) / a.splits;
   const int c_begin = blockIdx.z * cps;
@@ -460,13 +466,25 @@ __global__ __launch_bounds__(256) void conv_backward_weights_lds_kernel(ConvBwdA
       f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
       if (pos < P) {
         if (g_ok) gv = *reinterpret_cast<const f32x4*>(a.g + (size_t)pos * a.Cout + co0 + c4);
-        const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * OH + oy
-        const int ox = pos - row * a.OW;
-        const int n = (int)fdiv((unsigned)row, a.div_h);
-        const int oy = row - n * a.OH;
-        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-        if (x_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          xv = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c4);
+        if (LEVELS) {
+          int l = 0;
+#pragma unroll
+          for (int q = 1; q < WGRAD_MAX_LEVELS; ++q) l += (q < a.nlv && pos >= a.lv_off[q]) ? 1 : 0;
+          const int base = a.lv_off[l], lw = a.lv_w[l], lh = a.lv_h[l];
+          const int local = pos - base;
+          const int oy = local / lw, ox = local - oy * lw;
+          const int iy = oy + ky - a.pad, ix = ox + kx - a.pad;
+          if (x_ok && (unsigned)iy < (unsigned)lh && (unsigned)ix < (unsigned)lw)
+            xv = *reinterpret_cast<const f32x4*>(a.x + ((size_t)base + (size_t)iy * lw + ix) * a.Cin + ci0 + c4);
+        } else {
+          const int row = (int)fdiv((unsigned)pos, a.div_w);           // n * OH + oy
+          const int ox = pos - row * a.OW;
+          const int n = (int)fdiv((unsigned)row, a.div_h);
+          const int oy = row - n * a.OH;
+          const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+          if (x_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            xv = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c4);
+        }
       }
       gr[i] = gv;
       xr[i] = xv;
@@ -846,7 +864,7 @@ static int conv2d_backward_weights_impl(const float* x, const float* g, int N, i
   else if (Cin == 4)
     hipLaunchKernelGGL(conv_backward_weights_tap4_kernel, dim3(KH * KW, Cout >> 4, a.splits), dim3(1024), 0, (hipStream_t)stream, a);
   else if (wgrad_lds())
-    hipLaunchKernelGGL(conv_backward_weights_lds_kernel, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
+    hipLaunchKernelGGL(conv_backward_weights_lds_kernel<false>, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
                        (hipStream_t)stream, a);
   else if (wgrad_register_blocked())
     hipLaunchKernelGGL(conv_backward_weights_rb_kernel, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
@@ -871,6 +889,61 @@ extern "C" int eod_conv2d_backward_weights_ws(const float* x, const float* g, in
                                               eod_stream_t stream) {
   if (workspace_bytes && !workspace) return EOD_ERR_NULL;
   return conv2d_backward_weights_impl(x, g, N, H, W, Cin, Cout, KH, KW, pad, stride, dw, db, workspace, workspace_bytes, stream);
+}
+
+// Pyramid mode: one launch for a level-shared layer (CenterNet tower / head, centernet_head.py:141-161) over all levels' rows.
+static int wgrad_levels_splits(long rows, int Cin, int Cout, int KH, int KW) {
+  const long wgs = (long)((Cout + 63) >> 6) * ((Cin + 63) >> 6) * KH * KW;
+  long s = (768 + wgs - 1) / wgs;
+  const long cap = (rows + 31) / 32 / 4;
+  if (s > cap) s = cap;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" size_t eod_conv2d_backward_weights_levels_workspace_bytes(int rows, int Cin, int Cout, int KH, int KW) {
+  if (rows <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+  const int s = wgrad_levels_splits(rows, Cin, Cout, KH, KW);
+  return s > 1 ? (size_t)s * ((size_t)Cout * KH * KW * Cin + Cout) * sizeof(float) : 0;
+}
+
+extern "C" int eod_conv2d_backward_weights_levels(const float* x, const float* g, int levels, const int32_t* level_off,
+                                                  const int32_t* level_h, const int32_t* level_w, int Cin, int Cout, int KH, int KW, int pad,
+                                                  float* dw, float* db, void* workspace, size_t workspace_bytes, eod_stream_t stream) {
+  if (!x || !g || !dw || !level_off || !level_h || !level_w) return EOD_ERR_NULL;
+  if (levels < 1 || levels > WGRAD_MAX_LEVELS || Cin <= 0 || Cout <= 0 || (Cin & 31) || (Cout & 31) || KH <= 0 || KW <= 0 || KH != KW ||
+      pad * 2 != KH - 1 || level_off[0] != 0)
+    return EOD_ERR_BAD_DIMS;
+  for (int l = 0; l < levels; ++l)
+    if (level_h[l] <= 0 || level_w[l] <= 0 || level_off[l + 1] - level_off[l] != level_h[l] * level_w[l]) return EOD_ERR_BAD_DIMS;
+  if (workspace_bytes && !workspace) return EOD_ERR_NULL;
+  if (!eod_aligned16(x) || !eod_aligned16(g) || !eod_aligned16(dw)) return EOD_ERR_ALIGN;
+  ConvBwdArgs a{};
+  a.x = x; a.g = g; a.dw = dw; a.db = db;
+  a.N = 1; a.H = a.OH = level_h[0]; a.W = a.OW = level_w[0];
+  a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.pad = pad; a.stride = 1;
+  a.nlv = levels;
+  for (int l = 0; l < levels; ++l) {
+    a.lv_off[l] = level_off[l]; a.lv_h[l] = level_h[l]; a.lv_w[l] = level_w[l];
+  }
+  a.lv_off[levels] = level_off[levels];
+  a.splits = 1;
+  const size_t n = (size_t)Cout * KH * KW * Cin;
+  const size_t need = eod_conv2d_backward_weights_levels_workspace_bytes(level_off[levels], Cin, Cout, KH, KW);
+  if (workspace && need) {
+    if (need > workspace_bytes) return EOD_ERR_CAPACITY;
+    a.splits = wgrad_levels_splits(level_off[levels], Cin, Cout, KH, KW);
+    a.part = static_cast<float*>(workspace);
+    a.bpart = a.part + (size_t)a.splits * n;
+  }
+  hipLaunchKernelGGL(conv_backward_weights_lds_kernel<true>, dim3(((Cout + 63) >> 6) * ((Cin + 63) >> 6), KH * KW, a.splits), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  if (a.splits > 1) {
+    size_t blocks = (n + Cout + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a.part, a.bpart, dw, db, n, Cout, a.splits);
+  }
+  return eod_launch_status();
 }
 
 extern "C" int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW,

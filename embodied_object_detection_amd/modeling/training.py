@@ -45,6 +45,7 @@ class ProposalTraining:
         self._bw: Dict[int, ops.ConvBackward] = {}
         self._loss = {}
         self.last = None
+        self.pyramid_backward = True     # False: the level-shared layers' backward level by level (25 calls + their sums; tests compare)
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------------
     def _conv_bwd(self, conv: ops.Conv, xin: torch.Tensor, gout: torch.Tensor, shapes, off):
@@ -52,6 +53,10 @@ class ProposalTraining:
         if id(conv) not in self._bw:
             self._bw[id(conv)] = ops.ConvBackward(conv, side_stream=self.side)
         bwd = self._bw[id(conv)]
+        if self.pyramid_backward and not self.side:
+            # one weight-gradient launch and one input-gradient launch over all levels' rows (`ConvBackward(..., levels=)`)
+            o = bwd(xin, None, gout, levels=(off, shapes))
+            return o["dx"], o["dw"], o["db"]
         dw = db = None
         dxs = []
         for l, (h, w) in enumerate(shapes):
@@ -473,15 +478,16 @@ class DetectorTraining:
             d_h2 = o["dx"]
             g32 = torch.zeros((B, 1, 1, 32), dtype=torch.float32, device=self.dev)
             g32[:, 0, 0, :4] = rec["d_deltas"] * self.box_w
-            o = self._conv_bw(self.bb2_32[k])(rec["hb"], None, g32)
+            # every ReLU's backward (and the sum of h2's two gradients) rides on the epilogue of the input-gradient launch that
+            # produces the gradient (`dx_gate` / `dx_res` of ops.ConvBackward)
+            o = self._conv_bw(self.bb2_32[k])(rec["hb"], None, g32, dx_gate=rec["hb"])
             with ops.ConvBackward.on_side(self.dev, self.side):
                 grads[st["bb2"].name] = (o["dw"][:4].contiguous(), o["db"][:4].contiguous())
-            o = self._conv_bw(st["bb0"])(rec["h2"], rec["hb"], o["dx"], relu=True)
+            o = self._conv_bw(st["bb0"])(rec["h2"], None, o["dx"], dx_res=d_h2, dx_gate=rec["h2"])
             grads[st["bb0"].name] = (o["dw"], o["db"])
-            d_h2 = d_h2 + o["dx"]
-            o = self._conv_bw(st["fc2"])(rec["h1"], rec["h2"], d_h2, relu=True)
+            o = self._conv_bw(st["fc2"])(rec["h1"], None, o["dx"], dx_gate=rec["h1"])
             grads[st["fc2"].name] = (o["dw"], o["db"])
-            o = self._conv_bw(st["fc1"])(rec["pool"].view(B, 1, 1, -1), rec["h1"], o["dx"], relu=True)
+            o = self._conv_bw(st["fc1"])(rec["pool"].view(B, 1, 1, -1), None, o["dx"])
             grads[st["fc1"].name] = (o["dw"], o["db"])
             d_pool = (o["dx"].view(B, 7, 7, 256) * (1.0 / rh.num_stages)).contiguous()
             ops.roi_align_backward(dP[0], dP[1], dP[2], h3, w3, 256, rec["boxes"], None, B, 7, d_pool)

@@ -689,6 +689,38 @@ class ConvBackward:
             self._flipped_of = key
         return self._flipped
 
+    def _pyramid(self, x, y, g_out, relu, need_dx, dx_res, dx_gate, levels):
+        """`levels=(row_offsets, [(h, w), ...])`: a level-shared layer over a feature pyramid stored as one row list (x [rows, Cin],
+        g_out [rows, Cout]; the forward's `Conv(..., levels=)`): dW / db summed over the levels by ONE weight-gradient launch
+        (`eod_conv2d_backward_weights_levels`) and dX by one pyramid-mode launch of the rotated-weights conv."""
+        c = self.conv
+        if not self.same:
+            raise ValueError("pyramid mode covers stride-1 'same' layers")
+        off, shapes = levels
+        L, rows = len(shapes), int(off[-1])
+        assert tuple(x.shape) == (rows, c.Cin) and tuple(g_out.shape) == (rows, c.Cout) and x.is_contiguous() and g_out.is_contiguous()
+        g = g_out
+        if relu:
+            g = torch.empty_like(g_out)
+            check(self.lib.eod_relu_backward(g_out.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "eod_relu_backward")
+        lo = (C.c_int32 * (L + 1))(*off)
+        lh = (C.c_int32 * L)(*[h for h, _ in shapes])
+        lw = (C.c_int32 * L)(*[w for _, w in shapes])
+        K = c.KH * c.KW * c.Cin
+        dw = torch.empty((c.Cout, K), dtype=torch.float32, device=x.device)
+        db = torch.empty((c.Cout,), dtype=torch.float32, device=x.device)
+        need = self.lib.eod_conv2d_backward_weights_levels_workspace_bytes(rows, c.Cin, c.Cout, c.KH, c.KW)
+        ws = ConvBackward._workspace.get(x.device)
+        if need and (ws is None or ws.numel() * 4 < need):
+            ws = ConvBackward._workspace[x.device] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=x.device)
+        check(self.lib.eod_conv2d_backward_weights_levels(x.data_ptr(), g.data_ptr(), L, lo, lh, lw, c.Cin, c.Cout, c.KH, c.KW, c.pad,
+                                                          dw.data_ptr(), db.data_ptr(), ws.data_ptr() if need else None,
+                                                          ws.numel() * 4 if need else 0, _stream()), "eod_conv2d_backward_weights_levels")
+        dx = None
+        if need_dx:
+            dx = self._dgrad_conv()(g, 1, 0, 0, levels=(off, shapes), res=dx_res, res_mode=1 if dx_res is not None else 0, gate=dx_gate)
+        return dict(dx=dx, dw=dw, db=db)
+
     @staticmethod
     def refresh_all(bws: Sequence["ConvBackward"]) -> None:
         """After an optimizer step: the rotated weights of every layer in `bws` that has an input-gradient convolution, in
@@ -709,9 +741,12 @@ class ConvBackward:
             bw._flipped_of = (bw.conv.w.data_ptr(), bw.conv.w._version)
 
     def __call__(self, x: torch.Tensor, y: Optional[torch.Tensor], g_out: torch.Tensor, relu: bool = False, need_dx: bool = True,
-                 dx_res: Optional[torch.Tensor] = None, dx_gate: Optional[torch.Tensor] = None):
+                 dx_res: Optional[torch.Tensor] = None, dx_gate: Optional[torch.Tensor] = None,
+                 levels: Optional[Tuple[Sequence[int], Sequence[Tuple[int, int]]]] = None):
         c = self.conv
         _need_cuda(x, y, g_out)
+        if levels is not None:
+            return self._pyramid(x, y, g_out, relu, need_dx, dx_res, dx_gate, levels)
         if c.tap4 and need_dx:
             raise ValueError("the 4-channel stem has a weight gradient only (its input is the image): pass need_dx=False")
         N, H, W, _ = x.shape

@@ -494,6 +494,13 @@ int eod_conv2d_backward_weights(const float* x, const float* g, int N, int H, in
 size_t eod_conv2d_backward_weights_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride);
 int eod_conv2d_backward_weights_ws(const float* x, const float* g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                                    int stride, float* dw, float* db, void* workspace, size_t workspace_bytes, eod_stream_t stream);
+/* Pyramid mode (the weight gradient of a level-shared layer, centernet_head.py:141-161, in one launch): x [rows, Cin] / g [rows, Cout]
+ * are row lists, rows [level_off[l], level_off[l+1]) an level_h[l] x level_w[l] image (levels <= 8); stride 1, pad = (KH - 1) / 2;
+ * dW / db are summed over the levels.  The workspace (optional, as above) holds the position ranges' partial results. */
+size_t eod_conv2d_backward_weights_levels_workspace_bytes(int rows, int Cin, int Cout, int KH, int KW);
+int eod_conv2d_backward_weights_levels(const float* x, const float* g, int levels, const int32_t* level_off, const int32_t* level_h,
+                                       const int32_t* level_w, int Cin, int Cout, int KH, int KW, int pad, float* dw, float* db,
+                                       void* workspace, size_t workspace_bytes, eod_stream_t stream);
 /* Input gradient of a strided convolution (stride >= 2: P6 / P7, timm.py:359-364; g is [N,OH,OW,Cout]), gather form, w = the
  * forward's packed weights [Cout][Kpad]; dx [N,H,W,Cin].  Stride-1 'same' layers use eod_conv2d with the rotated weights instead. */
 int eod_conv2d_backward_input(const float* g, const float* w, int Kpad, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad,

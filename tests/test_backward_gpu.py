@@ -923,6 +923,7 @@ def test_weight_gradients_on_a_side_stream_give_the_same_gradients(synthetic_sd)
     outs = []
     for side in (False, True):
         step = ProposalTraining(model, synthetic_sd, side_stream=side)
+        step.pyramid_backward = False          # level by level on both sides: the side-stream form has no pyramid-mode launch
         losses, grads = step.forward_backward(img, gt, memory=mem)
         torch.cuda.synchronize()
         outs.append((losses, grads))
@@ -1031,3 +1032,33 @@ def test_relu_backward_and_shortcut_add_ride_on_the_input_gradient_launch(N, H, 
     only_gate = bw(x, None, go, dx_gate=gate)["dx"]
     assert torch.equal(only_gate, torch.where(gate > 0, plain["dx"], torch.zeros_like(plain["dx"])))
     assert torch.equal(bw(x, None, go, dx_res=res)["dx"], summed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout", [(256, 256), (256, 32), (64, 96)])
+def test_level_shared_layer_backward_in_one_launch_per_gradient(Cin, Cout):
+    """`ConvBackward(..., levels=)`: the weight gradient of a level-shared 3x3 layer summed over a five-level pyramid by ONE launch
+    (`eod_conv2d_backward_weights_levels`) and its input gradient by one pyramid-mode launch, against torch autograd level by level
+    (the tower / head convs of centernet_head.py:141-161 at the level sizes of a 640x640 frame, and odd sizes)."""
+    from embodied_object_detection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(44)
+    shapes = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)] if Cin == 256 else [(13, 9), (7, 5), (3, 4)]
+    off = [0]
+    for (h, w) in shapes:
+        off.append(off[-1] + h * w)
+    wt = (torch.randn((Cout, Cin, 3, 3), generator=g) * (0.5 / (Cin * 9) ** 0.5)).requires_grad_()
+    b = (torch.randn((Cout,), generator=g) * 0.1).requires_grad_()
+    xs = [torch.randn((1, Cin, h, w), generator=g).requires_grad_() for (h, w) in shapes]
+    gos = [torch.randn((1, Cout, h, w), generator=g) for (h, w) in shapes]
+    sum((F.conv2d(x, wt, b, padding=1) * go).sum() for x, go in zip(xs, gos)).backward()
+    conv = ops.Conv(wt.detach(), b.detach(), stride=1, pad=1, device=dev)
+    xd = torch.cat([x.detach()[0].permute(1, 2, 0).reshape(-1, Cin) for x in xs]).contiguous().to(dev)
+    gd = torch.cat([go[0].permute(1, 2, 0).reshape(-1, Cout) for go in gos]).contiguous().to(dev)
+    out = ops.ConvBackward(conv)(xd, None, gd, levels=(off, shapes))
+    ref_dx = torch.cat([x.grad[0].permute(1, 2, 0).reshape(-1, Cin) for x in xs])
+    for name, got, ref in (("dW", out["dw"].cpu(), wt.grad.permute(0, 2, 3, 1).reshape(Cout, -1)), ("db", out["db"].cpu(), b.grad),
+                           ("dX", out["dx"].cpu(), ref_dx)):
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 3e-5 * scale, f"{name}: {err:.3e} at scale {scale:.3e}"

@@ -200,8 +200,12 @@ class ProposalTrainer:
         self.merge_w = [sd[f"backbone.map_merge_projection{i}.weight"].float().reshape(256, 512).contiguous().to(dev) for i in (1, 2, 3)]
         self.merge_b = [sd[f"backbone.map_merge_projection{i}.bias"].float().contiguous().to(dev) for i in (1, 2, 3)]
         for i in range(3):
-            add(f"backbone.map_merge_projection{i + 1}.weight", self.merge_w[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][0])
-            add(f"backbone.map_merge_projection{i + 1}.bias", self.merge_b[i], lambda g, i=i: g[f"map_merge_projection{i + 1}"][1])
+            # a frame without a memory (MEMORY_TYPE '': the non-recurrent detector) leaves the projections without a gradient:
+            # None, which the optimizer skips as torch skips a parameter whose .grad is None
+            add(f"backbone.map_merge_projection{i + 1}.weight", self.merge_w[i],
+                lambda g, i=i: g.get(f"map_merge_projection{i + 1}", (None, None))[0])
+            add(f"backbone.map_merge_projection{i + 1}.bias", self.merge_b[i],
+                lambda g, i=i: g.get(f"map_merge_projection{i + 1}", (None, None))[1])
 
         self.step_fn.bb.merge_weights = self.merge_w
         self.after.append(lambda: bbm.merge.refresh(self.merge_w, self.merge_b))
@@ -623,7 +627,10 @@ class Trainer(ProposalTrainer):
                 losses, grads = self.fm.forward_backward(img, gt_boxes.to(dev).contiguous(), gt_classes.to(dev), memory=memory,
                                                          generator=generator)
                 gl = [self.step_getters[g["name"]](grads) for g in self.groups]
-                acc = [t.clone() for t in gl] if acc is None else [a.add_(t) for a, t in zip(acc, gl)]
+                if acc is None:
+                    acc = [None if t is None else t.clone() for t in gl]
+                else:
+                    acc = [a if t is None else (t.clone() if a is None else a.add_(t)) for a, t in zip(acc, gl)]
                 for k, v in losses.items():
                     total[k] = v.clone() if k not in total else total[k] + v
         self._acc = acc

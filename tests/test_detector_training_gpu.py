@@ -12,6 +12,15 @@ from oracle import losses as OL
 from oracle import model as M
 
 
+def _report(name, values):
+    """The measured figures behind a bound, for DESIGN.md / profiles (gpurun_out/<name>.json)."""
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", name + ".json"), "w") as fh:
+        json.dump(values, fh, indent=1, sort_keys=True)
+
+
 def _boxes(g, n_gt, n_rand, W=640.0, H=640.0):
     xy = torch.rand((n_gt, 2), generator=g) * torch.tensor([W * 0.8, H * 0.8])
     wh = torch.rand((n_gt, 2), generator=g) * 150 + 6
@@ -303,6 +312,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
              "backbone.map_merge_projection3.bias", "backbone.top_block.p6.weight", f"{h}.bbox_tower.0.weight", f"{h}.bbox_tower.10.weight",
              "roi_heads.box_head.0.fc1.weight", "roi_heads.box_head.1.fc2.bias", "roi_heads.box_predictor.2.cls_score.linear.weight",
              "roi_heads.box_predictor.0.bbox_pred.0.weight", "roi_heads.box_predictor.1.bbox_pred.2.weight"]
+    measured = {}
     for name in probe:
         mine = trainer.getters[name](grads).cpu()
         want = sd[name].grad
@@ -314,7 +324,9 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
             want = packed(want)
         want = want.reshape(mine.shape)
         l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
+        measured[name] = l2
         assert l2 <= 5e-3, (name, l2)
+    _report("training_gradient_l2_128x160", measured)
     # the pyramid gradient of the ROI heads really reaches the backbone: without it the FPN gradient is a different one
     _, g_prop = fm.prop.forward_backward(img.to(dev), gt.to(dev), memory=mem)
     a, b = trainer.getters["backbone.fpn_output3.weight"](grads), trainer.getters["backbone.fpn_output3.weight"](g_prop)
@@ -420,6 +432,7 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
              "roi_heads.box_head.0.fc1.weight", "roi_heads.box_head.2.fc2.weight", "roi_heads.box_predictor.1.cls_score.linear.weight",
              "roi_heads.box_predictor.2.bbox_pred.0.weight"]
     worst = 0.0
+    measured = {}
     for name in probe:
         mine = trainer.getters[name](grads).cpu()
         want = sd[name].grad
@@ -432,7 +445,10 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
         want = want.reshape(mine.shape)
         l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
         worst = max(worst, l2)
+        measured[name] = l2
         assert l2 <= 5e-3, (name, l2)
+    _report("training_gradient_l2_640x640", dict(measured, losses_relative={k: abs(float(losses[k]) - float(v.detach())) /
+                                                                             max(abs(float(v.detach())), 1e-3) for k, v in ref.items()}))
     print("640x640 training parity: %d proposals (%d in another order than the oracle's), %d sampled rows (%d foreground), worst probe "
           "gradient L2 %.2e" % (props.shape[0], swapped, rows.shape[0], n_fg, worst))
 
@@ -534,3 +550,38 @@ def test_training_mode_forward_sums_frames_and_steps(synthetic_sd):
     a, b = model2.backbone.bottom_up.blocks[5][2].w, model.backbone.bottom_up.blocks[5][2].w      # re-folded with its FrozenBatchNorm
     assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
     assert torch.equal(model2.backbone.lateral[4].w, model.backbone.lateral[4].w)
+
+
+@pytest.mark.gpu
+def test_training_without_a_memory_leaves_the_projections_alone(synthetic_sd):
+    """`MODEL.MEMORY_TYPE ''` (the non-recurrent detector the reference also trains): a frame carries no memory, the map_merge
+    projections get no gradient -- `None`, skipped by the optimizer as torch skips a parameter whose `.grad` is None -- and every
+    other group steps; both entries (`trainer.step` on one frame, `model(data)` + `optimizer_step` over sequences)."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["SOLVER.BASE_LR", 2e-5, "FP16", False])
+    assert cfg.MODEL.MEMORY_TYPE == ""
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    H, W = 128, 160
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    gt = torch.tensor([[10.0, 12.0, 60.0, 70.0], [40.0, 30.0, 150.0, 120.0], [90.0, 8.0, 118.0, 40.0]])
+    gc = torch.tensor([1, 4, 9])
+    merge_before = [w.clone() for w in trainer.merge_w] + [b.clone() for b in trainer.merge_b]
+    fc2_before = model.roi_heads.stages[0]["fc2"].w.clone()
+    losses = trainer.step(img.to(dev), gt.to(dev), gt_classes=gc.int().to(dev), generator=torch.Generator(device=dev).manual_seed(1))
+    assert len(losses) == 10 and all(bool(torch.isfinite(v)) for v in losses.values())
+    frame = {"image": img, "instances": {"gt_boxes": gt, "gt_classes": gc}, "sequence_name": "s0", "memory_reset": True}
+    model.train()
+    out = model([[frame, dict(frame, memory_reset=False)], [frame]])
+    assert len(out) == 10
+    assert all(a is None for a, g_ in zip(trainer._acc, trainer.groups) if "map_merge" in g_["name"])
+    assert all(a is not None for a, g_ in zip(trainer._acc, trainer.groups) if "map_merge" not in g_["name"])
+    trainer.optimizer_step()
+    model.eval()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(merge_before, trainer.merge_w + trainer.merge_b))
+    assert not torch.equal(fc2_before, model.roi_heads.stages[0]["fc2"].w)

@@ -52,6 +52,7 @@ def main():
     for _ in range(a.warmup):
         losses.append(sum(float(v) for v in trainer.step(img, gt, memory=(mem16, proj), **kw).values()))
     torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = trainer.step(img, gt, memory=(mem16, proj), **kw)
@@ -63,6 +64,7 @@ def main():
     print(json.dumps({"metric": "training_iterations_per_second" + ("" if a.roi_heads else "_proposal_half"), **extra, "value": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 2),
                       "size": [H, W], "gt_boxes": 24, "steps": a.steps, "warmup": a.warmup, "dtype": "f32",
                       "total_loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+                      "device_mb_allocated_before_after_the_timed_steps": [round(mem0 / 2**20, 1), round(torch.cuda.memory_allocated(dev) / 2**20, 1)],
                       "note": "one frame per iteration, parameters stepped in the layers the inference path runs"}))
 
 

@@ -23,6 +23,44 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _usage_file(src: str) -> str:
+    return os.path.join(HERE, "build", src.replace(".hip", ".usage.txt"))
+
+
+def resource_usage() -> dict:
+    """{kernel symbol: {'vgprs', 'scratch', 'occupancy', 'lds'}} of the last build, from the compiler's own remarks
+    (`-Rpass-analysis=kernel-resource-usage`, kept per translation unit under build/).  Empty when the library was not built here."""
+    import re
+    out = {}
+    for src in SOURCES:
+        f = _usage_file(src)
+        if not os.path.exists(f):
+            continue
+        cur = None
+        for line in open(f):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+                m = re.search(pat, line)
+                if m and cur is not None:
+                    cur[key] = int(m.group(1))
+    return out
+
+
+# kernels of the dense path must not touch scratch memory: a spill in an epilogue costs a launch its wave-launch rate (round 4: one
+# more conditional load in the shared epilogue spilled in the 128-wide and bf16x3 kernels, 352 -> 214 frames/s in that arithmetic)
+NO_SCRATCH = ("conv_igemm_kernel", "conv_bf16x3", "conv_wavek_kernel", "conv_splitk_reduce", "conv_backward_weights", "roi_align_kernel",
+              "project_fuse_kernel", "gather_pool_kernel")
+
+
+def scratch_offenders(usage: dict = None) -> list:
+    usage = resource_usage() if usage is None else usage
+    return sorted(k for k, v in usage.items() if v.get("scratch", 0) > 0 and any(n in k for n in NO_SCRATCH))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
@@ -33,14 +71,29 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-               "-ffp-contract=on", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
+        procs.append((src, subprocess.Popen(cmd, stderr=open(_usage_file(src), "w"))))
         objs.append(obj)
     failed = [s for s, p in procs if p.wait() != 0]
+    for src in SOURCES:                       # the compiler's other diagnostics (warnings, errors) still reach the terminal
+        skip = 0
+        for line in open(_usage_file(src)):
+            if "kernel-resource-usage" in line:
+                skip = 2 if "Function Name" in line else 0      # the remark that names a kernel is followed by its source line + caret
+                continue
+            if skip and (line.lstrip()[:1].isdigit() or line.strip().startswith("|")):
+                skip -= 1
+                continue
+            skip = 0
+            if line.strip():
+                sys.stderr.write(line)
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
+    bad = scratch_offenders()
+    if bad:
+        raise RuntimeError("kernels of the dense path use scratch memory (register spills): " + ", ".join(bad))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

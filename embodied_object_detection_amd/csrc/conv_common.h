@@ -67,6 +67,10 @@ __device__ __forceinline__ bool conv_tile_active(const ConvArgs& p, int m0, int 
   return false;
 }
 
+// GATE: the kernel honours ConvArgs.gate (the 64x64 fp32 tile, the wave-K kernel and the slab reduces: the plans a gated layer is
+// given).  The larger tiles and the bf16x3 kernels are compiled without the extra load: with it their register allocation
+// spilled (320 bytes of scratch per lane, bf16x3 frame rate 352 -> 214).
+template <bool GATE = false>
 __device__ __forceinline__ float epilogue_store(const ConvArgs& p, float v, int m, int n) {
   int co = n;
   size_t oidx;
@@ -105,7 +109,7 @@ __device__ __forceinline__ float epilogue_store(const ConvArgs& p, float v, int 
     return v;
   }
   if (p.relu) v = fmaxf(v, 0.0f);
-  if (p.gate && !(p.gate[oidx] > 0.0f)) v = 0.0f;
+  if (GATE && p.gate && !(p.gate[oidx] > 0.0f)) v = 0.0f;
   p.y[oidx] = v;
   return v;
 }
@@ -126,7 +130,7 @@ __device__ __forceinline__ unsigned long long tap_mask(int iy0, int ix0, int hh,
 
 // Stores one wave's accumulators (TM x TN tiles of 32x32, MFMA C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
 // through the fused epilogue, or as a split-K slab.
-template <int TM, int TN>
+template <int TM, int TN, bool GATE = false>
 __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16 (&acc)[TM][TN], int m_base, int n_base, int M, int z,
                                                  int lane) {
   const int half = lane >> 5;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void store_wave_tiles(const ConvArgs& p, const f32x16
           if (p.splitk > 1) {
             p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
           } else {
-            epilogue_store(p, v, m, n);
+            epilogue_store<GATE>(p, v, m, n);
           }
         }
       }

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       return;
     }
   }
-  store_wave_tiles<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
+  store_wave_tiles<TM, TN, BM == 64 && BN == 64>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, z, lane);
 }
 
 
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wavek_kernel(ConvArgs p) {
     for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
   f32x16 out[1][1];
   out[0][0] = acc;
-  store_wave_tiles<1, 1>(p, out, m0, n0, M, 0, lane);
+  store_wave_tiles<1, 1, true>(p, out, m0, n0, M, 0, lane);
 }
 
 }  // namespace

@@ -40,14 +40,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p) {
         for (int j = 0; j < 4; ++j)
           if (zb + j < p.splitk) v += t[j];
       }
-      epilogue_store(p, v.x, (int)m, (int)n);
-      epilogue_store(p, v.y, (int)m, (int)n + 1);
-      epilogue_store(p, v.z, (int)m, (int)n + 2);
-      epilogue_store(p, v.w, (int)m, (int)n + 3);
+      epilogue_store<true>(p, v.x, (int)m, (int)n);
+      epilogue_store<true>(p, v.y, (int)m, (int)n + 1);
+      epilogue_store<true>(p, v.z, (int)m, (int)n + 2);
+      epilogue_store<true>(p, v.w, (int)m, (int)n + 3);
     } else {
       float v = 0.f;
       for (int z = 0; z < p.splitk; ++z) v += src[z * slab];
-      epilogue_store(p, v, (int)m, (int)n);
+      epilogue_store<true>(p, v, (int)m, (int)n);
     }
   }
 }
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_gn_kernel(ConvArgs p) 
       for (int j = 0; j < 4; ++j)
         if (zb + j < p.splitk) v += t[j];
     }
-    const double o0 = (double)epilogue_store(p, v.x, r, col * 4 + 0);
-    const double o1 = (double)epilogue_store(p, v.y, r, col * 4 + 1);
-    const double o2 = (double)epilogue_store(p, v.z, r, col * 4 + 2);
-    const double o3 = (double)epilogue_store(p, v.w, r, col * 4 + 3);
+    const double o0 = (double)epilogue_store<true>(p, v.x, r, col * 4 + 0);
+    const double o1 = (double)epilogue_store<true>(p, v.y, r, col * 4 + 1);
+    const double o2 = (double)epilogue_store<true>(p, v.z, r, col * 4 + 2);
+    const double o3 = (double)epilogue_store<true>(p, v.w, r, col * 4 + 3);
     s += o0; q += o0 * o0;
     s += o1; q += o1 * o1;
     s += o2; q += o2 * o2;
@@ -197,6 +197,10 @@ Plan make_plan(const EodConvDesc* d, int M, int nchunks32) {
   }
   if (d->out_mode == 2) {   // one workgroup owns all 256 channels of a deconv quadrant; fp32 kernel in every arithmetic mode
     pick = 4;
+    pl.glds = 0;
+  }
+  if (d->gate) {            // the gated epilogue lives in the 64x64 fp32 tile, the wave-K kernel and the slab reduces
+    pick = 2;
     pl.glds = 0;
   }
   pl.bk = (pl.glds || d->out_mode == 2) ? 32 : ((fbk == 2 && bk64_ok) ? 64 : (fbk == 1 ? 32 : (bk64_ok && default_bk() == 64 ? 64 : 32)));
@@ -312,6 +316,8 @@ int check_desc(const EodConvDesc* d) {
     if (((long)(d->N / d->m_segments) * d->OH * d->OW) % d->m_unit != 0) return EOD_ERR_BAD_DIMS;
   }
   if (d->gate && (d->out_mode != 0 || d->split_n != 0 || d->gn_partial)) return EOD_ERR_BAD_DIMS;
+  if (d->gate && d->force_tile != 0 && d->force_tile % 10 != 3 && d->force_tile != 6 && d->force_tile != 7) return EOD_ERR_BAD_DIMS;
+  if (d->gate && d->force_tile / 10 == 5) return EOD_ERR_BAD_DIMS;          // no gated epilogue in the bf16x3 kernels
   if (d->lds_reserve < 0 || d->lds_reserve > 48 * 1024) return EOD_ERR_BAD_DIMS;
   if (d->split_n != 0) {
     if (!d->y2) return EOD_ERR_NULL;

@@ -590,6 +590,7 @@ class Trainer(ProposalTrainer):
     def __init__(self, model, sd: Dict[str, torch.Tensor]):
         super().__init__(model, sd, roi_heads=True)
         self._acc = None
+        self._copy_stream = None
         model.trainer = self                      # `model.train(); model(data)` reaches `forward_backward_frames` (meta_arch.forward)
 
     @staticmethod
@@ -611,28 +612,54 @@ class Trainer(ProposalTrainer):
         dev = self.dev
         total: Dict[str, torch.Tensor] = {}
         acc = None
-        for seq in batched_inputs:
-            for frame in seq:
-                img = torch.as_tensor(frame["image"]).to(dev)
+        frames = [frame for seq in batched_inputs for frame in seq]
+        main = torch.cuda.current_stream(dev)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+
+        def stage(frame):
+            """The frame's tensors on the device, copied on the copy stream (the memory table alone is 82 MB at 200 x 200 cells:
+            ~2 ms per frame on the compute stream otherwise) while the frame before computes -> (tensors, event)."""
+            with torch.cuda.stream(self._copy_stream):
+                t = {"image": torch.as_tensor(frame["image"]).to(dev, non_blocking=True)}
                 gt_boxes, gt_classes = self._gt(frame)
-                memory = None
+                t["gt_boxes"] = gt_boxes.to(dev, non_blocking=True).contiguous()
+                t["gt_classes"] = gt_classes.to(dev, non_blocking=True)
                 if self.model.memory_type == "implicit_memory":
                     if frame.get("observations") is None:
                         raise ValueError("training reads frame['observations'] (custom_rcnn.py:765): point MODEL.SEMMAP_PATH at the "
                                          "memory snapshots (`impicit_memory` / `observations` per episode file, loader.py:213-223)")
-                    mem = torch.as_tensor(frame["memory"]).to(dev, torch.float32).contiguous()
-                    obs = torch.as_tensor(frame["observations"]).to(dev, torch.float32).reshape(-1).contiguous()
-                    proj = torch.as_tensor(frame["proj_indices"]).to(dev).reshape(int(img.shape[1]), int(img.shape[2])).to(torch.int32).contiguous()
-                    memory = (ops.memory_normalize_f16(mem, obs), proj)
-                losses, grads = self.fm.forward_backward(img, gt_boxes.to(dev).contiguous(), gt_classes.to(dev), memory=memory,
-                                                         generator=generator)
-                gl = [self.step_getters[g["name"]](grads) for g in self.groups]
-                if acc is None:
-                    acc = [None if t is None else t.clone() for t in gl]
-                else:
-                    acc = [a if t is None else (t.clone() if a is None else a.add_(t)) for a, t in zip(acc, gl)]
-                for k, v in losses.items():
-                    total[k] = v.clone() if k not in total else total[k] + v
+                    H, W = int(t["image"].shape[1]), int(t["image"].shape[2])
+                    t["mem"] = torch.as_tensor(frame["memory"]).to(dev, torch.float32, non_blocking=True).contiguous()
+                    t["obs"] = torch.as_tensor(frame["observations"]).to(dev, torch.float32, non_blocking=True).reshape(-1).contiguous()
+                    t["proj"] = torch.as_tensor(frame["proj_indices"]).to(dev, non_blocking=True).reshape(H, W).to(torch.int32).contiguous()
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            return t, ev
+
+        staged = stage(frames[0]) if frames else None
+        for i in range(len(frames)):
+            t, ev = staged
+            staged = stage(frames[i + 1]) if i + 1 < len(frames) else None      # the next frame's copies run beside this frame's step
+            main.wait_event(ev)
+            for v in t.values():
+                v.record_stream(main)
+            memory = None
+            if "mem" in t:
+                memory = (ops.memory_normalize_f16(t["mem"], t["obs"]), t["proj"])
+            losses, grads = self.fm.forward_backward(t["image"], t["gt_boxes"], t["gt_classes"], memory=memory, generator=generator)
+            gl = [self.step_getters[g["name"]](grads) for g in self.groups]
+            if acc is None:
+                acc = [None if g_ is None else g_.clone() for g_ in gl]
+            else:
+                # the frames' gradients are summed as the single `losses.backward()` of the reference sums them; one multi-tensor
+                # add for the tensors both sides have
+                both = [(a, g_) for a, g_ in zip(acc, gl) if a is not None and g_ is not None]
+                if both:
+                    torch._foreach_add_([a for a, _ in both], [g_ for _, g_ in both])
+                acc = [a if g_ is None else (g_.clone() if a is None else a) for a, g_ in zip(acc, gl)]
+            for k, v in losses.items():
+                total[k] = v.clone() if k not in total else total[k] + v
         self._acc = acc
         return total
 

@@ -50,15 +50,12 @@ def resource_usage() -> dict:
     return out
 
 
-# kernels of the dense path must not touch scratch memory: a spill in an epilogue costs a launch its wave-launch rate (round 4: one
-# more conditional load in the shared epilogue spilled in the 128-wide and bf16x3 kernels, 352 -> 214 frames/s in that arithmetic)
-NO_SCRATCH = ("conv_igemm_kernel", "conv_bf16x3", "conv_wavek_kernel", "conv_splitk_reduce", "conv_backward_weights", "roi_align_kernel",
-              "project_fuse_kernel", "gather_pool_kernel")
-
-
+# No kernel of the library touches scratch memory.  Round 4: one more conditional load in the shared conv epilogue spilled in the
+# 128-wide and bf16x3 kernels (nothing failed; 352 -> 214 frames/s in that arithmetic), and the proposal kernels of the frame's
+# critical chain kept a 168-byte copy of their argument struct in scratch because they wrote to two of its fields.
 def scratch_offenders(usage: dict = None) -> list:
     usage = resource_usage() if usage is None else usage
-    return sorted(k for k, v in usage.items() if v.get("scratch", 0) > 0 and any(n in k for n in NO_SCRATCH))
+    return sorted(k for k, v in usage.items() if v.get("scratch", 0) > 0)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -93,7 +90,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         raise RuntimeError(f"hipcc failed for {failed}")
     bad = scratch_offenders()
     if bad:
-        raise RuntimeError("kernels of the dense path use scratch memory (register spills): " + ", ".join(bad))
+        raise RuntimeError("kernels that use scratch memory (register spills / an argument struct copied to private memory): " + ", ".join(bad))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

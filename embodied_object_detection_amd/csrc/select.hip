@@ -500,8 +500,10 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
   const int r0 = p.level_off[level];
   const int n = p.level_off[level + 1] - r0;
   const size_t head0 = cn_head_row(p, scene, level, 0);
-  p.cand_keys += (size_t)scene * p.pk_off[p.levels];
-  p.cand_cnt += scene * 8;
+  // (the argument struct is not written to: a modified copy lives in scratch memory -- 168 bytes per lane -- and every indexed
+  // read of the level tables goes through it)
+  u64* const cand_keys = p.cand_keys + (size_t)scene * p.pk_off[p.levels];
+  int* const cand_cnt = p.cand_cnt + scene * 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
   if (tid == 0) {
@@ -575,14 +577,14 @@ __global__ __launch_bounds__(1024) void cn_level_topk_kernel(CnArgs p) {
   __syncthreads();
   const int n2 = sh_n2;                              // take <= n2 <= cnt
   const int slots = p.pk_off[level + 1] - p.pk_off[level];
-  u64* out = p.cand_keys + p.pk_off[level];
+  u64* out = cand_keys + p.pk_off[level];
   const int ns = n2 > slots ? n2 : slots;            // the sort's size must also cover the slots it zero-fills
   if (ns <= 1024) cn_sort_emit<1>(xch, n2, take, r0, slots, out);
   else if (ns <= 2048) cn_sort_emit<2>(xch, n2, take, r0, slots, out);
   else if (ns <= 4096) cn_sort_emit<4>(xch, n2, take, r0, slots, out);
   else if (EMAX <= 8 || ns <= 8192) cn_sort_emit<8>(xch, n2, take, r0, slots, out);
   else cn_sort_emit<(EMAX > 8 ? 16 : 8)>(xch, n2, take, r0, slots, out);
-  if (tid == 0) p.cand_cnt[level] = take;
+  if (tid == 0) cand_cnt[level] = take;
 }
 
 // single block: merge the per-level lists, sort by sqrt-score, decode boxes (E*1024 >= packed slots: E = 4 covers the usual
@@ -595,8 +597,8 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
   static_assert(sizeof(NmsSmem) <= sizeof(u64) * 1024 * E, "the NMS state reuses the sort's exchange buffer");
   const int total_slots = p.pk_off[p.levels];
   const int scene = blockIdx.x;
-  p.cand_keys += (size_t)scene * total_slots;
-  p.cand_cnt += scene * 8;
+  const u64* const cand_keys = p.cand_keys + (size_t)scene * total_slots;
+  const int* const cand_cnt = p.cand_cnt + scene * 8;
   sorted_boxes += (size_t)scene * total_slots * 4;
   sorted_scores += (size_t)scene * total_slots;
   o = scene_outputs(o, scene);
@@ -605,11 +607,11 @@ __global__ __launch_bounds__(1024) void cn_merge_nms_kernel(CnArgs p, float* sor
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int i = threadIdx.x * E + e;
-    v[e] = i < total_slots ? p.cand_keys[i] : 0ull;
+    v[e] = i < total_slots ? cand_keys[i] : 0ull;
   }
   EOD_STAMP(1);
   int n = 0;
-  for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
+  for (int l = 0; l < p.levels; ++l) n += cand_cnt[l];
   // Decode the boxes of the sorted keys held in `keys` (registers of a full sort, or the sorted LDS list of the best candidates)
   auto decode = [&](int r, u64 k) {
     const int g = (int)key_index(k);
@@ -749,21 +751,21 @@ __device__ __forceinline__ int cn_count_above(const u64* __restrict__ keys, int 
 __global__ __launch_bounds__(256) void cn_rank_decode_kernel(CnArgs p, float* sorted_boxes, float* sorted_scores, int* n_out) {
   const int total_slots = p.pk_off[p.levels];
   const int scene = blockIdx.y;
-  p.cand_keys += (size_t)scene * total_slots;
-  p.cand_cnt += scene * 8;
+  const u64* const cand_keys = p.cand_keys + (size_t)scene * total_slots;
+  const int* const cand_cnt = p.cand_cnt + scene * 8;
   sorted_boxes += (size_t)scene * total_slots * 4;
   sorted_scores += (size_t)scene * total_slots;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) {
     int n = 0;
-    for (int l = 0; l < p.levels; ++l) n += p.cand_cnt[l];
+    for (int l = 0; l < p.levels; ++l) n += cand_cnt[l];
     n_out[scene] = n;
   }
   if (s >= total_slots) return;
   int level = 0;
   while (level + 1 < p.levels && s >= p.pk_off[level + 1]) ++level;
-  if (s - p.pk_off[level] >= p.cand_cnt[level]) return;
-  const u64 k = p.cand_keys[s];
+  if (s - p.pk_off[level] >= cand_cnt[level]) return;
+  const u64 k = cand_keys[s];
   const float sc = key_score(k);
   const unsigned g = key_index(k);
   // rank = number of candidates that precede k in (score desc, position asc) order.  A level list is sorted by the HEAT; sqrt is
@@ -771,8 +773,8 @@ __global__ __launch_bounds__(256) void cn_rank_decode_kernel(CnArgs p, float* so
   // a sqrt in fp32, and quantised logits give long runs)
   int rank = 0;
   for (int l = 0; l < p.levels; ++l) {
-    const u64* lk = p.cand_keys + p.pk_off[l];
-    const int nl = p.cand_cnt[l];
+    const u64* lk = cand_keys + p.pk_off[l];
+    const int nl = cand_cnt[l];
     const int a = cn_count_above(lk, nl, sc, 1), b = cn_count_above(lk, nl, sc, 0);
     rank += a;
     for (int q = a; q < b; ++q) rank += key_index(lk[q]) < g ? 1 : 0;

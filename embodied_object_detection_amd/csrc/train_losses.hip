@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void centernet_loss_dense_kernel(CnLossArgs a)
     const float tl = a.reg_t[i * 4 + 0], tt = a.reg_t[i * 4 + 1], tr = a.reg_t[i * 4 + 2], tb = a.reg_t[i * 4 + 3];
     float g4[4] = {0.f, 0.f, 0.f, 0.f};
     if (fmaxf(fmaxf(tl, tt), fmaxf(tr, tb)) >= 0.f) {
-      int l = 0;
-      while (l + 1 < a.levels && i >= a.lv_off[l + 1]) ++l;
-      const float sc = a.lv_scale[l];
+      // the level's Scale by a chain of selects over the (ascending) level offsets: indexing the kernel arguments with a per-lane
+      // level makes the compiler keep a copy of the argument struct in scratch memory (216 bytes per lane)
+      float sc = a.lv_scale[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q)
+        if (q < a.levels && i >= a.lv_off[q]) sc = a.lv_scale[q];
       const float r0 = h[1] * sc, r1 = h[2] * sc, r2 = h[3] * sc, r3 = h[4] * sc;
       const float pl = fmaxf(r0, 0.f), pt = fmaxf(r1, 0.f), pr = fmaxf(r2, 0.f), pb = fmaxf(r3, 0.f);
       const float t_area = (tl + tr) * (tt + tb), p_area = (pl + pr) * (pt + pb);

@@ -663,9 +663,10 @@ def test_trainer_reads_ground_truth_of_both_frame_formats():
 
 
 def test_dense_kernels_compile_without_scratch_memory():
-    """`build.resource_usage()` (the compiler's own kernel-resource remarks of the last build): the conv / GEMM, weight-gradient,
-    ROIAlign and memory-read kernels use no scratch memory.  Round 4: one more conditional load in the shared conv epilogue spilled
-    320 bytes per lane in the 128-wide and bf16x3 kernels -- nothing failed, that arithmetic's frame rate fell from 352 to 214."""
+    """`build.resource_usage()` (the compiler's own kernel-resource remarks of the last build): no kernel of the library uses
+    scratch memory.  Round 4: one more conditional load in the shared conv epilogue spilled 320 bytes per lane in the 128-wide and
+    bf16x3 kernels -- nothing failed, that arithmetic's frame rate fell from 352 to 214 -- and the proposal kernels of the critical
+    chain kept their argument struct in scratch."""
     import __graft_entry__
     from embodied_object_detection_amd import build
     __graft_entry__.build()

@@ -39,23 +39,41 @@ class BackboneBackward:
         return self._bw[id(conv)]
 
     # ---- forward that keeps its activations -------------------------------------------------------------------------------
-    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, memory=None):
-        """-> ([P3..P7] as [N,h,w,256] tensors, saved).  `memory = (memory_f16, proj)`: the memory read + sum fusion into P3..P5 as
-        the hot path runs it (`eod_memory_gather_pool` + `eod_memory_project_fuse`; N == 1); None = image only."""
+    # Two halves: the TRUNK half (ResNet-50 + FPN laterals / top-down / output convs -> P3..P5 before the fusion) does not depend
+    # on the memory and runs for N images in one launch per layer; the TAIL half (memory read + sum fusion, P6 / P7) is per scene.
+    # `forward` = trunk + tail for the single-frame step; a batch of frames shares one trunk pass (`ProposalTraining.
+    # forward_backward_batch`).
+    def forward_trunk(self, x4: torch.Tensor, H: int, W: int, N: int = 1):
+        """-> ([p3, p4, p5] as [N,h,w,256] before the memory fusion, keep)."""
         bb = self.bb
         keep: dict = {}
         c = bb.bottom_up.forward(x4, H, W, N, keep=keep)
         (c5, h5, w5), (c4, h4, w4), (c3, h3, w3) = c["layer5"], c["layer4"], c["layer3"]
-        lat5 = bb.lateral[5](c5, N, h5, w5)
-        p5 = bb.output[5](lat5, N, h5, w5)
-        lat4 = bb.lateral[4](c4, N, h4, w4, res=lat5, res_mode=2)
-        p4 = bb.output[4](lat4, N, h4, w4)
-        lat3 = bb.lateral[3](c3, N, h3, w3, res=lat4, res_mode=2)
-        p3 = bb.output[3](lat3, N, h3, w3)
-        P = [p3, p4, p5]
-        keep["pooled"] = None
+        # N > 1: planned like a single image (`plan_rows`: the same split-K walk), so every image's levels are bitwise those of its
+        # own N = 1 pass -- as the trunk's layers are (`ResNet50Trunk.forward`) -- and the selections behind them cannot flip
+        pr = (lambda h, w: h * w) if N > 1 else (lambda h, w: 0)
+        lat5 = bb.lateral[5](c5, N, h5, w5, plan_rows=pr(h5, w5))
+        p5 = bb.output[5](lat5, N, h5, w5, plan_rows=pr(h5, w5))
+        lat4 = bb.lateral[4](c4, N, h4, w4, res=lat5, res_mode=2, plan_rows=pr(h4, w4))
+        p4 = bb.output[4](lat4, N, h4, w4, plan_rows=pr(h4, w4))
+        lat3 = bb.lateral[3](c3, N, h3, w3, res=lat4, res_mode=2, plan_rows=pr(h3, w3))
+        p3 = bb.output[3](lat3, N, h3, w3, plan_rows=pr(h3, w3))
+        h6, w6 = bb.p6.out_hw(h5, w5)
+        keep["fpn"] = dict(c=(c3, c4, c5), lat=(lat3, lat4, lat5), hw=((h3, w3), (h4, w4), (h5, w5), (h6, w6)))
+        keep["N"], keep["x4"], keep["HW"] = N, x4, (H, W)
+        return [p3, p4, p5], keep
+
+    def forward_tail(self, p345: List[torch.Tensor], H: int, W: int, memory=None):
+        """[p3, p4, p5] of n images ([n,h,w,256]; n == 1 with a memory) -> ([P3..P7], tail): the memory read + sum fusion into
+        P3..P5 as the hot path runs it (`eod_memory_gather_pool` + `eod_memory_project_fuse`; the inputs are not written to), then
+        P6 / P7.  `memory = (memory_f16, proj)` or None = image only."""
+        bb = self.bb
+        P = list(p345)
+        n = int(P[0].shape[0])
+        h5, w5 = int(P[2].shape[1]), int(P[2].shape[2])
+        pooled = None
         if memory is not None and bb.feat_fusion == "sum":
-            if N != 1:
+            if n != 1:
                 raise ValueError("the memory fusion is per scene: N == 1")
             rows = torch.cat([p.reshape(-1, 256) for p in P])
             pooled = ops.memory_gather_pool(memory[0], memory[1], H, W, torch_order=bb.pool_in_torch_order)
@@ -64,13 +82,20 @@ class BackboneBackward:
             for i, p in enumerate(P):
                 P[i] = rows[o:o + p.shape[1] * p.shape[2]].view(p.shape)
                 o += p.shape[1] * p.shape[2]
-            keep["pooled"] = pooled
-        p6 = bb.p6(P[2], N, h5, w5)
+        p6 = bb.p6(P[2], n, h5, w5)
         h6, w6 = bb.p6.out_hw(h5, w5)
-        p7 = bb.p7(p6, N, h6, w6, in_relu=True)
-        keep["fpn"] = dict(c=(c3, c4, c5), lat=(lat3, lat4, lat5), P=P, p6=p6, hw=((h3, w3), (h4, w4), (h5, w5), (h6, w6)))
-        keep["N"], keep["x4"], keep["HW"] = N, x4, (H, W)
-        return P + [p6, p7], keep
+        p7 = bb.p7(p6, n, h6, w6, in_relu=True)
+        return P + [p6, p7], dict(P=P, p6=p6, pooled=pooled, HW=(H, W))
+
+    def forward(self, x4: torch.Tensor, H: int, W: int, N: int = 1, memory=None):
+        """-> ([P3..P7] as [N,h,w,256] tensors, saved).  `memory = (memory_f16, proj)`: the memory read + sum fusion into P3..P5 as
+        the hot path runs it (`eod_memory_gather_pool` + `eod_memory_project_fuse`; N == 1); None = image only."""
+        p345, keep = self.forward_trunk(x4, H, W, N)
+        P, tail = self.forward_tail(p345, H, W, memory)
+        keep["tail"] = tail
+        keep["pooled"] = tail["pooled"]
+        keep["fpn"].update(P=tail["P"], p6=tail["p6"])
+        return P, keep
 
     # ---- backward ------------------------------------------------------------------------------------------------------------
     def _relu_bw(self, g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -85,15 +110,18 @@ class BackboneBackward:
     def backward(self, saved: dict, dP: List[torch.Tensor], need_stem_grad: bool = True):
         """dP: dL/d(P3..P7) ([N,h,w,256] each) -> (grads {conv.name: (dw, db)}, dL/d(stem pre-activation) or None; without
         `need_stem_grad` the chain stops at the max pool and the stem gets no entry)."""
-        bb, N = self.bb, saved["N"]
-        f = saved["fpn"]
-        (c3, c4, c5), (lat3, lat4, lat5), P, p6 = f["c"], f["lat"], f["P"], f["p6"]
-        (h3, w3), (h4, w4), (h5, w5), (h6, w6) = f["hw"]
+        grads, g_out = self.backward_tail(saved["tail"], dP)
+        tg, g_stem = self.backward_trunk(saved, g_out, need_stem_grad)
+        grads.update(tg)
+        return grads, g_stem
+
+    def backward_tail(self, tail: dict, dP: List[torch.Tensor]):
+        """The tail half's backward: P7, P6, the memory branch's dW / db -> (grads, [g3, g4, g5] = dL/d(p3..p5 before the fusion))."""
+        bb = self.bb
+        P, p6 = tail["P"], tail["p6"]
         grads: Dict[str, tuple] = {}
 
         def put(conv, r):
-            if conv.name in grads:
-                raise RuntimeError(f"layer {conv.name} visited twice")
             grads[conv.name] = (r["dw"], r["db"])
 
         # P7 = conv(relu(P6)), P6 = conv(P5 fused)
@@ -104,17 +132,33 @@ class BackboneBackward:
         r = self._b(bb.p6)(P[2].contiguous(), None, g6.contiguous(), dx_res=dP[2].contiguous())    # P5 also feeds P6: both gradients
         put(bb.p6, r)
         g_out = [dP[0].contiguous(), dP[1].contiguous(), r["dx"]]      # sum fusion: identity to the image branch
-        if saved["pooled"] is not None:
+        if tail["pooled"] is not None:
             # the memory branch of the fusion: dW / db of the map_merge projections (timm.py:170-178)
             if self._merge_bw is None:
                 if self.merge_weights is None:
                     raise ValueError("pass the map_merge_projection weights (merge_weights=) to back-propagate into the memory branch")
                 self._merge_bw = ops.MemoryProjectorBackward(self.merge_weights, self.bb.device)
-            H, W = saved["HW"]
+            H, W = tail["HW"]
             # the memory table is an input of the training step, not a parameter (loader.py:199-223): only dW / db are needed
-            mb = self._merge_bw([t.view(-1, 256) for t in g_out], saved["pooled"], H, W, bb.map_feature_weight, need_input_grad=False)
+            mb = self._merge_bw([t.view(-1, 256) for t in g_out], tail["pooled"], H, W, bb.map_feature_weight, need_input_grad=False)
             for i in range(3):
                 grads[f"map_merge_projection{i + 1}"] = (mb["dW"][i], mb["db"][i])
+        return grads, g_out
+
+    def backward_trunk(self, saved: dict, g_out: List[torch.Tensor], need_stem_grad: bool = True):
+        """g_out: dL/d(p3..p5) of the N images of `forward_trunk` ([N,h,w,256]) -> (grads of the output / lateral convs and the
+        trunk, dL/d(stem pre-activation) or None).  dW / db are sums over the N images (one launch per layer)."""
+        bb, N = self.bb, saved["N"]
+        f = saved["fpn"]
+        (c3, c4, c5), (lat3, lat4, lat5) = f["c"], f["lat"]
+        (h3, w3), (h4, w4), (h5, w5), (h6, w6) = f["hw"]
+        grads: Dict[str, tuple] = {}
+
+        def put(conv, r):
+            if conv.name in grads:
+                raise RuntimeError(f"layer {conv.name} visited twice")
+            grads[conv.name] = (r["dw"], r["db"])
+
         # output convs -> gradients of the merged laterals; top-down add: the coarser level also collects the 2x2 block sums
         r5 = self._b(bb.output[5])(lat5, None, g_out[2])
         put(bb.output[5], r5)

@@ -78,9 +78,50 @@ class ProposalTraining:
 
         `reduce_counts(counts int32 [2]) -> counts` sums the positives / regression rows over the ranks (the reference's
         `reduce_sum`, centernet.py:263-265,293); both are then divided by `world_size`."""
-        m, pg, dev = self.model, self.pg, self.dev
+        m = self.model
         x4, Hp, Wp = ops.preprocess_image(image_u8, m.pixel_mean, m.pixel_std)
-        P, saved = self.bb.forward(x4, Hp, Wp, memory=memory)
+        p345, saved = self.bb.forward_trunk(x4, Hp, Wp, 1)
+        losses, grads, g_out = self._frame_on_pyramid(p345, saved, Hp, Wp, gt_boxes, memory, world_size, reduce_counts, roi_half)
+        bgrads, _ = self.bb.backward_trunk(saved, g_out)
+        grads.update(bgrads)
+        if self.side:
+            ops.ConvBackward.join(self.dev)                           # the weight gradients ran on their own stream (ops.ConvBackward)
+        return losses, grads
+
+    def forward_backward_batch(self, images: List[torch.Tensor], gt_boxes: List[torch.Tensor], memories: List, world_size: int = 1,
+                               reduce_counts=None, roi_halves: Optional[List] = None):
+        """`forward_backward` for B frames of one image size: the memory-independent trunk half (ResNet-50, FPN laterals / top-down /
+        output convs) runs ONCE for the B images, forward and backward -- one launch per layer over N = B, planned like a single
+        image (every frame's pyramid is bitwise the single-frame one), weight gradients summed over the frames by the launch --
+        and everything that is per scene (memory fusion, P6 / P7, heads, losses, their backward) frame by frame in between.
+        -> ([losses of frame b], grads summed over the frames: what one `losses.backward()` over the summed loss gives)."""
+        m, B = self.model, len(images)
+        xs = []
+        for img in images:
+            x4, Hp, Wp = ops.preprocess_image(img, m.pixel_mean, m.pixel_std)
+            xs.append(x4)
+        p345, saved = self.bb.forward_trunk(torch.cat(xs, dim=0), Hp, Wp, B)
+        all_losses, total, g_outs = [], None, []
+        for b in range(B):
+            losses, grads, g_out = self._frame_on_pyramid([p[b:b + 1] for p in p345], None, Hp, Wp, gt_boxes[b], memories[b], world_size,
+                                                          reduce_counts, roi_halves[b] if roi_halves is not None else None)
+            all_losses.append(losses)
+            g_outs.append(g_out)
+            total = grads if total is None else _sum_grads(total, grads)
+        bgrads, _ = self.bb.backward_trunk(saved, [torch.cat([g[l] for g in g_outs], dim=0) for l in range(3)])
+        total.update(bgrads)
+        if self.side:
+            ops.ConvBackward.join(self.dev)
+        return all_losses, total
+
+    def _frame_on_pyramid(self, p345, saved, Hp, Wp, gt_boxes, memory, world_size, reduce_counts, roi_half):
+        """Everything of a frame behind the trunk half: memory fusion + P6 / P7 (`forward_tail`), CenterNet head, targets, proposal
+        losses, the ROI heads' half, and their backward down to the gradient of p3..p5 -> (losses, grads, [g3, g4, g5])."""
+        pg, dev = self.pg, self.dev
+        P, tail = self.bb.forward_tail(p345, Hp, Wp, memory)
+        if saved is not None:                                        # single-frame step: the whole record under one roof (tests)
+            saved["tail"], saved["pooled"] = tail, tail["pooled"]
+            saved["fpn"].update(P=tail["P"], p6=tail["p6"])
         shapes = [(p.shape[1], p.shape[2]) for p in P]
         off = [0]
         for (h, w) in shapes:
@@ -104,6 +145,7 @@ class ProposalTraining:
         if key not in self._loss:
             self._loss[key] = ops.CenterNetLoss(off, pg.scales, dev, head_stride=32, **self.loss_cfg)
         losses_t, d_head = self._loss[key](head, heat, reg_t, pos, counts_local=counts, counts_total=total, world_size=world_size)
+        losses_t = losses_t.clone()              # the loss object's own buffer: the next frame of a batch writes to it again
         losses = {"loss_centernet_loc": losses_t[0], "loss_centernet_agn_pos": losses_t[1], "loss_centernet_agn_neg": losses_t[2]}
         # ---- backward
         grads: Dict[str, tuple] = {}
@@ -129,11 +171,36 @@ class ProposalTraining:
         if roi_dP is not None:
             for l, d in enumerate(roi_dP):
                 dP[l] = (dP[l] + d.view(dP[l].shape)).contiguous()
-        bgrads, _ = self.bb.backward(saved, dP)
-        grads.update(bgrads)
-        if self.side:
-            ops.ConvBackward.join(self.dev)                           # the weight gradients ran on their own stream (ops.ConvBackward)
-        return losses, grads
+        tgrads, g_out = self.bb.backward_tail(tail, dP)
+        grads.update(tgrads)
+        return losses, grads, g_out
+
+
+def _sum_grads(total: dict, grads: dict) -> dict:
+    """total += grads, entry by entry (values: a tensor or a tuple of tensors; an entry only one side has is kept): the frames'
+    gradients of one training iteration, added by one multi-tensor launch."""
+    a_list, b_list = [], []
+    for k, v in grads.items():
+        if k not in total:
+            total[k] = v
+            continue
+        t = total[k]
+        if torch.is_tensor(v):
+            a_list.append(t)
+            b_list.append(v)
+        else:
+            fixed = []
+            for ti, vi in zip(t, v):
+                if ti is None or vi is None:
+                    fixed.append(vi if ti is None else ti)
+                    continue
+                a_list.append(ti)            # (every gradient tensor is the fresh output of its launch, or a view of one)
+                b_list.append(vi)
+                fixed.append(ti)
+            total[k] = tuple(fixed)
+    if a_list:
+        torch._foreach_add_(a_list, b_list)
+    return total
 
 
 class ProposalTrainer:
@@ -582,6 +649,35 @@ class ForwardModelTraining:
                                              roi_half=roi_half)
         return out
 
+    def forward_backward_batch(self, images: List[torch.Tensor], gt_boxes: List[torch.Tensor], gt_classes: List[torch.Tensor],
+                               memories: List, generator: Optional[torch.Generator] = None, world_size: int = 1, reduce_counts=None):
+        """`forward_backward` for B frames of one image size with ONE pass of the memory-independent trunk half for all of them
+        (`ProposalTraining.forward_backward_batch`) -> ([loss dict of frame b], gradients summed over the frames).  The optimistic
+        row counts are verified once for the whole batch; a batch in which a frame fails them is repeated on the exact path."""
+        H, W = int(images[0].shape[1]), int(images[0].shape[2])
+        det = self.det
+        det.speculate = self.speculate and (H, W) not in self._exact_sizes
+        det.checks = []
+
+        def half(b):
+            def roi_half(P, head, shapes, off):
+                props, count = self.train_proposals(head, shapes)
+                self._last_props = (props.clone(), None if count is None else count.clone())
+                losses = det.losses(P[:3], props, gt_boxes[b], gt_classes[b], (H, W), generator=generator, prop_count=count)
+                grads, dP = det.backward(P[:3], join=False)
+                return losses, grads, dP
+            return roi_half
+        halves = [half(b) for b in range(len(images))]
+        out = self.prop.forward_backward_batch(images, gt_boxes, memories, world_size=world_size, reduce_counts=reduce_counts,
+                                               roi_halves=halves)
+        if det.speculate and det.checks and bool(torch.cat(det.checks).any().cpu()):
+            self._exact_sizes.add((H, W))
+            self.repeated_frames += len(images)
+            det.speculate, det.checks = False, []
+            out = self.prop.forward_backward_batch(images, gt_boxes, memories, world_size=world_size, reduce_counts=reduce_counts,
+                                                   roi_halves=halves)
+        return out
+
 
 class Trainer(ProposalTrainer):
     """One optimizer over every trainable parameter of the recurrent detector (build_custom_optimizer's groups, custom_solver.py:19-79)
@@ -591,6 +687,9 @@ class Trainer(ProposalTrainer):
         super().__init__(model, sd, roi_heads=True)
         self._acc = None
         self._copy_stream = None
+        # frames of a training batch that share one pass of the trunk half, forward and backward (`forward_backward_frames`);
+        # 1 = every frame on its own (the two give the same losses, and gradients up to the order of summation over the frames)
+        self.trunk_batch = 4
         model.trainer = self                      # `model.train(); model(data)` reaches `forward_backward_frames` (meta_arch.forward)
 
     @staticmethod
@@ -637,17 +736,37 @@ class Trainer(ProposalTrainer):
                 ev.record(self._copy_stream)
             return t, ev
 
-        staged = stage(frames[0]) if frames else None
-        for i in range(len(frames)):
-            t, ev = staged
-            staged = stage(frames[i + 1]) if i + 1 < len(frames) else None      # the next frame's copies run beside this frame's step
-            main.wait_event(ev)
-            for v in t.values():
-                v.record_stream(main)
-            memory = None
-            if "mem" in t:
-                memory = (ops.memory_normalize_f16(t["mem"], t["obs"]), t["proj"])
-            losses, grads = self.fm.forward_backward(t["image"], t["gt_boxes"], t["gt_classes"], memory=memory, generator=generator)
+        # consecutive frames of one image size share a pass of the memory-independent trunk half (`trunk_batch` frames at a time)
+        B = max(1, int(self.trunk_batch))
+        batches: List[list] = []
+        for frame in frames:
+            shape = tuple(torch.as_tensor(frame["image"]).shape)
+            if batches and len(batches[-1]) < B and batches[-1][0][0] == shape:
+                batches[-1].append((shape, frame))
+            else:
+                batches.append([(shape, frame)])
+
+        def stage_batch(batch):
+            return [stage(frame) for _, frame in batch]
+
+        staged = stage_batch(batches[0]) if batches else None
+        for i in range(len(batches)):
+            cur = staged
+            staged = stage_batch(batches[i + 1]) if i + 1 < len(batches) else None    # the next frames' copies run beside this step
+            ts = []
+            for t, ev in cur:
+                main.wait_event(ev)
+                for v in t.values():
+                    v.record_stream(main)
+                ts.append(t)
+            mems = [(ops.memory_normalize_f16(t["mem"], t["obs"]), t["proj"]) if "mem" in t else None for t in ts]
+            if len(ts) == 1:
+                t = ts[0]
+                losses, grads = self.fm.forward_backward(t["image"], t["gt_boxes"], t["gt_classes"], memory=mems[0], generator=generator)
+                loss_list = [losses]
+            else:
+                loss_list, grads = self.fm.forward_backward_batch([t["image"] for t in ts], [t["gt_boxes"] for t in ts],
+                                                                  [t["gt_classes"] for t in ts], mems, generator=generator)
             gl = [self.step_getters[g["name"]](grads) for g in self.groups]
             if acc is None:
                 acc = [None if g_ is None else g_.clone() for g_ in gl]
@@ -658,8 +777,9 @@ class Trainer(ProposalTrainer):
                 if both:
                     torch._foreach_add_([a for a, _ in both], [g_ for _, g_ in both])
                 acc = [a if g_ is None else (g_.clone() if a is None else a) for a, g_ in zip(acc, gl)]
-            for k, v in losses.items():
-                total[k] = v.clone() if k not in total else total[k] + v
+            for losses in loss_list:
+                for k, v in losses.items():
+                    total[k] = v.clone() if k not in total else total[k] + v
         self._acc = acc
         return total
 

@@ -303,7 +303,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
         assert fm.det.last[k]["boxes"].shape[0] == rstages[k]["boxes"].shape[0]
         assert int((fm.det.last[k]["classes"].cpu().long() != rstages[k]["classes"]).sum()) == 0, k
     for name, v in ref.items():
-        assert abs(float(losses[name]) - float(v.detach())) <= 3e-4 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))
+        assert abs(float(losses[name]) - float(v.detach())) <= 3e-5 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))   # measured: <= 4e-7 (profiles/r04_training_gradient_l2_*.json)
     packed = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     base = "backbone.bottom_up.base"
     h = "proposal_generator.centernet_head"
@@ -325,7 +325,7 @@ def test_forward_model_training_step_both_halves(synthetic_sd):
         want = want.reshape(mine.shape)
         l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
         measured[name] = l2
-        assert l2 <= 5e-3, (name, l2)
+        assert l2 <= 2e-3, (name, l2)                  # measured: <= 4.2e-4 (the stem, behind every ReLU of the trunk)
     _report("training_gradient_l2_128x160", measured)
     # the pyramid gradient of the ROI heads really reaches the backbone: without it the FPN gradient is a different one
     _, g_prop = fm.prop.forward_backward(img.to(dev), gt.to(dev), memory=mem)
@@ -423,7 +423,7 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
         assert torch.equal(fm.det.last[k]["classes"].cpu().long().sort().values, rstages[k]["classes"].sort().values), k
     assert set(losses) == set(ref) and len(ref) == 10
     for name, v in ref.items():
-        assert abs(float(losses[name]) - float(v.detach())) <= 3e-4 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))
+        assert abs(float(losses[name]) - float(v.detach())) <= 3e-5 * max(abs(float(v.detach())), 1e-3), (name, float(losses[name]), float(v))   # measured: <= 4e-7 (profiles/r04_training_gradient_l2_*.json)
     packed = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     base = "backbone.bottom_up.base"
     h = "proposal_generator.centernet_head"
@@ -446,7 +446,7 @@ def test_forward_model_training_640_with_the_oracles_own_proposals_and_sample(sy
         l2 = float((mine - want).norm()) / max(float(want.norm()), 1e-20)
         worst = max(worst, l2)
         measured[name] = l2
-        assert l2 <= 5e-3, (name, l2)
+        assert l2 <= 2e-3, (name, l2)                  # measured: <= 4.2e-4 (the stem, behind every ReLU of the trunk)
     _report("training_gradient_l2_640x640", dict(measured, losses_relative={k: abs(float(losses[k]) - float(v.detach())) /
                                                                              max(abs(float(v.detach())), 1e-3) for k, v in ref.items()}))
     print("640x640 training parity: %d proposals (%d in another order than the oracle's), %d sampled rows (%d foreground), worst probe "
@@ -585,3 +585,62 @@ def test_training_without_a_memory_leaves_the_projections_alone(synthetic_sd):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(merge_before, trainer.merge_w + trainer.merge_b))
     assert not torch.equal(fc2_before, model.roi_heads.stages[0]["fc2"].w)
+
+
+def test_frames_of_a_batch_share_one_trunk_pass(synthetic_sd):
+    """`Trainer.trunk_batch`: the frames of a training batch go through the memory-independent trunk half (ResNet-50, FPN laterals /
+    top-down / output convs) in ONE pass, forward and backward, planned like a single image -- every frame's pyramid is bitwise the
+    single-frame one, so the summed losses are bitwise those of the frame-by-frame path; the gradients agree up to the order in
+    which the frames are summed (inside the weight-gradient launch instead of across launches)."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
+                           "SOLVER.BASE_LR", 2e-5, "FP16", False])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    H, W, n_cells = 128, 160, 400
+    g = torch.Generator().manual_seed(77)
+
+    def frame(i, hw=(H, W)):
+        h, w = hw
+        xy = torch.rand((4, 2), generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        wh = torch.rand((4, 2), generator=g) * 40 + 10
+        obs = torch.randint(0, 6, (n_cells,), generator=g).float()
+        return {"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8),
+                "instances": {"gt_boxes": torch.cat([xy, xy + wh], dim=1), "gt_classes": torch.randint(0, 20, (4,), generator=g)},
+                "memory": (torch.randn((n_cells, 512), generator=g) * obs.clamp(min=1)[:, None]).numpy(), "observations": obs.numpy(),
+                "proj_indices": torch.randint(0, n_cells, (h, w, 1), generator=g).numpy(), "sequence_name": f"s{i}", "memory_reset": i == 0}
+
+    # five frames of one size, then one of another size (its own pass), then one more of the first size
+    data = [[frame(0), frame(1), frame(2)], [frame(3), frame(4), frame(5, (96, 128)), frame(6)]]
+    model.train()
+    # warm-up: these small images yield fewer than 512 candidates, the first frame of each size fails the optimistic row count, is
+    # repeated on the exact path (drawing keys twice) and the size is remembered; the compared runs below draw the same keys
+    trainer.trunk_batch = 1
+    trainer.forward_backward_frames(data, generator=torch.Generator(device=dev).manual_seed(5))
+    trainer._acc = None
+    assert trainer.fm.repeated_frames >= 1 and len(trainer.fm._exact_sizes) == 2
+    runs = {}
+    for tb in (1, 4):
+        trainer.trunk_batch = tb
+        # the same sampling keys in both runs: the generator restarts from one seed
+        losses = trainer.forward_backward_frames(data, generator=torch.Generator(device=dev).manual_seed(5))
+        torch.cuda.synchronize()
+        runs[tb] = ({k: float(v) for k, v in losses.items()}, [None if a is None else a.clone() for a in trainer._acc])
+        trainer._acc = None
+    model.eval()
+    (la, ga), (lb, gb) = runs[1], runs[4]
+    assert set(la) == set(lb) and len(la) == 10
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    worst = 0.0
+    for a, b, g_ in zip(ga, gb, trainer.groups):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-12)
+        worst = max(worst, err)
+        assert err <= 1e-5, (g_["name"], err)                      # measured: 2.6e-7
+    print("frames sharing a trunk pass: worst relative gradient difference %.2e" % worst)

@@ -191,6 +191,9 @@ SIGNATURES = {
     "eod_memory_project_prepare": (C.c_int, [C.c_void_p] * 8),
     "eod_memory_project_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "eod_memory_project_backward_weights": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 7),
+    "eod_memory_project_backward_weights_workspace_bytes": (C.c_size_t, []),
+    "eod_memory_project_backward_weights_ws": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 7 +
+                                               [C.c_size_t, C.c_void_p]),
     "eod_memory_pool_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5),
     "eod_conv2d_backward_weights": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "eod_conv2d_backward_weights_levels_workspace_bytes": (C.c_size_t, [C.c_int] * 5),

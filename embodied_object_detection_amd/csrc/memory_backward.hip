@@ -43,6 +43,12 @@ struct BwdArgs {
   int rows[3];              // P_l
   int tile_base[3];         // first 32-row tile of level l in `pooled`
   float weight;
+  // splits > 1 (blockIdx.z): the positions of a level are cut into `splits` ranges, each writing its own partial dW / db into
+  // part [level][splits][256 * 512] / bpart [level][splits][256]; wgrad_reduce_kernel adds them in range order.  Without it the 128
+  // workgroups of the finest level each walk all of its 6 400 positions (290 us at 640x640).
+  int splits;
+  float* part;
+  float* bpart;
 };
 
 __global__ __launch_bounds__(256) void proj_backward_weights_kernel(BwdArgs a) {
@@ -53,12 +59,15 @@ __global__ __launch_bounds__(256) void proj_backward_weights_kernel(BwdArgs a) {
   const int P = a.rows[level];
   const float* __restrict__ G = a.g[level];
   const int col = lane & 31, kh = lane >> 5;
-  // positions of this wave: a contiguous quarter, rounded to whole k-steps of 8 positions
+  // positions of this workgroup's range, then of this wave: a contiguous quarter, rounded to whole k-steps of 8 positions
   const int steps = (P + 7) / 8;
-  const int spw = (steps + 3) / 4;
-  const int s_begin = wave * spw;
+  const int sps = (steps + a.splits - 1) / a.splits;
+  const int z_begin = (int)blockIdx.z * sps;
+  const int z_end = min(z_begin + sps, steps);
+  const int spw = (sps + 3) / 4;
+  const int s_begin = z_begin + wave * spw;
   int s_end = s_begin + spw;
-  if (s_end > steps) s_end = steps;
+  if (s_end > z_end) s_end = z_end;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -93,16 +102,18 @@ __global__ __launch_bounds__(256) void proj_backward_weights_kernel(BwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
   // C/D layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* dw = a.splits > 1 ? a.part + ((size_t)level * a.splits + blockIdx.z) * (256 * 512) : a.dw[level];
+  float* db = a.splits > 1 ? a.bpart + ((size_t)level * a.splits + blockIdx.z) * 256 : a.db[level];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    a.dw[level][(size_t)co * 512 + ci] = acc[r] * a.weight;
+    dw[(size_t)co * 512 + ci] = acc[r] * a.weight;
   }
   if ((tile & 15) == 0 && lane < 32) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += bred[w * 64 + lane] + bred[w * 64 + 32 + lane];    // even + odd positions, wave order
-    a.db[level][co0 + lane] = v * a.weight;
+    db[co0 + lane] = v * a.weight;
   }
 }
 
@@ -1132,9 +1143,32 @@ extern "C" int eod_adamw_step_multi(const EodAdamWTensor* tensors, int count, do
   return eod_launch_status();
 }
 
+#define PROJ_WGRAD_SPLITS 8
+extern "C" size_t eod_memory_project_backward_weights_workspace_bytes(void) {
+  return (size_t)3 * PROJ_WGRAD_SPLITS * (256 * 512 + 256) * sizeof(float);
+}
+
+static int memory_project_backward_weights_impl(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
+                                                int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,
+                                                float* db5, void* workspace, size_t workspace_bytes, eod_stream_t stream);
+
 extern "C" int eod_memory_project_backward_weights(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
                                                    int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,
                                                    float* db5, eod_stream_t stream) {
+  return memory_project_backward_weights_impl(g3, g4, g5, pooled_f16, H, W, weight, dw3, db3, dw4, db4, dw5, db5, nullptr, 0, stream);
+}
+
+extern "C" int eod_memory_project_backward_weights_ws(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
+                                                      int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,
+                                                      float* db5, void* workspace, size_t workspace_bytes, eod_stream_t stream) {
+  if (!workspace || workspace_bytes < eod_memory_project_backward_weights_workspace_bytes()) return EOD_ERR_CAPACITY;
+  return memory_project_backward_weights_impl(g3, g4, g5, pooled_f16, H, W, weight, dw3, db3, dw4, db4, dw5, db5, workspace,
+                                              workspace_bytes, stream);
+}
+
+static int memory_project_backward_weights_impl(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H,
+                                                int W, float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5,
+                                                float* db5, void* workspace, size_t workspace_bytes, eod_stream_t stream) {
   if (!g3 || !g4 || !g5 || !pooled_f16 || !dw3 || !db3 || !dw4 || !db4 || !dw5 || !db5) return EOD_ERR_NULL;
   if (H <= 0 || W <= 0 || (H & 31) || (W & 31)) return EOD_ERR_BAD_DIMS;
   BwdArgs a{};
@@ -1149,7 +1183,18 @@ extern "C" int eod_memory_project_backward_weights(const float* g3, const float*
     base += (a.rows[l] + 31) / 32;
   }
   a.weight = weight;
-  hipLaunchKernelGGL(proj_backward_weights_kernel, dim3(128, 3), dim3(256), 0, (hipStream_t)stream, a);
+  a.splits = 1;
+  if (workspace) {
+    a.splits = PROJ_WGRAD_SPLITS;
+    a.part = static_cast<float*>(workspace);
+    a.bpart = a.part + (size_t)3 * PROJ_WGRAD_SPLITS * 256 * 512;
+  }
+  hipLaunchKernelGGL(proj_backward_weights_kernel, dim3(128, 3, a.splits), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.splits > 1) {
+    for (int l = 0; l < 3; ++l)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(513), dim3(256), 0, (hipStream_t)stream, a.part + (size_t)l * a.splits * 256 * 512,
+                         a.bpart + (size_t)l * a.splits * 256, a.dw[l], a.db[l], (size_t)256 * 512, 256, a.splits);
+  }
   return eod_launch_status();
 }
 

@@ -593,10 +593,12 @@ class MemoryProjectorBackward:
             assert tuple(g.shape) == (r, 256) and g.dtype == torch.float32 and g.is_contiguous()
         dW = [torch.empty((256, 512), dtype=torch.float32, device=dev) for _ in range(3)]
         db = [torch.empty((256,), dtype=torch.float32, device=dev) for _ in range(3)]
-        check(self.lib.eod_memory_project_backward_weights(grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(),
-                                                           pooled_f16.data_ptr(), H, W, float(weight), dW[0].data_ptr(), db[0].data_ptr(),
-                                                           dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(), _stream()),
-              "eod_memory_project_backward_weights")
+        ws = _conv_ws.get(self.lib.eod_memory_project_backward_weights_workspace_bytes(), dev)      # the position ranges' partial sums
+        check(self.lib.eod_memory_project_backward_weights_ws(grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(),
+                                                              pooled_f16.data_ptr(), H, W, float(weight), dW[0].data_ptr(), db[0].data_ptr(),
+                                                              dW[1].data_ptr(), db[1].data_ptr(), dW[2].data_ptr(), db[2].data_ptr(),
+                                                              ws.data_ptr(), ws.numel(), _stream()),
+              "eod_memory_project_backward_weights_ws")
         if not need_input_grad:
             return dict(dW=dW, db=db)
         dec = [self.convs[l](grads[l].view(1, H >> (3 + l), W >> (3 + l), 256), 1, H >> (3 + l), W >> (3 + l), out_scale=float(weight))

@@ -474,6 +474,13 @@ int eod_unique_rows(const int32_t* rows, const int32_t* count, int K_cap, int R_
 int eod_memory_project_backward_weights(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H, int W,
                                         float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5, float* db5,
                                         eod_stream_t stream);
+/* The same with a workspace (>= eod_memory_project_backward_weights_workspace_bytes()): every level's positions are cut into 8
+ * ranges, one grid slice each, whose partial results are added in range order by a second launch per level (without it the 128
+ * workgroups of the finest level each walk all of its positions: 290 us at 640x640 against ~50). */
+size_t eod_memory_project_backward_weights_workspace_bytes(void);
+int eod_memory_project_backward_weights_ws(const float* g3, const float* g4, const float* g5, const uint16_t* pooled_f16, int H, int W,
+                                           float weight, float* dw3, float* db3, float* dw4, float* db4, float* dw5, float* db5,
+                                           void* workspace, size_t workspace_bytes, eod_stream_t stream);
 /* Backward of the cascaded pools avg_pool2 -> half (timm.py:163-168) with autograd's rounding of gradients that enter half tensors:
  * dec3..5 = weight * G_l . W_l ([P_l,512] fp32 rows) -> ge3..5 (gradients of the half tensors E_3..E_5, [P_l,512] half rows) and
  * ge2 (gradient of the fp32 avg_pool4 output, [(H/4)*(W/4), 512]). */

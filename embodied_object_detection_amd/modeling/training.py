@@ -720,7 +720,8 @@ class Trainer(ProposalTrainer):
             """The frame's tensors on the device, copied on the copy stream (the memory table alone is 82 MB at 200 x 200 cells:
             ~2 ms per frame on the compute stream otherwise) while the frame before computes -> (tensors, event)."""
             with torch.cuda.stream(self._copy_stream):
-                t = {"image": torch.as_tensor(frame["image"]).to(dev, non_blocking=True)}
+                # (the loader's image is a permuted HWC view, train_mp3d.py:469: contiguous CHW on the device)
+                t = {"image": torch.as_tensor(frame["image"]).to(dev, non_blocking=True).contiguous()}
                 gt_boxes, gt_classes = self._gt(frame)
                 t["gt_boxes"] = gt_boxes.to(dev, non_blocking=True).contiguous()
                 t["gt_classes"] = gt_classes.to(dev, non_blocking=True)

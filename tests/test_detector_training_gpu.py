@@ -644,3 +644,73 @@ def test_frames_of_a_batch_share_one_trunk_pass(synthetic_sd):
         worst = max(worst, err)
         assert err <= 1e-5, (g_["name"], err)                      # measured: 2.6e-7
     print("frames sharing a trunk pass: worst relative gradient difference %.2e" % worst)
+
+
+def test_on_disk_episodes_train_through_the_loop(synthetic_sd, tmp_path):
+    """The training side of SURVEY §8f rank 1 end to end on the GPU: episode files in the reference's layout (HDF5 + JPEG under
+    MODEL.TRAIN_DATA_PATH, the memory snapshots `impicit_memory` / `observations` under MODEL.SEMMAP_PATH, loader.py:199-227) ->
+    `SMNetDetectionLoader` -> TrainingSampler batches through `collate_smnet` / `map_mp3d_batch_to_coco` -> `do_train` (model(data),
+    optimizer step, schedule, checkpoints) for three iterations of 2 episodes x 2 frames: finite losses under the reference's
+    names, the snapshot's table reaches the step, parameters move, both checkpoint kinds are written."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.data import h5io
+    if not h5io.available():
+        pytest.skip("no libhdf5 in this image")
+    from embodied_object_detection_amd.data.mp3d import SMNetDetectionLoader, collate_smnet, map_mp3d_batch_to_coco
+    from embodied_object_detection_amd.data.snapshot import write_snapshot
+    from embodied_object_detection_amd.engine import train_loop
+    from embodied_object_detection_amd.modeling.training import Trainer
+    H, W, n_cells = 128, 160, 300
+    g = torch.Generator().manual_seed(31)
+    root, out = str(tmp_path / "ds"), str(tmp_path / "out")
+    for d in ("memory_data", "sensor_data", "JPEGImages"):
+        os.makedirs(os.path.join(root, d))
+    for ep in range(3):                                                # one scene, three episodes of two frames
+        name = f"scene_y_{ep}.h5"
+        with h5io.H5File(os.path.join(root, "memory_data", name), "w") as f:
+            f.write("memory_features", np.zeros((n_cells, 256), dtype=np.float32))
+            f.write("semmap_gt", np.zeros((n_cells,), dtype=np.int32))
+            f.write("proj_indices", torch.randint(0, n_cells, (2, H, W, 1), generator=g).numpy().astype(np.int32))
+        recs = []
+        for i in range(2):
+            fn = f"scene_y_{ep}_{i}.jpg"
+            Image.fromarray(torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).numpy()).save(
+                os.path.join(root, "JPEGImages", fn), quality=90)
+            recs.append(str({"file_name": fn, "image": "x", "gt_boxes": [[4, 4, 40, 60], [60, 30, 50, 70]], "gt_classes": [3, 11]}))
+        with h5io.H5File(os.path.join(root, "sensor_data", name), "w") as f:
+            f.write("segmentation_data", np.zeros((2, H, W), dtype=np.uint8))
+            f.write_strings("detection_data", recs)
+        obs = torch.randint(0, 5, (n_cells,), generator=g).float()
+        write_snapshot(out, name, np.zeros((n_cells,), dtype=np.int32),
+                       (torch.randn((n_cells, 512), generator=g) * obs.clamp(min=1)[:, None]).numpy(), obs.numpy())
+    semmap = os.path.join(out, "memory")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False,
+                           "SOLVER.MAX_ITER", 3, "SOLVER.CHECKPOINT_PERIOD", 2, "SOLVER.IMS_PER_BATCH", 2, "SOLVER.BASE_LR", 2e-5,
+                           "MODEL.TRAIN_DATA_PATH", root, "MODEL.SEMMAP_PATH", semmap, "OUTPUT_DIR", out])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    loader = SMNetDetectionLoader(data_path=root, clip_path=None, memory_type="implicit_memory", semmap_path=semmap)
+    seen = []
+    real_frames = trainer.forward_backward_frames
+
+    def spy(batched_inputs, generator=None):
+        seen.append([[(f["memory"].shape, float(np.asarray(f["observations"]).sum())) for f in seq] for seq in batched_inputs])
+        return real_frames(batched_inputs, generator=generator)
+    trainer.forward_backward_frames = spy
+    before = model.roi_heads.stages[0]["fc2"].w.clone()
+    saves = []
+    rows = train_loop.do_train(cfg, model, trainer, train_loop.training_batches(loader, 2, seed=0, collate=collate_smnet, workers=0),
+                               output_dir=out, base_state_dict=sd0, map_batch=map_mp3d_batch_to_coco,
+                               on_save=lambda name, it: saves.append(name))
+    torch.cuda.synchronize()
+    assert len(rows) == 3 and all(np.isfinite(r["total_loss"]) for r in rows)
+    assert {"loss_cls_stage0", "loss_box_reg_stage2", "loss_centernet_loc", "loss_mask"} <= set(rows[0])
+    assert len(seen) == 3 and all(len(b) == 2 and all(len(s) == 2 for s in b) for b in seen)          # 2 episodes x 2 frames per iteration
+    assert all(shape == (n_cells, 512) and obs_sum > 0 for b in seen for s in b for (shape, obs_sum) in s)   # the snapshot's table, not the offline one
+    assert not torch.equal(before, model.roi_heads.stages[0]["fc2"].w)
+    assert any(n.startswith("model_000") for n in saves) and "model_final" in " ".join(saves)
+    assert os.path.exists(os.path.join(out, "last_checkpoint"))

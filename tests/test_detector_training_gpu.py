@@ -646,29 +646,19 @@ def test_frames_of_a_batch_share_one_trunk_pass(synthetic_sd):
     print("frames sharing a trunk pass: worst relative gradient difference %.2e" % worst)
 
 
-def test_on_disk_episodes_train_through_the_loop(synthetic_sd, tmp_path):
-    """The training side of SURVEY §8f rank 1 end to end on the GPU: episode files in the reference's layout (HDF5 + JPEG under
-    MODEL.TRAIN_DATA_PATH, the memory snapshots `impicit_memory` / `observations` under MODEL.SEMMAP_PATH, loader.py:199-227) ->
-    `SMNetDetectionLoader` -> TrainingSampler batches through `collate_smnet` / `map_mp3d_batch_to_coco` -> `do_train` (model(data),
-    optimizer step, schedule, checkpoints) for three iterations of 2 episodes x 2 frames: finite losses under the reference's
-    names, the snapshot's table reaches the step, parameters move, both checkpoint kinds are written."""
+def _write_training_dataset(tmp_path, H=128, W=160, n_cells=300, episodes=3):
+    """Episode files in the reference's layout under <tmp>/ds (HDF5 + JPEG, loader.py:199-227) and the memory snapshots
+    (`impicit_memory` / `observations`) under <tmp>/out/memory -> (data root, output dir, snapshot dir)."""
     import os
     import numpy as np
     from PIL import Image
-    from embodied_object_detection_amd import build_model, setup_cfg
     from embodied_object_detection_amd.data import h5io
-    if not h5io.available():
-        pytest.skip("no libhdf5 in this image")
-    from embodied_object_detection_amd.data.mp3d import SMNetDetectionLoader, collate_smnet, map_mp3d_batch_to_coco
     from embodied_object_detection_amd.data.snapshot import write_snapshot
-    from embodied_object_detection_amd.engine import train_loop
-    from embodied_object_detection_amd.modeling.training import Trainer
-    H, W, n_cells = 128, 160, 300
     g = torch.Generator().manual_seed(31)
     root, out = str(tmp_path / "ds"), str(tmp_path / "out")
     for d in ("memory_data", "sensor_data", "JPEGImages"):
         os.makedirs(os.path.join(root, d))
-    for ep in range(3):                                                # one scene, three episodes of two frames
+    for ep in range(episodes):                                         # one scene, episodes of two frames
         name = f"scene_y_{ep}.h5"
         with h5io.H5File(os.path.join(root, "memory_data", name), "w") as f:
             f.write("memory_features", np.zeros((n_cells, 256), dtype=np.float32))
@@ -686,7 +676,26 @@ def test_on_disk_episodes_train_through_the_loop(synthetic_sd, tmp_path):
         obs = torch.randint(0, 5, (n_cells,), generator=g).float()
         write_snapshot(out, name, np.zeros((n_cells,), dtype=np.int32),
                        (torch.randn((n_cells, 512), generator=g) * obs.clamp(min=1)[:, None]).numpy(), obs.numpy())
-    semmap = os.path.join(out, "memory")
+    return root, out, os.path.join(out, "memory")
+
+
+def test_on_disk_episodes_train_through_the_loop(synthetic_sd, tmp_path):
+    """The training side of SURVEY §8f rank 1 end to end on the GPU: episode files in the reference's layout (HDF5 + JPEG under
+    MODEL.TRAIN_DATA_PATH, the memory snapshots `impicit_memory` / `observations` under MODEL.SEMMAP_PATH, loader.py:199-227) ->
+    `SMNetDetectionLoader` -> TrainingSampler batches through `collate_smnet` / `map_mp3d_batch_to_coco` -> `do_train` (model(data),
+    optimizer step, schedule, checkpoints) for three iterations of 2 episodes x 2 frames: finite losses under the reference's
+    names, the snapshot's table reaches the step, parameters move, both checkpoint kinds are written."""
+    import os
+    import numpy as np
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.data import h5io
+    if not h5io.available():
+        pytest.skip("no libhdf5 in this image")
+    from embodied_object_detection_amd.data.mp3d import SMNetDetectionLoader, collate_smnet, map_mp3d_batch_to_coco
+    from embodied_object_detection_amd.engine import train_loop
+    from embodied_object_detection_amd.modeling.training import Trainer
+    H, W, n_cells = 128, 160, 300
+    root, out, semmap = _write_training_dataset(tmp_path, H, W, n_cells)
     cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False,
                            "SOLVER.MAX_ITER", 3, "SOLVER.CHECKPOINT_PERIOD", 2, "SOLVER.IMS_PER_BATCH", 2, "SOLVER.BASE_LR", 2e-5,
                            "MODEL.TRAIN_DATA_PATH", root, "MODEL.SEMMAP_PATH", semmap, "OUTPUT_DIR", out])
@@ -714,3 +723,24 @@ def test_on_disk_episodes_train_through_the_loop(synthetic_sd, tmp_path):
     assert not torch.equal(before, model.roi_heads.stages[0]["fc2"].w)
     assert any(n.startswith("model_000") for n in saves) and "model_final" in " ".join(saves)
     assert os.path.exists(os.path.join(out, "last_checkpoint"))
+
+
+def test_cli_trains_and_evaluates_on_disk_episodes(tmp_path):
+    """`python -m embodied_object_detection_amd.train_mp3d ... KEY VALUE` without `--eval-only`, as the reference's `main` runs it
+    (train_mp3d.py:740-741): `do_train` on the on-disk episodes with the DataLoader's two forked worker processes (:563-572), then
+    `do_test` on MODEL.TEST_DATA_PATH with the trained model -> the evaluator's result dict; checkpoints on disk."""
+    import os
+    from embodied_object_detection_amd import train_mp3d
+    from embodied_object_detection_amd.data import h5io
+    if not h5io.available():
+        pytest.skip("no libhdf5 in this image")
+    root, out, semmap = _write_training_dataset(tmp_path)
+    args = train_mp3d.default_argument_parser().parse_args(
+        ["--num-gpus", "1", "FP16", "False", "MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", "5",
+         "MODEL.TRAIN_DATA_PATH", root, "MODEL.TEST_DATA_PATH", root, "MODEL.SEMMAP_PATH", semmap, "OUTPUT_DIR", out,
+         "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "2", "SOLVER.IMS_PER_BATCH", "2", "DATALOADER.NUM_WORKERS_TRAIN_MP3D", "2"])
+    res = train_mp3d.main(args)
+    torch.cuda.synchronize()
+    assert res is not None and "all" in res and {"AP", "AP50", "AP75", "num_images"} <= set(res["all"])
+    assert res["all"]["num_images"] == 3                       # frames 0 of every episode (every 5th frame of each, train_mp3d.py:187-188)
+    assert os.path.exists(os.path.join(out, "model_final.pth")) and os.path.exists(os.path.join(out, "last_checkpoint"))

@@ -744,3 +744,36 @@ def test_cli_trains_and_evaluates_on_disk_episodes(tmp_path):
     assert res is not None and "all" in res and {"AP", "AP50", "AP75", "num_images"} <= set(res["all"])
     assert res["all"]["num_images"] == 3                       # frames 0 of every episode (every 5th frame of each, train_mp3d.py:187-188)
     assert os.path.exists(os.path.join(out, "model_final.pth")) and os.path.exists(os.path.join(out, "last_checkpoint"))
+
+
+def test_freeze_backbone_steps_the_unfrozen_layers_only(synthetic_sd):
+    """MODEL.FREEZE_BACKBONE True with the shipped yaml's UNFROZEN_LAYERS ['roi', 'map_merge', 'proposal_generator']
+    (train_mp3d.py:704-710: a parameter stays trainable iff one of the keys is a substring of its name): after a step the trunk's
+    and the FPN's weights are bitwise what they were, the ROI heads, the map_merge projections and the CenterNet head have moved."""
+    from embodied_object_detection_amd import build_model, setup_cfg
+    from embodied_object_detection_amd.modeling.training import Trainer
+    dev = torch.device("cuda:0")
+    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False,
+                           "SOLVER.BASE_LR", 2e-5, "MODEL.FREEZE_BACKBONE", True,
+                           "MODEL.UNFROZEN_LAYERS", ["roi", "map_merge", "proposal_generator"]])
+    sd0 = {k: v.clone() for k, v in synthetic_sd.items()}
+    model = build_model(cfg, sd0)
+    trainer = Trainer(model, sd0)
+    names = [g_["name"] for g_ in trainer.groups]
+    assert names and all(any(k in n for k in ("roi", "map_merge", "proposal_generator")) for n in names)
+    assert not any("bottom_up" in n or "fpn_" in n or "top_block" in n for n in names)
+    H, W, n_cells = 128, 160, 300
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
+    mem = ((torch.randn((n_cells, 512), generator=g) * 2).half().to(dev), torch.randint(0, n_cells, (H, W), generator=g).int().to(dev))
+    gt = torch.tensor([[10.0, 12.0, 60.0, 70.0], [40.0, 30.0, 150.0, 120.0]]).to(dev)
+    bb = model.backbone
+    frozen_before = [bb.bottom_up.stem.w.clone(), bb.bottom_up.blocks[5][2].w.clone(), bb.lateral[4].w.clone(), bb.output[3].w.clone(),
+                     bb.p6.w.clone()]
+    moving_before = [model.roi_heads.stages[1]["fc1"].w.clone(), trainer.merge_w[0].clone(), model.proposal_generator.tower[2][0].w.clone()]
+    trainer.step(img, gt, memory=mem, gt_classes=torch.tensor([2, 7]).int().to(dev), generator=torch.Generator(device=dev).manual_seed(1))
+    torch.cuda.synchronize()
+    frozen_after = [bb.bottom_up.stem.w, bb.bottom_up.blocks[5][2].w, bb.lateral[4].w, bb.output[3].w, bb.p6.w]
+    moving_after = [model.roi_heads.stages[1]["fc1"].w, trainer.merge_w[0], model.proposal_generator.tower[2][0].w]
+    assert all(torch.equal(a, b) for a, b in zip(frozen_before, frozen_after))
+    assert all(not torch.equal(a, b) for a, b in zip(moving_before, moving_after))

@@ -145,9 +145,10 @@ class BackboneBackward:
                 grads[f"map_merge_projection{i + 1}"] = (mb["dW"][i], mb["db"][i])
         return grads, g_out
 
-    def backward_trunk(self, saved: dict, g_out: List[torch.Tensor], need_stem_grad: bool = True):
+    def backward_trunk(self, saved: dict, g_out: List[torch.Tensor], need_stem_grad: bool = True, blocks: bool = True):
         """g_out: dL/d(p3..p5) of the N images of `forward_trunk` ([N,h,w,256]) -> (grads of the output / lateral convs and the
-        trunk, dL/d(stem pre-activation) or None).  dW / db are sums over the N images (one launch per layer)."""
+        trunk, dL/d(stem pre-activation) or None).  dW / db are sums over the N images (one launch per layer).  `blocks=False`: the
+        ResNet's parameters are frozen (MODEL.FREEZE_BACKBONE): the chain stops at the laterals' weight gradients."""
         bb, N = self.bb, saved["N"]
         f = saved["fpn"]
         (c3, c4, c5), (lat3, lat4, lat5) = f["c"], f["lat"]
@@ -174,9 +175,11 @@ class BackboneBackward:
         gc = {}
         for l, cx, gl in ((3, c3, g_lat3), (4, c4, g_lat4), (5, c5, g_lat5)):
             # c5 feeds its lateral only: the ReLU it came out of is crossed on the way out of that layer's input-gradient launch
-            r = self._b(bb.lateral[l])(cx, None, gl, dx_gate=cx if l == 5 else None)
+            r = self._b(bb.lateral[l])(cx, None, gl, dx_gate=cx if l == 5 else None, need_dx=blocks)
             put(bb.lateral[l], r)
             gc[l] = r["dx"]
+        if not blocks:
+            return grads, None
         # trunk, last block first; the exposed stage outputs ('layer3', 'layer4', 'layer5') collect their lateral's gradient
         blocks = bb.bottom_up.blocks
         kept = saved["blocks"]

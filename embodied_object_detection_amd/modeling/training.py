@@ -46,6 +46,10 @@ class ProposalTraining:
         self._loss = {}
         self.last = None
         self.pyramid_backward = True     # False: the level-shared layers' backward level by level (25 calls + their sums; tests compare)
+        # which part of the trunk half's backward anybody reads (`ProposalTrainer` clears them for frozen parameters,
+        # MODEL.FREEZE_BACKBONE): the FPN laterals / output convs, and the ResNet blocks + stem below them
+        self.backward_fpn = True
+        self.backward_blocks = True
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------------
     def _conv_bwd(self, conv: ops.Conv, xin: torch.Tensor, gout: torch.Tensor, shapes, off):
@@ -82,8 +86,9 @@ class ProposalTraining:
         x4, Hp, Wp = ops.preprocess_image(image_u8, m.pixel_mean, m.pixel_std)
         p345, saved = self.bb.forward_trunk(x4, Hp, Wp, 1)
         losses, grads, g_out = self._frame_on_pyramid(p345, saved, Hp, Wp, gt_boxes, memory, world_size, reduce_counts, roi_half)
-        bgrads, _ = self.bb.backward_trunk(saved, g_out)
-        grads.update(bgrads)
+        if self.backward_fpn:
+            bgrads, _ = self.bb.backward_trunk(saved, g_out, blocks=self.backward_blocks)
+            grads.update(bgrads)
         if self.side:
             ops.ConvBackward.join(self.dev)                           # the weight gradients ran on their own stream (ops.ConvBackward)
         return losses, grads
@@ -108,8 +113,9 @@ class ProposalTraining:
             all_losses.append(losses)
             g_outs.append(g_out)
             total = grads if total is None else _sum_grads(total, grads)
-        bgrads, _ = self.bb.backward_trunk(saved, [torch.cat([g[l] for g in g_outs], dim=0) for l in range(3)])
-        total.update(bgrads)
+        if self.backward_fpn:
+            bgrads, _ = self.bb.backward_trunk(saved, [torch.cat([g[l] for g in g_outs], dim=0) for l in range(3)], blocks=self.backward_blocks)
+            total.update(bgrads)
         if self.side:
             ops.ConvBackward.join(self.dev)
         return all_losses, total
@@ -364,6 +370,11 @@ class ProposalTrainer:
             if g["name"] in self.folds:
                 g["fold"] = self.folds[g["name"]]
                 g["grad_of_folded"] = True
+        # frozen parameters have no reader for their gradients: the trunk half's backward stops where the last trainable layer is
+        # (with the yaml's UNFROZEN_LAYERS ['roi', 'map_merge', 'proposal_generator'] it is skipped altogether)
+        live = [g["name"] for g in self.groups]
+        self.step_fn.backward_blocks = any("bottom_up" in n for n in live)
+        self.step_fn.backward_fpn = self.step_fn.backward_blocks or any("backbone.fpn_" in n for n in live)
         self.getters = {n: f for n, _, f in self.entries}        # gradient of every stepped tensor (of the raw master for a trunk conv)
         self.step_getters = {**self.getters, **self.raw_getters}   # what `opt.step` is handed
         clip = s.CLIP_GRADIENTS

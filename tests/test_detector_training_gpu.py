@@ -762,6 +762,8 @@ def test_freeze_backbone_steps_the_unfrozen_layers_only(synthetic_sd):
     names = [g_["name"] for g_ in trainer.groups]
     assert names and all(any(k in n for k in ("roi", "map_merge", "proposal_generator")) for n in names)
     assert not any("bottom_up" in n or "fpn_" in n or "top_block" in n for n in names)
+    # nobody reads the gradients of the trunk half: its backward (FPN laterals / output convs, ResNet blocks, stem) is not run
+    assert trainer.step_fn.backward_fpn is False and trainer.step_fn.backward_blocks is False
     H, W, n_cells = 128, 160, 300
     g = torch.Generator().manual_seed(9)
     img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)

@@ -29,10 +29,15 @@ def main():
     ap.add_argument("--roi-heads", action="store_true", help="the whole forward_model: both halves, all 126 parameter tensors")
     ap.add_argument("--no-scale-sync", action="store_true",
                     help="experiment: skip the per-step read-back of the five Scale parameters (the one host synchronisation of a step)")
+    ap.add_argument("--freeze-backbone", action="store_true",
+                    help="MODEL.FREEZE_BACKBONE True with the shipped yaml's UNFROZEN_LAYERS ['roi', 'map_merge', 'proposal_generator']")
     a = ap.parse_args()
     H, W = a.size
     dev = torch.device("cuda:0")
-    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False])
+    opts = ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "FP16", False]
+    if a.freeze_backbone:
+        opts += ["MODEL.FREEZE_BACKBONE", True, "MODEL.UNFROZEN_LAYERS", ["roi", "map_merge", "proposal_generator"]]
+    cfg = setup_cfg(None, opts)
     sd = synthetic_state_dict(0)
     model = build_model(cfg, sd)
     trainer = Trainer(model, sd) if a.roi_heads else ProposalTrainer(model, sd)

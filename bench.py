@@ -456,7 +456,7 @@ def config5_variant(sd, memory_thresh: float) -> dict:
     return out
 
 
-def train_step_variant(sd) -> dict:
+def train_step_variant(sd, freeze_backbone: bool = False) -> dict:
     """One training iteration of `forward_model` (custom_rcnn.py:584-679 + the optimizer step, train_mp3d.py:609-633) at 640x640:
     `Trainer.step` on one frame with 24 ground-truth boxes -- both halves forward and backward, train-mode proposals at the yaml's
     4000 / 2000, 512 sampled ROI rows per cascade stage, AdamW over all 126 parameter tensors.  FLOPs: 2 x MAC of every conv / linear
@@ -465,8 +465,11 @@ def train_step_variant(sd) -> dict:
     from embodied_object_detection_amd.modeling.training import Trainer
     H = W = 640
     dev = torch.device("cuda:0")
-    cfg = setup_cfg(None, ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5,
-                           "MODEL.DEVICE", "cuda:0", "FP16", False])
+    opts = ["MODEL.MEMORY_TYPE", "implicit_memory", "MODEL.MAP_FEAT_FUSION", "sum", "MODEL.MAP_FEATURE_WEIGHT", 5, "MODEL.DEVICE", "cuda:0",
+            "FP16", False]
+    if freeze_backbone:      # the shipped fine-tuning yaml's list (Detic_..._mp3d_recurrent.yaml:18-19)
+        opts += ["MODEL.FREEZE_BACKBONE", True, "MODEL.UNFROZEN_LAYERS", ["roi", "map_merge", "proposal_generator"]]
+    cfg = setup_cfg(None, opts)
     sd = {k: v.clone() for k, v in sd.items()}
     model = build_model(cfg, sd)
     trainer = Trainer(model, sd)
@@ -506,8 +509,15 @@ def train_step_variant(sd) -> dict:
            "roi_rows_per_stage": rows, "gt_boxes": 24, "forward_gflop": round(fwd, 1), "algorithmic_gflop_per_iteration": round(3 * fwd, 1),
            "achieved_tflops": round(3 * fwd / dt / 1e3, 2), "frac_of_fp32_mfma_peak": round(3 * fwd / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
            "total_loss_first_last": [round(first, 4), round(last, 4)], "synchronised_iterations_ms": per_iter,
-           "note": "Trainer.step: forward_model forward + backward + AdamW over 126 tensors on one 640x640 frame, parameters stepped in the "
+           "stepped_tensors": len(trainer.groups),
+           "note": "Trainer.step: forward_model forward + backward + AdamW on one 640x640 frame, parameters stepped in the "
                    "layers the inference path runs; FP16: False (the yaml's autocast / GradScaler path is refused, not emulated)"}
+    if freeze_backbone:
+        # the trunk half's backward is not run: forward of everything + backward of the heads only
+        res["note"] += ("; MODEL.FREEZE_BACKBONE True, UNFROZEN_LAYERS ['roi', 'map_merge', 'proposal_generator']: nobody reads the trunk "
+                        "half's gradients, its backward is skipped (the GFLOP fields count the full backward and do not apply)")
+        for k in ("algorithmic_gflop_per_iteration", "achieved_tflops", "frac_of_fp32_mfma_peak"):
+            res.pop(k)
     del trainer, model
     torch.cuda.empty_cache()
     return res
@@ -846,6 +856,8 @@ def main():
                 try:
                     variants["train_step_640"] = train_step_variant(sd)
                     log(f"training iteration at 640x640: {variants['train_step_640']['ms_per_step']} ms")
+                    variants["train_step_640_frozen_backbone"] = train_step_variant(sd, freeze_backbone=True)
+                    log(f"training iteration at 640x640, frozen backbone: {variants['train_step_640_frozen_backbone']['ms_per_step']} ms")
                 except Exception as e:
                     log(f"train-step variant failed: {e!r}")
 

@@ -678,3 +678,54 @@ def test_dense_kernels_compile_without_scratch_memory():
     assert build.scratch_offenders(usage) == []
     hot = [v for k, v in usage.items() if "conv_igemm_kernelILi64ELi64ELi32ELb0ELb0ELi0" in k]
     assert len(hot) == 1 and hot[0]["scratch"] == 0 and hot[0]["vgprs"] <= 96 and hot[0]["occupancy"] >= 5
+
+
+def test_training_entry_points_validate_their_arguments_without_gpu():
+    """The round-4 training entry points reject bad arguments in their host-side checks, before any launch: the multi-tensor
+    rotation and AdamW, the pyramid-mode weight gradient, the gated conv epilogue, the map_merge weight gradient with a workspace."""
+    import ctypes as C
+    from embodied_object_detection_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_float * 4096)()
+    ptr = C.addressof(buf)
+    NULL, BAD, CAP = -4, -1, -5
+    # eod_conv_rotate_weights_multi
+    assert lib.eod_conv_rotate_weights_multi(None, 1, None) == NULL
+    r = (_lib.EodRotateTensor * 1)()
+    assert lib.eod_conv_rotate_weights_multi(r, 0, None) == BAD
+    assert lib.eod_conv_rotate_weights_multi(r, 1, None) == NULL          # w / out missing
+    r[0].w, r[0].out = ptr, ptr
+    r[0].Cout, r[0].KH, r[0].KW, r[0].Cin, r[0].ld_in, r[0].ld_out = 8, 3, 3, 4, 35, 72      # ld_in < KH * KW * Cin
+    assert lib.eod_conv_rotate_weights_multi(r, 1, None) == BAD
+    # eod_adamw_step_multi: the chain rule of the fold needs the per-row scale and the row length
+    t = (_lib.EodAdamWTensor * 1)()
+    t[0].param = t[0].grad = t[0].exp_avg = t[0].exp_avg_sq = ptr
+    t[0].n, t[0].lr, t[0].weight_decay, t[0].step = 64, 1e-3, 0.0, 1
+    t[0].grad_of_folded = 1
+    assert lib.eod_adamw_step_multi(t, 1, 0.9, 0.999, 1e-8, 0.0, None) == BAD
+    t[0].grad_of_folded, t[0].step = 0, 0
+    assert lib.eod_adamw_step_multi(t, 1, 0.9, 0.999, 1e-8, 0.0, None) == BAD          # step counts are 1-based
+    # eod_conv2d_backward_weights_levels
+    off = (C.c_int32 * 3)(0, 12, 16)
+    hh = (C.c_int32 * 2)(3, 2)
+    ww = (C.c_int32 * 2)(4, 2)
+    args = lambda levels, cin, cout, k, pad, lo=off: (ptr, ptr, levels, lo, hh, ww, cin, cout, k, k, pad, ptr, ptr, None, 0, None)
+    assert lib.eod_conv2d_backward_weights_levels(None, ptr, 2, off, hh, ww, 32, 32, 3, 3, 1, ptr, ptr, None, 0, None) == NULL
+    assert lib.eod_conv2d_backward_weights_levels(*args(9, 32, 32, 3, 1)) == BAD       # more than 8 levels
+    assert lib.eod_conv2d_backward_weights_levels(*args(2, 48, 32, 3, 1)) == BAD       # Cin % 32
+    assert lib.eod_conv2d_backward_weights_levels(*args(2, 32, 32, 3, 0)) == BAD       # not 'same' padding
+    assert lib.eod_conv2d_backward_weights_levels(*args(2, 32, 32, 3, 1, (C.c_int32 * 3)(0, 12, 17))) == BAD    # rows != h * w
+    assert lib.eod_conv2d_backward_weights_levels_workspace_bytes(0, 32, 32, 3, 3) == 0
+    assert lib.eod_conv2d_backward_weights_levels_workspace_bytes(8525, 256, 256, 3, 3) > 0
+    # the gated epilogue lives in the 64x64 fp32 tile, the wave-K kernel and the slab reduces: other forced tiles are refused
+    d = _lib.EodConvDesc()
+    d.x = d.w = d.y = d.gate = ptr
+    d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Kpad = 1, 4, 4, 32, 4, 4, 32, 1, 1, 1, 0, 32
+    d.force_tile = 1
+    assert lib.eod_conv2d(C.byref(d), None) == BAD
+    d.force_tile, d.out_mode, d.Cout = 0, 1, 32
+    assert lib.eod_conv2d(C.byref(d), None) == BAD                                     # no gate on the deconv scatter
+    # eod_memory_project_backward_weights_ws: a workspace that is too small
+    need = lib.eod_memory_project_backward_weights_workspace_bytes()
+    assert need == 3 * 8 * (256 * 512 + 256) * 4
+    assert lib.eod_memory_project_backward_weights_ws(ptr, ptr, ptr, ptr, 64, 64, 1.0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, need - 4, None) == CAP

@@ -729,3 +729,25 @@ def test_training_entry_points_validate_their_arguments_without_gpu():
     need = lib.eod_memory_project_backward_weights_workspace_bytes()
     assert need == 3 * 8 * (256 * 512 + 256) * 4
     assert lib.eod_memory_project_backward_weights_ws(ptr, ptr, ptr, ptr, 64, 64, 1.0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, need - 4, None) == CAP
+
+
+def test_sum_of_the_frames_gradient_dicts():
+    """`modeling.training._sum_grads` (the frames of a shared trunk pass hand their per-scene gradients over as dicts): tensors and
+    tuples of tensors are added entry by entry in place, an entry only one frame has is kept, a `None` inside a tuple gives way."""
+    from embodied_object_detection_amd.modeling.training import _sum_grads
+    a = {"scales": torch.tensor([1.0, 2.0]), "conv": (torch.ones((2, 3)), torch.zeros((2,))), "only_a": (torch.full((2,), 5.0), None)}
+    b = {"scales": torch.tensor([0.5, 0.5]), "conv": (torch.full((2, 3), 2.0), torch.ones((2,))), "only_b": torch.tensor([7.0]),
+         "only_a": (torch.full((2,), 1.0), torch.tensor([3.0]))}
+    keep = a["conv"][0]
+    out = _sum_grads(a, b)
+    assert out is a and out["conv"][0] is keep                                   # in place: frame 0's tensors are the accumulators
+    assert torch.equal(out["scales"], torch.tensor([1.5, 2.5]))
+    assert torch.equal(out["conv"][0], torch.full((2, 3), 3.0)) and torch.equal(out["conv"][1], torch.ones((2,)))
+    assert torch.equal(out["only_b"], torch.tensor([7.0]))
+    assert torch.equal(out["only_a"][0], torch.full((2,), 6.0)) and torch.equal(out["only_a"][1], torch.tensor([3.0]))
+    # views of one buffer (agn_hm / bbox_pred are rows of the 32-channel head's gradient) are added through the view
+    buf = torch.zeros((5, 4))
+    c = {"agn_hm": (buf[0:1], None), "bbox_pred": (buf[1:5], None)}
+    d = {"agn_hm": (torch.ones((1, 4)), None), "bbox_pred": (torch.full((4, 4), 2.0), None)}
+    _sum_grads(c, d)
+    assert torch.equal(buf[0], torch.ones(4)) and torch.equal(buf[1:], torch.full((4, 4), 2.0))
